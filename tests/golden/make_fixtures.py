@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the reference's own Python (run in the build container only).
+
+The reference package cannot be imported as a package: it needs mmcv / mmdet / mmdet3d / spconv at import
+time and none is installed.  Its decoder arithmetic is torch-only, so the two files that hold
+it -- mmdet3d_plugin/core/bbox/util.py and mmdet3d_plugin/models/sparse_heads/srfdet_head.py -- are loaded
+BY PATH from /root/reference with name-only stand-ins for the missing third-party symbols (decorators that
+return the function, `BaseModule` = nn.Module, registries whose `register_module` returns the class, ...).
+No reference source is copied: this script only executes the files where they lie and stores the arrays
+they return.  Inputs and weights are regenerated on both sides from tests/golden/detgen.py, so the .npz
+files hold expected OUTPUTS only.
+
+Fixtures that run a third-party op of the reference (RoIAlign inside SingleRoIExtractor, the ConvModule of
+the DPG stair) use this repo's restatement of that op; their header entry says so ("unpinned part").
+
+usage:  python tests/golden/make_fixtures.py [--ref /root/reference]
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import detgen  # noqa: E402
+from srfdet3d_amd import synthetic  # noqa: E402
+
+NUSC_RANGE = list(synthetic.NUSC_RANGE)
+NUSC_VOXEL = [0.075, 0.075, 0.2]
+
+
+# ------------------------------------------------------------------------------------------------
+# name-only stand-ins
+# ------------------------------------------------------------------------------------------------
+def _identity_decorator_factory(*a, **k):
+    def deco(f):
+        return f
+    return deco
+
+
+class _Registry:
+    def register_module(self, *a, **k):
+        def deco(cls):
+            return cls
+        return deco
+
+
+def _raiser(name):
+    def f(*a, **k):
+        raise RuntimeError(f"stand-in for {name} was called")
+    return f
+
+
+class _BaseModule(nn.Module):
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self.init_cfg = init_cfg
+
+    def init_weights(self):
+        pass
+
+
+def _bbox2roi(bbox_list):
+    """mmdet.core.bbox2roi: prepend the sample index -> (sum n, 5)."""
+    out = []
+    for i, b in enumerate(bbox_list):
+        out.append(torch.cat([b.new_full((b.size(0), 1), i), b[:, :4]], dim=-1))
+    return torch.cat(out, 0)
+
+
+def _conv_module(in_channels, out_channels, kernel_size, stride=1, padding=0, groups=1, norm_cfg=None, **kw):
+    """mmcv ConvModule with a norm_cfg: conv(bias=False) -> BN -> ReLU (order conv, norm, act)."""
+    mod = nn.Sequential()
+    mod.add_module("conv", nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, groups=groups,
+                                     bias=norm_cfg is None))
+    if norm_cfg is not None:
+        mod.add_module("bn", nn.BatchNorm2d(out_channels, eps=norm_cfg.get("eps", 1e-5),
+                                            momentum=norm_cfg.get("momentum", 0.1)))
+    mod.add_module("activate", nn.ReLU(inplace=True))
+    return mod
+
+
+def install_stand_ins():
+    torch.Tensor.cuda = lambda self, *a, **k: self  # util.py:134,143-145 hard-code .cuda()
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("mmcv")
+    mod("mmcv.runner", force_fp32=_identity_decorator_factory, auto_fp16=_identity_decorator_factory,
+        BaseModule=_BaseModule, ModuleList=nn.ModuleList)
+    mod("mmcv.cnn", build_activation_layer=lambda cfg: nn.ReLU(inplace=cfg.get("inplace", False)),
+        ConvModule=_conv_module, build_conv_layer=_raiser("build_conv_layer"))
+    mod("mmcv.cnn.bricks")
+    mod("mmcv.cnn.bricks.transformer", build_transformer_layer_sequence=_raiser("build_transformer_layer_sequence"))
+    mod("mmcv.ops", MultiScaleDeformableAttention=type("MultiScaleDeformableAttention", (nn.Module,), {}))
+    mod("mmdet")
+    mod("mmdet.core", build_assigner=_raiser("build_assigner"), bbox2roi=_bbox2roi,
+        multi_apply=_raiser("multi_apply"), build_sampler=_raiser("build_sampler"))
+    mod("mmdet.core.utils", reduce_mean=_raiser("reduce_mean"))
+    mod("mmdet.models")
+    mod("mmdet.models.dense_heads")
+    mod("mmdet.models.dense_heads.base_dense_head", BaseDenseHead=_BaseModule)
+    mod("mmdet3d")
+    mod("mmdet3d.core", box3d_multiclass_nms=_raiser("box3d_multiclass_nms"), xywhr2xyxyr=_raiser("xywhr2xyxyr"))
+    mod("mmdet3d.models", HEADS=_Registry(), build_loss=_raiser("build_loss"), build_head=_raiser("build_head"),
+        build_roi_extractor=_raiser("build_roi_extractor"))
+    for pkg in ("mmdet3d_plugin", "mmdet3d_plugin.core", "mmdet3d_plugin.core.bbox", "mmdet3d_plugin.models",
+                "mmdet3d_plugin.models.sparse_heads"):
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+
+
+def load_reference(ref):
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ref, rel))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        return m
+
+    util = load("mmdet3d_plugin.core.bbox.util", "mmdet3d_plugin/core/bbox/util.py")
+    head = load("mmdet3d_plugin.models.sparse_heads.srfdet_head", "mmdet3d_plugin/models/sparse_heads/srfdet_head.py")
+    return util, head
+
+
+# ------------------------------------------------------------------------------------------------
+# shared deterministic inputs (the tests call these too)
+# ------------------------------------------------------------------------------------------------
+def det_boxes(name, P, bs=1):
+    """(bs,P,10): centres in (0,1), log sizes, sin/cos of a yaw, velocities."""
+    c = detgen.det_uniform(name + ".ctr", (bs, P, 3), 0.05, 0.95)
+    size = np.log(detgen.det_uniform(name + ".size", (bs, P, 3), 0.5, 6.0))
+    yaw = detgen.det_uniform(name + ".yaw", (bs, P, 1), -np.pi, np.pi)
+    vel = detgen.det(name + ".vel", (bs, P, 2))
+    return np.concatenate([c, size, np.sin(yaw), np.cos(yaw), vel], -1).astype(np.float32)
+
+
+class RecordingPooler:
+    """Stands where the RoI extractor is called; returns a fixed tensor and keeps the RoIs it was asked for."""
+    num_inputs = 4
+
+    def __init__(self, out):
+        self.out = out
+        self.rois = None
+
+    def __call__(self, feats, rois):
+        self.rois = rois.detach().clone()
+        return self.out.clone()
+
+
+class OraclePooler:
+    """SingleRoIExtractor restated by oracle/oracle.py (unpinned part of the fixtures that use it)."""
+    num_inputs = 4
+
+    def __init__(self, strides):
+        from oracle import oracle as O
+        self.O = O
+        self.strides = strides
+        self.rois = []
+
+    def __call__(self, feats, rois):
+        self.rois.append(rois.detach().clone().numpy())
+        out, _ = self.O.roi_extract([f.detach().numpy() for f in feats], rois.detach().numpy(), self.strides)
+        return torch.from_numpy(out)
+
+
+STAGE_KW = dict(num_classes=10, feat_channels=128, pooler_resolution=7, dim_feedforward=512, num_cls_convs=2,
+                num_reg_convs=3, num_heads=8, dropout=0.1, dynamic_conv=dict(dynamic_dim=32, dynamic_num=2),
+                pc_range=NUSC_RANGE, voxel_size=NUSC_VOXEL)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    args = ap.parse_args()
+    install_stand_ins()
+    util, head = load_reference(args.ref)
+    torch.manual_seed(0)
+    out = {}
+    t = torch.from_numpy
+
+    # ---- box utilities: mmdet3d_plugin/core/bbox/util.py:4-38, :41-81, :84-176
+    P = 48
+    boxes = det_boxes("boxutil.boxes", P)
+    b_abs = boxes.copy()
+    b_abs[..., :3] = b_abs[..., :3] * 100.0 - 50.0
+    out["corners3d"] = util.boxes3d_to_corners3d(t(b_abs[..., :8].copy()), bottom_center=False, ry=False).numpy()
+    den = util.denormalize_bbox(t(b_abs[0].copy()), NUSC_RANGE)
+    out["denormalize"] = den.numpy()
+    out["normalize"] = util.normalize_bbox(den.clone(), NUSC_RANGE).numpy()
+
+    # ---- DynamicConv: srfdet_head.py:2633-2693
+    dc = head.DynamicConv(feat_channels=128, dynamic_dim=32, dynamic_num=2, pooler_resolution=7).eval()
+    detgen.load_det_params(dc, "dynconv.")
+    with torch.no_grad():
+        out["dynconv"] = dc(t(detgen.det("dynconv.prop", (1, P, 128))), t(detgen.det("dynconv.roi", (49, P, 128)))).numpy()
+
+    # ---- one LiDAR stage: srfdet_head.py:1455-1532 (+ geometry :1627-1689, deltas :1534-1625)
+    st = head.SingleSRFDetHeadLiDAR(**STAGE_KW).eval()
+    detgen.load_det_params(st, "lstage.")
+    bx = t(det_boxes("lstage.boxes", P))
+    pooler = RecordingPooler(t(detgen.det("lstage.roi_feats", (P, 128, 7, 7))))
+    with torch.no_grad():
+        logits, pred, obj = st([None] * 4, bx, t(detgen.det("lstage.prop", (1, P, 128))), pooler, None)
+    out["lstage.rois"] = pooler.rois.numpy()
+    out["lstage.boxes_after"] = bx.numpy()  # centres overwritten in place with metres (srfdet_head.py:1646)
+    out["lstage.logits"], out["lstage.pred"], out["lstage.obj"] = logits.numpy(), pred.numpy(), obj.numpy()
+
+    # ---- apply_deltas alone, including the clamp branch: srfdet_head.py:1534-1625
+    deltas = detgen.det("deltas.d", (P, 10), scale=0.5)
+    deltas[:4, 3:6] = 12.0  # above log(100000/16): exercises the scale clamp (:1580-1582)
+    with torch.no_grad():
+        out["apply_deltas"] = st.apply_deltas_lidar(t(deltas), t(b_abs[0].copy())).numpy()
+
+    # ---- one fusion stage: srfdet_head.py:2221-2329, image geometry :2424-2566
+    fs = head.SingleSRFDetHead(use_fusion=True, **STAGE_KW).eval()
+    detgen.load_det_params(fs, "fstage.")
+    bx = t(det_boxes("fstage.boxes", P))
+    l2i = synthetic.camera_rig()
+    metas = [dict(lidar2img=[m for m in l2i])]
+    img_feats = [torch.zeros(1, 6, 128, 2, 2) for _ in range(4)]
+    pl = RecordingPooler(t(detgen.det("fstage.roi_lidar", (P, 128, 7, 7))))
+    pi = RecordingPooler(t(detgen.det("fstage.roi_img", (6 * P, 128, 7, 7))))
+    with torch.no_grad():
+        logits, pred, obj = fs(img_feats, [None] * 4, bx, t(detgen.det("fstage.prop", (1, P, 128))), pl, metas,
+                               pooler_img=pi)
+    out["fstage.rois_img"], out["fstage.rois_lidar"] = pi.rois.numpy(), pl.rois.numpy()
+    out["fstage.logits"], out["fstage.pred"], out["fstage.obj"] = logits.numpy(), pred.numpy(), obj.numpy()
+
+    # ---- decode up to the NMS call: srfdet_head.py:1227-1293
+    captured = {}
+
+    class _Boxes:
+        def __init__(self, tensor, box_dim=9):
+            self.tensor = tensor
+
+        @property
+        def bev(self):
+            return self.tensor[:, [0, 1, 3, 4, 6]]
+
+    def _nms(b, b_nms, scores, thr, mx, cfg):
+        captured["boxes"], captured["scores"] = b.clone(), scores.clone()
+        return b[:0], scores[:0, 0], scores[:0, 0].long()
+
+    head.xywhr2xyxyr = lambda x: x
+    head.box3d_multiclass_nms = _nms
+    dh = object.__new__(head.SRFDetHead)
+    nn.Module.__init__(dh)
+    dh.use_focal_loss, dh.use_fed_loss, dh.use_nms, dh.num_classes = True, False, True, 10
+    dh.pc_range = NUSC_RANGE
+
+    class _Cfg(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+    dh.test_cfg = _Cfg(score_thr=0.1, max_per_img=300, post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0])
+    with torch.no_grad():
+        dh.get_bboxes(t(detgen.det("decode.logits", (5, 1, P, 10))), t(b_abs[None].repeat(5, 0).copy()),
+                      [dict(box_type_3d=_Boxes)])
+    out["decode.boxes"], out["decode.scores"] = captured["boxes"].numpy(), captured["scores"].numpy()
+
+    # ---- DPG proposals + full 5-stage head loop (LiDAR): srfdet_head.py:379-504, :506-655
+    # unpinned parts: ConvModule stand-in (conv -> BN2d -> ReLU) and oracle RoIAlign/SingleRoIExtractor.
+    Pn = 32
+    hd = object.__new__(head.SRFDetHead)
+    nn.Module.__init__(hd)
+    hd.use_img, hd.with_lidar_encoder, hd.with_dpg, hd.deep_supervision = False, False, True, True
+    hd.num_dpg_exp, hd.num_proposals, hd.feat_channels_lidar, hd.lidar_feat_lvls = 4, Pn, 128, 4
+    hd.hidden_dim, hd.feat_channels_img = 128, 256
+    hd.grid_size, hd.out_size_factor, hd.pc_range = [1472, 1472, 40], 8, NUSC_RANGE
+    hd.code_weights = [1.0] * 8 + [0.2, 0.2]
+    hd._build_dynamic_prop_gen()
+    hd.head_series_lidar = nn.ModuleList([head.SingleSRFDetHeadLiDAR(**STAGE_KW) for _ in range(5)])
+    hd.eval()
+    detgen.load_det_params(hd, "head.")
+    feats = [t(detgen.det(f"head.feat{i}", (1, 128, s, s), scale=0.5)) for i, s in enumerate((184, 92, 46, 23))]
+    hd.roi_extractor_lidar = OraclePooler([8, 16, 32, 64])
+    with torch.no_grad():
+        ib, ifeat = hd._get_init_proposals(None, feats)
+        out["head.init_boxes"], out["head.init_feats"] = ib.numpy().copy(), ifeat.numpy().copy()
+        lg, bxs = hd(None, feats, None)
+    out["head.logits"], out["head.boxes"] = lg.numpy(), bxs.numpy()
+    out["head.rois"] = np.stack(hd.roi_extractor_lidar.rois, 0)
+
+    path = os.path.join(HERE, "decoder_nusc.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()
