@@ -1,0 +1,171 @@
+/*
+ * srfdet3d.h -- C ABI of libsrfdet3d_hip.so, the MI355X (gfx950) implementation of the SRFDet3D hot path.
+ *
+ * The reference (gopi-erabati/SRFDet3D) has no native code and no FFI of its own: its Python reaches the
+ * operators below through third-party CUDA wheels (mmcv-full 1.7.0, mmdet 2.28.2, mmdet3d 1.0.0rc6,
+ * spconv).  Each entry point cites the reference call site whose operator it replaces; the Python binding a
+ * maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions:
+ *   - plain C types only; every pointer is a DEVICE pointer borrowed from the caller unless marked "host";
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised here;
+ *   - the library never allocates, frees or retains memory: outputs and workspaces come from the caller,
+ *     sized with the *_workspace_bytes / *_capacity helpers (host-side, pure functions);
+ *   - data-dependent sizes (voxel count, active-site count) are written to a device int the caller reads
+ *     back when it needs the value on the host;
+ *   - return value: 0 on success, negative on error (srf_error_string); no exceptions, no exit();
+ *   - re-entrant, no global mutable state.
+ */
+#ifndef SRFDET3D_H
+#define SRFDET3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *srf_stream_t;
+
+#define SRF_OK 0
+#define SRF_EINVAL (-1)       /* bad argument (null pointer, non-positive size, unsupported shape) */
+#define SRF_EWORKSPACE (-2)   /* workspace smaller than *_workspace_bytes() */
+#define SRF_EUNSUPPORTED (-3) /* channel count / kernel size outside the compiled set */
+#define SRF_EHIP_BASE (-1000) /* -(1000 + hipError_t) */
+
+int srf_abi_version(void);
+const char *srf_error_string(int code);
+/* Number of HIP devices visible, or a negative error.  Used by the Python loader to fail loudly. */
+int srf_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K2  dynamic voxelization.
+ * Replaces mmcv.ops.Voxelization(max_num_points=-1).forward as called from SRFDet.voxelize,
+ * mmdet3d_plugin/models/detectors/srfdet.py:233-247.
+ * coors: (n,3) int32 rows (z,y,x), (-1,-1,-1) for points outside the range.  grid = (gx,gy,gz).
+ * ------------------------------------------------------------------------------------------------------- */
+int srf_dynamic_voxelize(const float *points, int n, int nf, const float *voxel_size /*host[3]*/,
+                         const float *pc_range /*host[6]*/, const int *grid /*host[3] x,y,z*/, int *coors,
+                         srf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K1  hard voxelization (+ a3 HardSimpleVFE mean, fused).
+ * Replaces mmcv.ops.Voxelization(max_num_points>0, deterministic=True).forward as called from
+ * SRFDet.voxelize, srfdet.py:218-232 (module built at srfdet.py:58), and the HardSimpleVFE of
+ * configs/nus/srfdet_voxel_nusc_L.py:40.
+ * Outputs in first-seen voxel order: voxels (rows x max_points x nf, unused slots zero), coors (rows x 3,
+ * z,y,x), num (rows), voxel_num (1 int).  rows = min(n, max_voxels) must be allocated; only the first
+ * *voxel_num rows are written.  mean (rows x mean_features) may be NULL.
+ * ------------------------------------------------------------------------------------------------------- */
+size_t srf_hard_voxelize_workspace_bytes(int n, int max_points);
+int srf_hard_voxelize(const float *points, int n, int nf, const float *voxel_size /*host[3]*/,
+                      const float *pc_range /*host[6]*/, const int *grid /*host[3]*/, int max_points, int max_voxels,
+                      float *voxels, int *coors, int *num, int *voxel_num, float *mean, int mean_features,
+                      void *workspace, size_t workspace_bytes, srf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K3  DynamicScatter, split in its two halves so that a caller can reuse the point->voxel map.
+ * Replaces mmcv.ops.DynamicScatter.forward as called from
+ * mmdet3d_plugin/models/voxel_encoders/voxel_encoder.py:189 (mean) and :232 (max), and the dense canvas of
+ * map_voxel_center_to_point (:118-158).
+ * srf_voxel_unique: coors (n,4) int32 (b,z,y,x); rows with any negative entry are dropped.  Outputs, all
+ *   caller-allocated with n rows: out_coors (n x 4, first *num_voxels rows valid, sorted lexicographically),
+ *   point2voxel (n; -1 for dropped points), counts (n; points per voxel), offsets (n; start of each voxel's
+ *   list in `order`), order (n; point indices grouped by voxel, ascending within a voxel), num_voxels (1 int).
+ * srf_scatter_reduce: out (rows x C), rows >= *num_voxels; mode 0 = mean (sum in point order / count),
+ *   1 = max.
+ * ------------------------------------------------------------------------------------------------------- */
+size_t srf_voxel_unique_workspace_bytes(int n, const int *grid_zyx /*host[3] D,H,W*/, int batch);
+int srf_voxel_unique(const int *coors, int n, const int *grid_zyx /*host[3]*/, int batch, int *out_coors,
+                     int *point2voxel, int *counts, int *offsets, int *order, int *num_voxels, void *workspace,
+                     size_t workspace_bytes, srf_stream_t stream);
+int srf_scatter_reduce(const float *feats, const int *order, const int *offsets, const int *counts,
+                       const int *num_voxels, int rows, int C, int mode, float *out, srf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K4  sparse-conv rulebooks.
+ * Replaces spconv's indice-pair generation behind SparseConvTensor / SubMConv3d / SparseConv3d as used by
+ * SparseEncoderCustom, mmdet3d_plugin/models/middle_encoders/sparse_encoder_custom.py:123-134 (layers built
+ * at :73-107, :182-201).
+ * A coordinate table maps (b,z,y,x) -> row.  The rulebook is output-stationary:
+ * nbr[k * nbr_stride + o] = input row feeding output row o through kernel offset k, or -1;
+ * k = (kz*KH + ky)*KW + kx.  pair_counts[k] = number of valid pairs of offset k.
+ * Strided convs number their output rows in first-seen order over (input row, k) ascending.
+ * ------------------------------------------------------------------------------------------------------- */
+int srf_coord_table_capacity(int max_rows); /* power of two >= 2*max_rows */
+size_t srf_coord_table_bytes(int capacity);
+int srf_coord_table_build(const int *indices /* A x 4 */, int A, const int *shape /*host[3] D,H,W*/, int batch,
+                          void *table, int capacity, srf_stream_t stream);
+int srf_rulebook_subm(const int *indices, int A, const int *shape /*host[3]*/, const int *ksize /*host[3]*/,
+                      const void *table, int capacity, int *nbr /* K x A */, int *pair_counts /* K */,
+                      srf_stream_t stream);
+/* bound on the outputs of a strided conv: A * prod(ceil(k/s)), clipped to the output volume */
+int srf_strided_max_outputs(int A, int batch, const int *shape, const int *ksize, const int *stride, const int *pad);
+size_t srf_rulebook_strided_workspace_bytes(int A, const int *ksize /*host[3]*/, int out_capacity);
+/* phase 1: discover and number the outputs; builds the coordinate table of the output level */
+int srf_rulebook_strided_outputs(const int *indices, int A, const int *shape, int batch, const int *ksize,
+                                 const int *stride, const int *pad, int *out_indices /* max_out x 4 */,
+                                 int *num_out /* 1 int */, void *out_table, int out_capacity, void *workspace,
+                                 size_t workspace_bytes, srf_stream_t stream);
+/* phase 2: fill nbr (K x num_out_host, caller-allocated after reading num_out) from the same workspace */
+int srf_rulebook_strided_pairs(int A, const int *ksize, const void *out_table, int out_capacity,
+                               const void *workspace, int num_out_host, int *nbr, int *pair_counts,
+                               srf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K5  sparse convolution forward with fused eval-BatchNorm / residual / ReLU epilogue.
+ * Replaces spconv SubMConv3d/SparseConv3d.forward (+ the BN1d and ReLU modules chained by mmdet3d's
+ * make_sparse_convmodule / SparseBasicBlock) on the path sparse_encoder_custom.py:125-134.
+ * out[o] = sum_k W[k]^T in[nbr[k][o]] accumulated as an f32 fma chain (k ascending, c ascending);
+ * then y = fma(x, alpha, beta) if alpha, y += residual[o] if residual, y = max(y,0) if relu.
+ * W: (K, Cin, Cout) row-major.  Supported Cout: 16, 32, 64, 128; Cin: 1..128.
+ * ------------------------------------------------------------------------------------------------------- */
+int srf_spconv_fwd(const float *in, int A_in, int Cin, const float *W, int K, const int *nbr, int nbr_stride,
+                   int A_out, int Cout, const float *alpha, const float *beta, const float *residual, int relu,
+                   float *out, srf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K6  SparseConvTensor.dense() (+ the view to (B, C*D, H, W), which is a no-op on this layout).
+ * Replaces sparse_encoder_custom.py:135-138.  out: (B, C, D, H, W) contiguous; zero_fill != 0 clears it first.
+ * ------------------------------------------------------------------------------------------------------- */
+int srf_densify(const float *feats, const int *indices, int A, int C, int B, int D, int H, int W, float *out,
+                int zero_fill, srf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * K7  RoIAlign(avg, aligned) behind mmdet SingleRoIExtractor.
+ * Replaces pooler(feats[:4], rois) at mmdet3d_plugin/models/sparse_heads/srfdet_head.py:1685, :2548, :2626
+ * (config configs/nus/srfdet_voxel_nusc_LC.py:169-178).
+ * Feature maps are described by element strides so that NCHW and channels-last tensors both work.
+ * out element (r, c, bin) is written at out[r*out_stride_r + c*out_stride_c + bin*out_stride_bin];
+ * accumulate != 0 adds into out instead of overwriting it (camera sum, srfdet_head.py:2561).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float *data;
+    int N, H, W;
+    int64_t stride_n, stride_c, stride_h, stride_w; /* in elements */
+    float spatial_scale;                            /* 1 / featmap stride */
+} srf_featmap;
+
+int srf_roi_extract(const srf_featmap *levels /*host[num_levels]*/, int num_levels, int C, const float *rois /* R x 5 */,
+                    int R, int pooled, int sampling_ratio, float finest_scale, float *out, int64_t out_stride_r,
+                    int64_t out_stride_c, int64_t out_stride_bin, int accumulate, int *levels_out /* R or NULL */,
+                    srf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a11-a13  proposal box -> RoI geometry, fused.
+ * Replaces the torch op chains of points_feats_sampling_bboxes_roi (srfdet_head.py:1638-1683 / :2579-2624)
+ * and img_feats_sampling_bboxes_roi (:2435-2528), including boxes3d_to_corners3d
+ * (mmdet3d_plugin/core/bbox/util.py:84-176).
+ * boxes: (B, P, box_dim >= 8).  mutate_centres != 0 overwrites boxes[..., :3] with metres in place, as
+ * srfdet_head.py:1646 does.  rois_bev: (B*P, 5).  rois_img: (n_cam*B*P, 5), cam-major, batch id b + cam*B
+ * (the reference's indexing, :2520-2528); lidar2img: (B, n_cam, 4, 4) row-major.  Either output may be NULL.
+ * ------------------------------------------------------------------------------------------------------- */
+int srf_box_rois(float *boxes, int B, int P, int box_dim, const float *pc_range /*host[6]*/,
+                 const float *voxel_size /*host[3]*/, int mutate_centres, float *rois_bev, const float *lidar2img,
+                 int n_cam, float *rois_img, srf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRFDET3D_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of libsrfdet3d_hip.so (the C ABI declared in include/srfdet3d.h).
+
+There is no CPU fallback: if the library is missing or an op is handed a non-GPU tensor this module raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrfdet3d_hip.so")
+
+_lib = None
+
+
+class FeatMap(ctypes.Structure):
+    """srf_featmap of include/srfdet3d.h."""
+    _fields_ = [("data", c_void_p), ("N", c_int), ("H", c_int), ("W", c_int),
+                ("stride_n", c_int64), ("stride_c", c_int64), ("stride_h", c_int64), ("stride_w", c_int64),
+                ("spatial_scale", c_float)]
+
+
+_P = c_void_p
+_HF = POINTER(c_float)  # host float array
+_HI = POINTER(c_int)    # host int array
+
+# name -> (restype, argtypes); must list every symbol include/srfdet3d.h declares
+SIGNATURES = {
+    "srf_abi_version": (c_int, []),
+    "srf_error_string": (c_char_p, [c_int]),
+    "srf_device_count": (c_int, []),
+    "srf_dynamic_voxelize": (c_int, [_P, c_int, c_int, _HF, _HF, _HI, _P, _P]),
+    "srf_hard_voxelize_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "srf_hard_voxelize": (c_int, [_P, c_int, c_int, _HF, _HF, _HI, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P,
+                                  c_size_t, _P]),
+    "srf_voxel_unique_workspace_bytes": (c_size_t, [c_int, _HI, c_int]),
+    "srf_voxel_unique": (c_int, [_P, c_int, _HI, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "srf_scatter_reduce": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "srf_coord_table_capacity": (c_int, [c_int]),
+    "srf_coord_table_bytes": (c_size_t, [c_int]),
+    "srf_coord_table_build": (c_int, [_P, c_int, _HI, c_int, _P, c_int, _P]),
+    "srf_rulebook_subm": (c_int, [_P, c_int, _HI, _HI, _P, c_int, _P, _P, _P]),
+    "srf_strided_max_outputs": (c_int, [c_int, c_int, _HI, _HI, _HI, _HI]),
+    "srf_rulebook_strided_workspace_bytes": (c_size_t, [c_int, _HI, c_int]),
+    "srf_rulebook_strided_outputs": (c_int, [_P, c_int, _HI, c_int, _HI, _HI, _HI, _P, _P, _P, c_int, _P, c_size_t,
+                                             _P]),
+    "srf_rulebook_strided_pairs": (c_int, [c_int, _HI, _P, c_int, _P, c_int, _P, _P, _P]),
+    "srf_spconv_fwd": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
+    "srf_densify": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "srf_roi_extract": (c_int, [POINTER(FeatMap), c_int, c_int, _P, c_int, c_int, c_int, c_float, _P, c_int64,
+                                c_int64, c_int64, c_int, _P, _P]),
+    "srf_box_rois": (c_int, [_P, c_int, c_int, c_int, _HF, _HF, c_int, _P, _P, c_int, _P, _P]),
+}
+
+
+def lib():
+    """The loaded library; raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -m srfdet3d_amd.build` "
+                "(or __graft_entry__.build()). srfdet3d_amd has no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name, None)
+            if fn is None:
+                raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it")
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, op):
+    if rc != 0:
+        msg = lib().srf_error_string(rc)
+        raise RuntimeError(f"srfdet3d {op} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def hf(values):
+    return (c_float * len(values))(*[float(v) for v in values])
+
+
+def hi(values):
+    return (c_int * len(values))(*[int(v) for v in values])

@@ -1,0 +1,315 @@
+// rulebook.hip -- K4: coordinate tables and output-stationary rulebooks for SubM and strided sparse convs (gfx950).
+//
+// Reference call sites: SparseConvTensor / SubMConv3d / SparseConv3d as used by SparseEncoderCustom,
+// mmdet3d_plugin/models/middle_encoders/sparse_encoder_custom.py:123-134 (layers built at :73-107, :182-201);
+// spconv semantics in SURVEY.md Appendix B.4.
+//
+// Layout in HBM.  A coordinate table is keys[cap] (uint32 linearised (b,z,y,x)) followed by rows[cap] (int32);
+// it stays resident in L2 (<= a few MB per level).  A rulebook is nbr[K][A_out] int32: the input row that
+// feeds output row o through kernel offset k, or -1 -- one coalesced int per (k, o), no atomics at conv time,
+// and the conv accumulates in a fixed (k, c) order.
+//
+// Strided convs discover their outputs from the inputs.  To make the numbering of the new active set
+// independent of atomics, every candidate (input row i, offset k) that lands on output q lowers
+// mincand[slot(q)] with atomicMin; an exclusive scan over the flags "candidate == mincand of its slot" numbers
+// the outputs in first-seen order over (i, k) ascending -- the order a sequential build produces.
+// pair_counts are accumulated per block in LDS and flushed with one atomic per (block, k).
+#include "common.hpp"
+
+#define SRF_MAX_K 27
+
+struct ConvGeom {
+    int shape[3];   // input D,H,W
+    int oshape[3];  // output D,H,W
+    int ks[3], st[3], pd[3];
+    int K;
+};
+
+__device__ __forceinline__ uint32_t srf_coord_key(int b, int z, int y, int x, const int *shape)
+{
+    return (((uint32_t)b * (uint32_t)shape[0] + (uint32_t)z) * (uint32_t)shape[1] + (uint32_t)y) * (uint32_t)shape[2] +
+           (uint32_t)x;
+}
+
+__global__ __launch_bounds__(256) void srf_table_build_k(const int4 *__restrict__ indices, int A, ConvGeom g,
+                                                       uint32_t *keys, int *rows, uint32_t mask)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A) return;
+    int4 c = indices[i];
+    int s = srf_table_insert(keys, mask, srf_coord_key(c.x, c.y, c.z, c.w, g.shape));
+    if (s >= 0) rows[s] = i;
+}
+
+__global__ __launch_bounds__(256) void srf_subm_k(const int4 *__restrict__ indices, int A, ConvGeom g,
+                                                const uint32_t *__restrict__ keys, const int *__restrict__ rows,
+                                                uint32_t mask, int *__restrict__ nbr, int *pair_counts)
+{
+    __shared__ int hist[SRF_MAX_K];
+    if (threadIdx.x < SRF_MAX_K) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int k = (int)(tid / A);
+    const int o = (int)(tid % A);
+    if (k < g.K) {
+        int4 c = indices[o];
+        int kx = k % g.ks[2], t = k / g.ks[2];
+        int ky = t % g.ks[1], kz = t / g.ks[1];
+        int z = c.y + kz - g.ks[0] / 2, y = c.z + ky - g.ks[1] / 2, x = c.w + kx - g.ks[2] / 2;
+        int v = -1;
+        if (z >= 0 && z < g.shape[0] && y >= 0 && y < g.shape[1] && x >= 0 && x < g.shape[2]) {
+            int s = srf_table_find(keys, mask, srf_coord_key(c.x, z, y, x, g.shape));
+            if (s >= 0) v = rows[s];
+        }
+        nbr[(size_t)k * A + o] = v;
+        if (v >= 0) atomicAdd(&hist[k], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < g.K && hist[threadIdx.x]) atomicAdd(&pair_counts[threadIdx.x], hist[threadIdx.x]);
+}
+
+// candidate c = i*K + k -> output coordinate, or false
+__device__ __forceinline__ bool srf_candidate(const int4 &ci, int k, const ConvGeom &g, int q[3])
+{
+    int kk[3];
+    kk[2] = k % g.ks[2];
+    int t = k / g.ks[2];
+    kk[1] = t % g.ks[1];
+    kk[0] = t / g.ks[1];
+    const int p[3] = {ci.y, ci.z, ci.w};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int v = p[d] + g.pd[d] - kk[d];
+        if (v < 0 || v % g.st[d] != 0) return false;
+        q[d] = v / g.st[d];
+        if (q[d] >= g.oshape[d]) return false;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void srf_strided_insert_k(const int4 *__restrict__ indices, int A, ConvGeom g,
+                                                          uint32_t *okeys, uint32_t omask, int *mincand,
+                                                          int *__restrict__ cand_slot)
+{
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= (long long)A * g.K) return;
+    const int i = (int)(c / g.K), k = (int)(c % g.K);
+    int4 ci = indices[i];
+    int q[3];
+    int slot = -1;
+    if (srf_candidate(ci, k, g, q)) {
+        slot = srf_table_insert(okeys, omask, srf_coord_key(ci.x, q[0], q[1], q[2], g.oshape));
+        if (slot >= 0) atomicMin(&mincand[slot], (int)c);
+    }
+    cand_slot[c] = slot;
+}
+
+struct StridedFlag {
+    const int *cand_slot;
+    const int *mincand;
+    __device__ int operator()(int c) const
+    {
+        int s = cand_slot[c];
+        return (s >= 0 && mincand[s] == c) ? 1 : 0;
+    }
+};
+
+struct StridedAssign {
+    const int4 *indices;
+    const int *cand_slot;
+    int *orows;
+    int4 *out_indices;
+    ConvGeom g;
+    __device__ void operator()(int c, int v, int prefix) const
+    {
+        if (!v) return;
+        const int i = c / g.K, k = c % g.K;
+        int4 ci = indices[i];
+        int q[3];
+        srf_candidate(ci, k, g, q);
+        orows[cand_slot[c]] = prefix;
+        out_indices[prefix] = make_int4(ci.x, q[0], q[1], q[2]);
+    }
+};
+
+__global__ __launch_bounds__(256) void srf_strided_fill_k(int A, int K, const int *__restrict__ cand_slot,
+                                                        const int *__restrict__ orows, int num_out,
+                                                        int *__restrict__ nbr, int *pair_counts)
+{
+    __shared__ int hist[SRF_MAX_K];
+    if (threadIdx.x < SRF_MAX_K) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c < (long long)A * K) {
+        int s = cand_slot[c];
+        if (s >= 0) {
+            const int i = (int)(c / K), k = (int)(c % K);
+            int m = orows[s];
+            if (m >= 0 && m < num_out) {
+                nbr[(size_t)k * num_out + m] = i;
+                atomicAdd(&hist[k], 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < K && hist[threadIdx.x]) atomicAdd(&pair_counts[threadIdx.x], hist[threadIdx.x]);
+}
+
+static bool srf_fill_conv_geom(ConvGeom &g, const int *shape, const int *ksize, const int *stride, const int *pad,
+                               int batch)
+{
+    g.K = 1;
+    unsigned long long vol = (unsigned long long)(batch > 0 ? batch : 1), ovol = vol;
+    for (int d = 0; d < 3; ++d) {
+        g.shape[d] = shape[d];
+        g.ks[d] = ksize[d];
+        g.st[d] = stride ? stride[d] : 1;
+        g.pd[d] = pad ? pad[d] : ksize[d] / 2;
+        if (shape[d] <= 0 || ksize[d] <= 0 || g.st[d] <= 0 || g.pd[d] < 0) return false;
+        g.oshape[d] = (shape[d] + 2 * g.pd[d] - ksize[d]) / g.st[d] + 1;
+        if (g.oshape[d] <= 0) return false;
+        g.K *= ksize[d];
+        vol *= (unsigned long long)shape[d];
+        ovol *= (unsigned long long)g.oshape[d];
+    }
+    return g.K <= SRF_MAX_K && vol < 0xFFFFFFFFull && ovol < 0xFFFFFFFFull;
+}
+
+extern "C" int srf_coord_table_capacity(int max_rows)
+{
+    int cap = 1024;
+    while (cap < 2 * max_rows && cap < (1 << 30)) cap <<= 1;
+    return cap;
+}
+
+extern "C" size_t srf_coord_table_bytes(int capacity) { return (size_t)capacity * 8; }
+
+extern "C" int srf_coord_table_build(const int *indices, int A, const int *shape, int batch, void *table, int capacity,
+                                     srf_stream_t stream)
+{
+    if (A < 0 || !shape || !table || capacity < 1024 || (capacity & (capacity - 1)) || capacity < 2 * A) return SRF_EINVAL;
+    const int one[3] = {1, 1, 1};
+    ConvGeom g;
+    if (!srf_fill_conv_geom(g, shape, one, one, nullptr, batch)) return SRF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    SRF_HIP_TRY(hipMemsetAsync(table, 0xFF, (size_t)capacity * 8, st));
+    if (A == 0) return SRF_OK;
+    if (!indices) return SRF_EINVAL;
+    uint32_t *keys = (uint32_t *)table;
+    int *rows = (int *)(keys + capacity);
+    hipLaunchKernelGGL(srf_table_build_k, dim3(srf_ceil_div(A, 256)), dim3(256), 0, st, (const int4 *)indices, A, g, keys,
+                       rows, (uint32_t)(capacity - 1));
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+extern "C" int srf_rulebook_subm(const int *indices, int A, const int *shape, const int *ksize, const void *table,
+                                 int capacity, int *nbr, int *pair_counts, srf_stream_t stream)
+{
+    if (A < 0 || !shape || !ksize || !table || !pair_counts || (capacity & (capacity - 1))) return SRF_EINVAL;
+    ConvGeom g;
+    const int one[3] = {1, 1, 1};
+    if (!srf_fill_conv_geom(g, shape, ksize, one, nullptr, 1)) return SRF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    SRF_HIP_TRY(hipMemsetAsync(pair_counts, 0, sizeof(int) * g.K, st));
+    if (A == 0) return SRF_OK;
+    if (!indices || !nbr) return SRF_EINVAL;
+    const uint32_t *keys = (const uint32_t *)table;
+    const int *rows = (const int *)(keys + capacity);
+    hipLaunchKernelGGL(srf_subm_k, dim3(srf_ceil_div((long long)A * g.K, 256)), dim3(256), 0, st, (const int4 *)indices, A,
+                       g, keys, rows, (uint32_t)(capacity - 1), nbr, pair_counts);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+extern "C" int srf_strided_max_outputs(int A, int batch, const int *shape, const int *ksize, const int *stride,
+                                       const int *pad)
+{
+    ConvGeom g;
+    if (A < 0 || !srf_fill_conv_geom(g, shape, ksize, stride, pad, batch)) return SRF_EINVAL;
+    long long per = 1, vol = batch > 0 ? batch : 1;
+    for (int d = 0; d < 3; ++d) {
+        per *= (g.ks[d] + g.st[d] - 1) / g.st[d];
+        vol *= g.oshape[d];
+    }
+    long long b = (long long)A * per;
+    if (b > vol) b = vol;
+    if (b > 0x3FFFFFFF) return SRF_EINVAL;
+    return (int)b;
+}
+
+// workspace:  cand_slot[A*K] | mincand[out_capacity] | partial[scan_blocks(A*K)+1]
+static size_t srf_strided_ws_layout(int A, int K, int cap, size_t *off_min, size_t *off_partial)
+{
+    size_t b = srf_align256((size_t)(A > 0 ? A : 1) * K * 4);
+    *off_min = b;
+    b += srf_align256((size_t)cap * 4);
+    *off_partial = b;
+    b += srf_align256((size_t)(srf_scan_blocks((long long)A * K) + 1) * 4);
+    return b;
+}
+
+extern "C" size_t srf_rulebook_strided_workspace_bytes(int A, const int *ksize, int out_capacity)
+{
+    if (A < 0 || !ksize || out_capacity <= 0) return 0;
+    int K = ksize[0] * ksize[1] * ksize[2];
+    size_t o1, o2;
+    return srf_strided_ws_layout(A, K, out_capacity, &o1, &o2);
+}
+
+extern "C" int srf_rulebook_strided_outputs(const int *indices, int A, const int *shape, int batch, const int *ksize,
+                                            const int *stride, const int *pad, int *out_indices, int *num_out,
+                                            void *out_table, int out_capacity, void *workspace, size_t workspace_bytes,
+                                            srf_stream_t stream)
+{
+    if (A < 0 || !shape || !ksize || !stride || !pad || !num_out || !out_table || !workspace) return SRF_EINVAL;
+    if (out_capacity < 1024 || (out_capacity & (out_capacity - 1))) return SRF_EINVAL;
+    ConvGeom g;
+    if (!srf_fill_conv_geom(g, shape, ksize, stride, pad, batch)) return SRF_EINVAL;
+    int bound = srf_strided_max_outputs(A, batch, shape, ksize, stride, pad);
+    if (bound < 0 || out_capacity < 2 * bound) return SRF_EINVAL;
+    size_t off_min, off_partial;
+    size_t need = srf_strided_ws_layout(A, g.K, out_capacity, &off_min, &off_partial);
+    if (workspace_bytes < need) return SRF_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *okeys = (uint32_t *)out_table;
+    int *orows = (int *)(okeys + out_capacity);
+    int *cand_slot = (int *)workspace;
+    int *mincand = (int *)((char *)workspace + off_min);
+    int *partial = (int *)((char *)workspace + off_partial);
+    SRF_HIP_TRY(hipMemsetAsync(out_table, 0xFF, (size_t)out_capacity * 8, st));
+    SRF_HIP_TRY(hipMemsetAsync(mincand, 0x7F, (size_t)out_capacity * 4, st));
+    if (A == 0) {
+        SRF_HIP_TRY(hipMemsetAsync(num_out, 0, sizeof(int), st));
+        return SRF_OK;
+    }
+    if (!indices || !out_indices) return SRF_EINVAL;
+    const long long nc = (long long)A * g.K;
+    if (nc > 0x7F000000) return SRF_EINVAL;
+    hipLaunchKernelGGL(srf_strided_insert_k, dim3(srf_ceil_div(nc, 256)), dim3(256), 0, st, (const int4 *)indices, A, g,
+                       okeys, (uint32_t)(out_capacity - 1), mincand, cand_slot);
+    SRF_LAUNCH_CHECK();
+    StridedFlag flag{cand_slot, mincand};
+    StridedAssign assign{(const int4 *)indices, cand_slot, orows, (int4 *)out_indices, g};
+    return srf_device_scan((int)nc, flag, assign, partial, num_out, -1, st);
+}
+
+extern "C" int srf_rulebook_strided_pairs(int A, const int *ksize, const void *out_table, int out_capacity,
+                                          const void *workspace, int num_out_host, int *nbr, int *pair_counts,
+                                          srf_stream_t stream)
+{
+    if (A < 0 || !ksize || !out_table || !workspace || !pair_counts || num_out_host < 0) return SRF_EINVAL;
+    const int K = ksize[0] * ksize[1] * ksize[2];
+    if (K <= 0 || K > SRF_MAX_K) return SRF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    SRF_HIP_TRY(hipMemsetAsync(pair_counts, 0, sizeof(int) * K, st));
+    if (A == 0 || num_out_host == 0) return SRF_OK;
+    if (!nbr) return SRF_EINVAL;
+    SRF_HIP_TRY(hipMemsetAsync(nbr, 0xFF, (size_t)K * num_out_host * 4, st));
+    const int *orows = (const int *)((const uint32_t *)out_table + out_capacity);
+    const int *cand_slot = (const int *)workspace;
+    hipLaunchKernelGGL(srf_strided_fill_k, dim3(srf_ceil_div((long long)A * K, 256)), dim3(256), 0, st, A, K, cand_slot,
+                       orows, num_out_host, nbr, pair_counts);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}

@@ -1,0 +1,263 @@
+// spconv.hip -- K5 sparse convolution forward on the f32 MFMA pipe, K6 densify (gfx950).
+//
+// Reference call sites: every SubMConv3d / SparseConv3d (+ BN1d + ReLU, + residual in SparseBasicBlock) of
+// SparseEncoderCustom.forward, mmdet3d_plugin/models/middle_encoders/sparse_encoder_custom.py:125-134, and
+// SparseConvTensor.dense() at :135-138.
+//
+// Output-stationary implicit GEMM.  A workgroup owns TM consecutive output rows and all COUT columns; for each
+// kernel offset k (skipped when no row of the tile has a neighbour at k) it gathers the TM input rows named by
+// nbr[k][.] into LDS in 32-channel chunks next to the matching 32 x COUT slab of W[k], and accumulates with
+// v_mfma_f32_32x32x2_f32 (v_mfma_f32_16x16x4_f32 for COUT = 16).  Missing neighbours contribute exact zeros.
+// The f32 MFMA is a k-ordered fma chain, so every output element is the chain over (k ascending, c ascending)
+// that oracle/srf_oracle.c:orc_spconv_fwd forms -- results compare exactly.  Each output row is written once,
+// with eval-BatchNorm (y = fma(x, alpha, beta)), residual add and ReLU applied in registers.
+//
+// LDS per workgroup (COUT = 128): nbr tile 27*64*4 = 6.9 KB, A chunk 64*33*4 = 8.4 KB, W chunk 32*128*4 = 16 KB
+// -> 5 workgroups per CU; latency is hidden by occupancy rather than by an explicit pipeline.
+#include "common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SRF_KC 32
+#define SRF_KMAX 27
+
+template <int TM, int COUT>
+__device__ __forceinline__ void srf_stage_tile(const float *__restrict__ in, int Cin, const float *__restrict__ Wk, int c0,
+                                               const int *s_nbr_k, float (*s_a)[SRF_KC + 1], float (*s_w)[COUT])
+{
+    const int tid = threadIdx.x;
+    const bool vec = (Cin & 3) == 0;
+    // gathered input rows: 8 threads per row, one float4 each
+    for (int e = tid; e < TM * (SRF_KC / 4); e += 256) {
+        const int r = e / (SRF_KC / 4), q = e % (SRF_KC / 4);
+        const int i = s_nbr_k[r];
+        const int c = c0 + q * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i >= 0 && c < Cin) {
+            const float *src = in + (size_t)i * Cin + c;
+            if (vec) {
+                v = *reinterpret_cast<const float4 *>(src);
+            } else {
+                v.x = src[0];
+                if (c + 1 < Cin) v.y = src[1];
+                if (c + 2 < Cin) v.z = src[2];
+                if (c + 3 < Cin) v.w = src[3];
+            }
+        }
+        float *dst = &s_a[r][q * 4];
+        dst[0] = v.x;
+        dst[1] = v.y;
+        dst[2] = v.z;
+        dst[3] = v.w;
+    }
+    // weight slab: rows c0..c0+31 of W[k] (Cin x COUT), zero beyond Cin
+    for (int e = tid; e < SRF_KC * (COUT / 4); e += 256) {
+        const int c = e / (COUT / 4), j = e % (COUT / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + c < Cin) v = *reinterpret_cast<const float4 *>(Wk + (size_t)(c0 + c) * COUT + j * 4);
+        *reinterpret_cast<float4 *>(&s_w[c][j * 4]) = v;
+    }
+}
+
+template <int TM>
+__device__ __forceinline__ void srf_load_nbr_tile(const int *__restrict__ nbr, int nbr_stride, int K, int row0, int A_out,
+                                                  int *s_nbr, int *s_any)
+{
+    if (threadIdx.x < SRF_KMAX) s_any[threadIdx.x] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < K * TM; t += 256) {
+        const int k = t / TM, r = t % TM;
+        const int row = row0 + r;
+        const int v = row < A_out ? nbr[(size_t)k * nbr_stride + row] : -1;
+        s_nbr[t] = v;
+        if (v >= 0) s_any[k] = 1;  // benign race: every writer stores 1
+    }
+    __syncthreads();
+}
+
+// COUT in {32, 64, 128}: waves arranged WR x WC, each owning 32 x (CT*32) outputs
+template <int COUT, int TM, int WR, int WC>
+__global__ __launch_bounds__(256) void srf_spconv_mfma32_k(const float *__restrict__ in, int Cin,
+                                                         const float *__restrict__ W, int K,
+                                                         const int *__restrict__ nbr, int nbr_stride, int A_out,
+                                                         const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                         const float *__restrict__ residual, int relu,
+                                                         float *__restrict__ out)
+{
+    static_assert(WR * WC == 4 && TM == WR * 32, "one 32-row tile per wave row");
+    constexpr int CT = COUT / WC / 32;
+    __shared__ int s_nbr[SRF_KMAX * TM];
+    __shared__ int s_any[SRF_KMAX];
+    __shared__ float s_a[TM][SRF_KC + 1];
+    __shared__ __attribute__((aligned(16))) float s_w[SRF_KC][COUT];
+
+    const int row0 = blockIdx.x * TM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    srf_load_nbr_tile<TM>(nbr, nbr_stride, K, row0, A_out, s_nbr, s_any);
+
+    f32x16 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[ct][j] = 0.0f;
+
+    const int ar = wr * 32 + (lane & 31);
+    const int kh = lane >> 5;
+    for (int k = 0; k < K; ++k) {
+        if (!s_any[k]) continue;  // block-uniform
+        const float *Wk = W + (size_t)k * Cin * COUT;
+        for (int c0 = 0; c0 < Cin; c0 += SRF_KC) {
+            __syncthreads();
+            srf_stage_tile<TM, COUT>(in, Cin, Wk, c0, s_nbr + k * TM, s_a, s_w);
+            __syncthreads();
+            const int kc = (Cin - c0) < SRF_KC ? (Cin - c0) : SRF_KC;
+            for (int kk = 0; kk < kc; kk += 2) {
+                const float a = s_a[ar][kk + kh];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const float b = s_w[kk + kh][(wc * CT + ct) * 32 + (lane & 31)];
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ct], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue: C/D layout of 32x32: col = lane & 31, row = (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = (wc * CT + ct) * 32 + (lane & 31);
+        const float al = alpha ? alpha[col] : 1.0f;
+        const float be = alpha ? beta[col] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = row0 + wr * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+            if (row < A_out) {
+                float v = acc[ct][j];
+                if (alpha) v = __fmaf_rn(v, al, be);
+                if (residual) v = __fadd_rn(v, residual[(size_t)row * COUT + col]);
+                if (relu) v = v > 0.0f ? v : 0.0f;
+                out[(size_t)row * COUT + col] = v;
+            }
+        }
+    }
+}
+
+// COUT = 16: four waves, each 16 rows x 16 cols on v_mfma_f32_16x16x4_f32
+template <int TM>
+__global__ __launch_bounds__(256) void srf_spconv_mfma16_k(const float *__restrict__ in, int Cin,
+                                                         const float *__restrict__ W, int K,
+                                                         const int *__restrict__ nbr, int nbr_stride, int A_out,
+                                                         const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                         const float *__restrict__ residual, int relu,
+                                                         float *__restrict__ out)
+{
+    constexpr int COUT = 16;
+    static_assert(TM == 64, "four 16-row wave tiles");
+    __shared__ int s_nbr[SRF_KMAX * TM];
+    __shared__ int s_any[SRF_KMAX];
+    __shared__ float s_a[TM][SRF_KC + 1];
+    __shared__ __attribute__((aligned(16))) float s_w[SRF_KC][COUT];
+
+    const int row0 = blockIdx.x * TM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    srf_load_nbr_tile<TM>(nbr, nbr_stride, K, row0, A_out, s_nbr, s_any);
+
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int ar = wave * 16 + (lane & 15);
+    const int kq = lane >> 4;
+    for (int k = 0; k < K; ++k) {
+        if (!s_any[k]) continue;
+        const float *Wk = W + (size_t)k * Cin * COUT;
+        for (int c0 = 0; c0 < Cin; c0 += SRF_KC) {
+            __syncthreads();
+            srf_stage_tile<TM, COUT>(in, Cin, Wk, c0, s_nbr + k * TM, s_a, s_w);
+            __syncthreads();
+            const int kc = (Cin - c0) < SRF_KC ? (Cin - c0) : SRF_KC;
+            for (int kk = 0; kk < kc; kk += 4) {
+                const float a = s_a[ar][kk + kq];
+                const float b = s_w[kk + kq][lane & 15];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            }
+        }
+    }
+    // C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + j
+    const int col = lane & 15;
+    const float al = alpha ? alpha[col] : 1.0f;
+    const float be = alpha ? beta[col] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = row0 + wave * 16 + kq * 4 + j;
+        if (row < A_out) {
+            float v = acc[j];
+            if (alpha) v = __fmaf_rn(v, al, be);
+            if (residual) v = __fadd_rn(v, residual[(size_t)row * COUT + col]);
+            if (relu) v = v > 0.0f ? v : 0.0f;
+            out[(size_t)row * COUT + col] = v;
+        }
+    }
+}
+
+extern "C" int srf_spconv_fwd(const float *in, int A_in, int Cin, const float *W, int K, const int *nbr, int nbr_stride,
+                              int A_out, int Cout, const float *alpha, const float *beta, const float *residual,
+                              int relu, float *out, srf_stream_t stream)
+{
+    if (A_in < 0 || A_out < 0 || Cin <= 0 || Cin > 512 || K <= 0 || K > SRF_KMAX || nbr_stride < A_out) return SRF_EINVAL;
+    if ((alpha == nullptr) != (beta == nullptr)) return SRF_EINVAL;
+    if (A_out == 0) return SRF_OK;
+    if (!in || !W || !nbr || !out) return SRF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define SRF_ARGS in, Cin, W, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out
+    switch (Cout) {
+    case 16:
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_mfma16_k<64>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0, st,
+                           SRF_ARGS);
+        break;
+    case 32:
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_mfma32_k<32, 128, 4, 1>), dim3(srf_ceil_div(A_out, 128)), dim3(256),
+                           0, st, SRF_ARGS);
+        break;
+    case 64:
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_mfma32_k<64, 64, 2, 2>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0,
+                           st, SRF_ARGS);
+        break;
+    case 128:
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_mfma32_k<128, 64, 2, 2>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0,
+                           st, SRF_ARGS);
+        break;
+    default:
+        return SRF_EUNSUPPORTED;
+    }
+#undef SRF_ARGS
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K6 densify: (A, C) rows at (b, z, y, x) -> (B, C, D, H, W).  One thread per (row, channel): the read is coalesced,
+// the write scatters one dword per channel plane.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void srf_densify_k(const float *__restrict__ feats, const int4 *__restrict__ indices,
+                                                   int A, int C, int D, int H, int W, float *__restrict__ out)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)A * C) return;
+    const int a = (int)(t / C), c = (int)(t % C);
+    const int4 p = indices[a];
+    out[((((size_t)p.x * C + c) * D + p.y) * H + p.z) * W + p.w] = feats[t];
+}
+
+extern "C" int srf_densify(const float *feats, const int *indices, int A, int C, int B, int D, int H, int W, float *out,
+                           int zero_fill, srf_stream_t stream)
+{
+    if (A < 0 || C <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || !out) return SRF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (zero_fill) SRF_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C * D * H * W, st));
+    if (A == 0) return SRF_OK;
+    if (!feats || !indices) return SRF_EINVAL;
+    hipLaunchKernelGGL(srf_densify_k, dim3(srf_ceil_div((long long)A * C, 256)), dim3(256), 0, st, feats,
+                       (const int4 *)indices, A, C, D, H, W, out);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}

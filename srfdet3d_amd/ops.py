@@ -1,0 +1,242 @@
+"""Functional layer over the C ABI: torch device tensors in, torch device tensors out.
+
+torch is used here only to own device memory and to name the current HIP stream; every computation is a
+kernel of libsrfdet3d_hip.so.  All functions raise on CPU tensors (there is no CPU fallback).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FeatMap, check, hf, hi
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dev(t, name, dtype=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"srfdet3d_amd: `{name}` must be a GPU tensor (no CPU fallback exists)")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"srfdet3d_amd: `{name}` must be {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _empty(shape, dtype, device):
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
+def grid_size(voxel_size, pc_range):
+    """mmcv Voxelization.__init__: round((range[3:] - range[:3]) / voxel_size) in float32 -> (gx, gy, gz)."""
+    r = np.asarray(pc_range, np.float32)
+    v = np.asarray(voxel_size, np.float32)
+    return [int(x) for x in np.round((r[3:] - r[:3]) / v)]
+
+
+# ---------------------------------------------------------------------------------------------- voxelization
+def dynamic_voxelize(points, voxel_size, pc_range):
+    points = _dev(points, "points", torch.float32)
+    n, nf = points.shape
+    coors = _empty((n, 3), torch.int32, points.device)
+    check(_lib.lib().srf_dynamic_voxelize(_ptr(points), n, nf, hf(voxel_size), hf(pc_range),
+                                          hi(grid_size(voxel_size, pc_range)), _ptr(coors), _stream()),
+          "dynamic_voxelize")
+    return coors
+
+
+def hard_voxelize(points, voxel_size, pc_range, max_points, max_voxels, mean_features=0):
+    """-> voxels (M,max_points,nf), coors (M,3) zyx, num (M,), mean (M,mean_features) or None.  One D2H sync for M."""
+    points = _dev(points, "points", torch.float32)
+    n, nf = points.shape
+    L = _lib.lib()
+    dev = points.device
+    rows = max(min(n, max_voxels), 1)
+    voxels = _empty((rows, max_points, nf), torch.float32, dev)
+    coors = _empty((rows, 3), torch.int32, dev)
+    num = _empty((rows,), torch.int32, dev)
+    vnum = _empty((1,), torch.int32, dev)
+    mean = _empty((rows, mean_features), torch.float32, dev) if mean_features else None
+    ws_bytes = L.srf_hard_voxelize_workspace_bytes(n, max_points)
+    ws = _empty((max(ws_bytes, 1),), torch.uint8, dev)
+    check(L.srf_hard_voxelize(_ptr(points), n, nf, hf(voxel_size), hf(pc_range), hi(grid_size(voxel_size, pc_range)),
+                              max_points, max_voxels, _ptr(voxels), _ptr(coors), _ptr(num), _ptr(vnum), _ptr(mean),
+                              mean_features, _ptr(ws), ws_bytes, _stream()), "hard_voxelize")
+    M = int(vnum.item())
+    return voxels[:M], coors[:M], num[:M], (mean[:M] if mean is not None else None)
+
+
+# ---------------------------------------------------------------------------------------------- dynamic scatter
+class VoxelMap:
+    """Sorted unique voxels of a (n,4) coordinate list and the point lists of each voxel."""
+
+    def __init__(self, coors, grid_zyx, batch):
+        coors = _dev(coors, "coors", torch.int32)
+        n = coors.shape[0]
+        L = _lib.lib()
+        dev = coors.device
+        self.n = n
+        rows = max(n, 1)
+        out_coors = _empty((rows, 4), torch.int32, dev)
+        self.point2voxel = _empty((rows,), torch.int32, dev)
+        self.counts = _empty((rows,), torch.int32, dev)
+        self.offsets = _empty((rows,), torch.int32, dev)
+        self.order = _empty((rows,), torch.int32, dev)
+        self.num_dev = _empty((1,), torch.int32, dev)
+        ws_bytes = L.srf_voxel_unique_workspace_bytes(n, hi(grid_zyx), batch)
+        if ws_bytes == 0 and n > 0:
+            raise RuntimeError("srfdet3d voxel_unique: grid too large for 32-bit keys")
+        ws = _empty((max(ws_bytes, 1),), torch.uint8, dev)
+        check(L.srf_voxel_unique(_ptr(coors), n, hi(grid_zyx), batch, _ptr(out_coors), _ptr(self.point2voxel),
+                                 _ptr(self.counts), _ptr(self.offsets), _ptr(self.order), _ptr(self.num_dev), _ptr(ws),
+                                 ws_bytes, _stream()), "voxel_unique")
+        self.M = int(self.num_dev.item())
+        self.coors = out_coors[:self.M]
+        self.point2voxel = self.point2voxel[:n]
+
+    def reduce(self, feats, mode):
+        feats = _dev(feats, "feats", torch.float32)
+        C = feats.shape[1]
+        out = _empty((max(self.M, 1), C), torch.float32, feats.device)
+        check(_lib.lib().srf_scatter_reduce(_ptr(feats), _ptr(self.order), _ptr(self.offsets), _ptr(self.counts),
+                                            _ptr(self.num_dev), self.M, C, 0 if mode == "mean" else 1, _ptr(out),
+                                            _stream()), "scatter_reduce")
+        return out[:self.M]
+
+
+# ---------------------------------------------------------------------------------------------- rulebooks
+class CoordTable:
+    def __init__(self, capacity, device):
+        self.capacity = capacity
+        self.buf = _empty((capacity * 2,), torch.int32, device)
+
+
+def coord_table_build(indices, spatial_shape, batch):
+    indices = _dev(indices, "indices", torch.int32)
+    L = _lib.lib()
+    A = indices.shape[0]
+    t = CoordTable(L.srf_coord_table_capacity(A), indices.device)
+    check(L.srf_coord_table_build(_ptr(indices), A, hi(spatial_shape), batch, _ptr(t.buf), t.capacity, _stream()),
+          "coord_table_build")
+    return t
+
+
+def rulebook_subm(indices, spatial_shape, ksize, table):
+    indices = _dev(indices, "indices", torch.int32)
+    A = indices.shape[0]
+    K = int(np.prod(ksize))
+    nbr = _empty((K, max(A, 1)), torch.int32, indices.device)
+    counts = _empty((K,), torch.int32, indices.device)
+    check(_lib.lib().srf_rulebook_subm(_ptr(indices), A, hi(spatial_shape), hi(ksize), _ptr(table.buf), table.capacity,
+                                       _ptr(nbr), _ptr(counts), _stream()), "rulebook_subm")
+    return nbr[:, :A], counts
+
+
+def out_spatial_shape(shape, ksize, stride, pad):
+    return [int((shape[d] + 2 * pad[d] - ksize[d]) // stride[d] + 1) for d in range(3)]
+
+
+def rulebook_strided(indices, spatial_shape, batch, ksize, stride, pad):
+    """-> out_indices (A_out,4), nbr (K,A_out), pair_counts (K,), out_table, out_shape.  One D2H sync for A_out."""
+    indices = _dev(indices, "indices", torch.int32)
+    L = _lib.lib()
+    dev = indices.device
+    A = indices.shape[0]
+    K = int(np.prod(ksize))
+    bound = L.srf_strided_max_outputs(A, batch, hi(spatial_shape), hi(ksize), hi(stride), hi(pad))
+    if bound < 0:
+        check(bound, "strided_max_outputs")
+    table = CoordTable(L.srf_coord_table_capacity(bound), dev)
+    out_idx = _empty((max(bound, 1), 4), torch.int32, dev)
+    num_out = _empty((1,), torch.int32, dev)
+    ws_bytes = L.srf_rulebook_strided_workspace_bytes(A, hi(ksize), table.capacity)
+    ws = _empty((max(ws_bytes, 1),), torch.uint8, dev)
+    check(L.srf_rulebook_strided_outputs(_ptr(indices), A, hi(spatial_shape), batch, hi(ksize), hi(stride), hi(pad),
+                                         _ptr(out_idx), _ptr(num_out), _ptr(table.buf), table.capacity, _ptr(ws),
+                                         ws_bytes, _stream()), "rulebook_strided_outputs")
+    A_out = int(num_out.item())
+    nbr = _empty((K, max(A_out, 1)), torch.int32, dev)
+    counts = _empty((K,), torch.int32, dev)
+    check(L.srf_rulebook_strided_pairs(A, hi(ksize), _ptr(table.buf), table.capacity, _ptr(ws), A_out, _ptr(nbr),
+                                       _ptr(counts), _stream()), "rulebook_strided_pairs")
+    return out_idx[:A_out], nbr[:, :A_out], counts, table, out_spatial_shape(spatial_shape, ksize, stride, pad)
+
+
+# ---------------------------------------------------------------------------------------------- sparse conv
+def spconv_fwd(feats, weight, nbr, alpha=None, beta=None, residual=None, relu=False):
+    """feats (A_in,Cin); weight (K,Cin,Cout); nbr (K,A_out) (row stride nbr.stride(0)) -> (A_out,Cout)."""
+    feats = _dev(feats, "feats", torch.float32)
+    weight = _dev(weight, "weight", torch.float32)
+    if not nbr.is_cuda or nbr.dtype != torch.int32 or nbr.stride(1) != 1:
+        raise RuntimeError("srfdet3d_amd: `nbr` must be a GPU int32 tensor with unit inner stride")
+    K, Cin, Cout = weight.shape
+    A_out = nbr.shape[1]
+    out = _empty((A_out, Cout), torch.float32, feats.device)
+    if residual is not None:
+        residual = _dev(residual, "residual", torch.float32)
+    check(_lib.lib().srf_spconv_fwd(_ptr(feats), feats.shape[0], Cin, _ptr(weight), K, _ptr(nbr),
+                                    nbr.stride(0) if A_out > 0 else 0, A_out, Cout,
+                                    _ptr(alpha), _ptr(beta), _ptr(residual), int(bool(relu)), _ptr(out), _stream()),
+          "spconv_fwd")
+    return out
+
+
+def densify(feats, indices, batch, spatial_shape):
+    feats = _dev(feats, "feats", torch.float32)
+    indices = _dev(indices, "indices", torch.int32)
+    A, C = feats.shape
+    D, H, W = spatial_shape
+    out = _empty((batch, C, D, H, W), torch.float32, feats.device)
+    check(_lib.lib().srf_densify(_ptr(feats), _ptr(indices), A, C, batch, D, H, W, _ptr(out), 1, _stream()), "densify")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- RoI gather
+def _featmap(t, scale):
+    """4-D tensor in any dense layout (NCHW or channels-last) -> srf_featmap."""
+    if t.dim() != 4 or not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError("srfdet3d_amd: feature maps must be 4-D float32 GPU tensors")
+    sn, sc, sh, sw = t.stride()
+    return FeatMap(t.data_ptr(), t.shape[0], t.shape[2], t.shape[3], sn, sc, sh, sw, float(scale))
+
+
+def roi_extract(feats, rois, strides, out_size=7, sampling_ratio=2, finest_scale=56.0, out=None, accumulate=False,
+                bin_major=False, return_levels=False):
+    """SingleRoIExtractor over len(strides) maps.  out: (R,C,out_size,out_size), or (R,out_size^2,C) if bin_major."""
+    rois = _dev(rois, "rois", torch.float32)
+    R = rois.shape[0]
+    C = feats[0].shape[1]
+    nl = len(strides)
+    fm = (FeatMap * nl)(*[_featmap(f, 1.0 / s) for f, s in zip(feats, strides)])
+    bins = out_size * out_size
+    if out is None:
+        shape = (R, bins, C) if bin_major else (R, C, out_size, out_size)
+        out = _empty(shape, torch.float32, rois.device)
+        accumulate = False
+    so_r = C * bins
+    so_c, so_b = (1, C) if bin_major else (bins, 1)
+    lv = _empty((max(R, 1),), torch.int32, rois.device) if return_levels else None
+    check(_lib.lib().srf_roi_extract(fm, nl, C, _ptr(rois), R, out_size, sampling_ratio, float(finest_scale), _ptr(out),
+                                     so_r, so_c, so_b, int(bool(accumulate)), _ptr(lv), _stream()), "roi_extract")
+    return (out, lv[:R]) if return_levels else out
+
+
+def box_rois(boxes, pc_range, voxel_size, mutate_centres=True, want_bev=True, lidar2img=None):
+    """boxes (B,P,>=8) normalised centres -> rois_bev (B*P,5) and/or rois_img (n_cam*B*P,5)."""
+    boxes = _dev(boxes, "boxes", torch.float32)
+    B, P, D = boxes.shape
+    dev = boxes.device
+    rb = _empty((B * P, 5), torch.float32, dev) if want_bev else None
+    ri, n_cam = None, 0
+    if lidar2img is not None:
+        lidar2img = _dev(lidar2img, "lidar2img", torch.float32)
+        n_cam = lidar2img.shape[1]
+        ri = _empty((n_cam * B * P, 5), torch.float32, dev)
+    check(_lib.lib().srf_box_rois(_ptr(boxes), B, P, D, hf(pc_range), hf(voxel_size), int(bool(mutate_centres)), _ptr(rb),
+                                  _ptr(lidar2img), n_cam, _ptr(ri), _stream()), "box_rois")
+    return rb, ri

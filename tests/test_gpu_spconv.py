@@ -1,0 +1,140 @@
+"""GPU parity: K4 rulebooks (bit-exact, including row order), K5 sparse conv (exact fma chain), K6 densify."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from srfdet3d_amd import ops, synthetic as S
+
+pytestmark = pytest.mark.gpu
+VS, RANGE = [0.075, 0.075, 0.2], list(S.NUSC_RANGE)
+SHAPE1 = [41, 1472, 1472]
+
+
+def _level1(seed=2000, n=30000, batch=1):
+    idx = []
+    for b in range(batch):
+        _, c, _ = O.hard_voxelize(S.nuscenes_sweep(seed + b, n), VS, RANGE, 10, 160000)
+        idx.append(np.concatenate([np.full((len(c), 1), b, np.int32), c], 1))
+    return np.concatenate(idx, 0).astype(np.int32)
+
+
+def _canon(nbr, in_idx, out_idx):
+    """canonical rulebook of SURVEY.md 8(a): per k the sorted set of (in coord, out coord) pairs."""
+    out = []
+    for k in range(nbr.shape[0]):
+        o = np.nonzero(nbr[k] >= 0)[0]
+        pairs = np.concatenate([in_idx[nbr[k][o]], out_idx[o]], 1)
+        out.append(pairs[np.lexsort(pairs.T[::-1])])
+    return out
+
+
+def test_subm_rulebook_bit_exact(dev):
+    idx = _level1(batch=2)
+    nbr, cnt = O.rulebook_subm(idx, SHAPE1, [3, 3, 3])
+    t = torch.from_numpy(idx).to(dev)
+    table = ops.coord_table_build(t, SHAPE1, 2)
+    gn, gc = ops.rulebook_subm(t, SHAPE1, [3, 3, 3], table)
+    np.testing.assert_array_equal(gn.cpu().numpy(), nbr)
+    np.testing.assert_array_equal(gc.cpu().numpy(), cnt)
+    assert (nbr[13] == np.arange(len(idx))).all()  # centre tap is the identity
+
+
+def test_strided_rulebook_chain_bit_exact(dev):
+    """the four strided convs of the nuScenes encoder, each fed by the previous level (Appendix A)."""
+    idx = _level1()
+    shape = SHAPE1
+    specs = [([3, 3, 3], [2, 2, 2], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [0, 1, 1]),
+             ([3, 1, 1], [2, 1, 1], [0, 0, 0])]
+    expect_shapes = [[21, 736, 736], [11, 368, 368], [5, 184, 184], [2, 184, 184]]
+    for (ks, st, pd), es in zip(specs, expect_shapes):
+        oi, nbr, cnt, osh = O.rulebook_strided(idx, shape, ks, st, pd)
+        gi, gn, gc, table, gsh = ops.rulebook_strided(torch.from_numpy(idx).to(dev), shape, 1, ks, st, pd)
+        assert osh == es and gsh == es
+        np.testing.assert_array_equal(gi.cpu().numpy(), oi)
+        np.testing.assert_array_equal(gn.cpu().numpy(), nbr)
+        np.testing.assert_array_equal(gc.cpu().numpy(), cnt)
+        # canonical form agrees too (order-free statement of the same rulebook)
+        for a, b in zip(_canon(gn.cpu().numpy(), idx, gi.cpu().numpy()), _canon(nbr, idx, oi)):
+            np.testing.assert_array_equal(a, b)
+        # the table built for the output level serves SubM lookups on it
+        sn, sc = O.rulebook_subm(oi, osh, [3, 3, 3])
+        gsn, gsc = ops.rulebook_subm(gi, osh, [3, 3, 3], table)
+        np.testing.assert_array_equal(gsn.cpu().numpy(), sn)
+        idx, shape = oi, osh
+
+
+def test_rulebook_empty_and_single(dev):
+    e = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+    table = ops.coord_table_build(e, SHAPE1, 1)
+    gn, gc = ops.rulebook_subm(e, SHAPE1, [3, 3, 3], table)
+    assert gn.shape == (27, 0) and int(gc.sum()) == 0
+    gi, gn, gc, _, _ = ops.rulebook_strided(e, SHAPE1, 1, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    assert gi.shape[0] == 0
+    one = np.array([[0, 40, 1471, 1471]], np.int32)  # corner voxel: most offsets fall outside the grid
+    oi, nbr, cnt, _ = O.rulebook_strided(one, SHAPE1, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    gi, gn, gc, _, _ = ops.rulebook_strided(torch.from_numpy(one).to(dev), SHAPE1, 1, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    np.testing.assert_array_equal(gi.cpu().numpy(), oi)
+    np.testing.assert_array_equal(gn.cpu().numpy(), nbr)
+
+
+@pytest.mark.parametrize("cin,cout,K", [(5, 16, 27), (16, 16, 27), (16, 32, 27), (32, 32, 27), (32, 64, 27),
+                                         (64, 64, 27), (64, 128, 27), (128, 128, 27), (128, 128, 3), (4, 16, 27)])
+def test_spconv_fwd_exact(dev, cin, cout, K):
+    rng = np.random.default_rng(cin * 1000 + cout)
+    idx = _level1(n=6000)
+    if K == 27:
+        nbr, _ = O.rulebook_subm(idx, SHAPE1, [3, 3, 3])
+        a_in = len(idx)
+    else:
+        oi, nbr, _, _ = O.rulebook_strided(idx, SHAPE1, [3, 1, 1], [2, 1, 1], [0, 0, 0])
+        a_in = len(idx)
+    feats = rng.standard_normal((a_in, cin)).astype(np.float32)
+    W = (rng.standard_normal((K, cin, cout)) / np.sqrt(cin * 3)).astype(np.float32)
+    alpha = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    beta = rng.standard_normal(cout).astype(np.float32)
+    res = rng.standard_normal((nbr.shape[1], cout)).astype(np.float32) if K == 27 else None
+    for use_bn, use_res, relu in ((False, False, False), (True, False, True), (True, True, True)):
+        if use_res and res is None:
+            continue
+        ref = O.spconv_fwd(feats, W, nbr, alpha if use_bn else None, beta if use_bn else None,
+                           res if use_res else None, relu)
+        tt = lambda x: torch.from_numpy(x).to(dev)
+        got = ops.spconv_fwd(tt(feats), tt(W), tt(nbr), tt(alpha) if use_bn else None, tt(beta) if use_bn else None,
+                             tt(res) if use_res else None, relu).cpu().numpy()
+        # exact: both sides are the same f32 fma chain (k ascending, c ascending); == treats +0/-0 alike
+        assert np.array_equal(got, ref), f"max abs diff {np.abs(got - ref).max()}"
+
+
+def test_spconv_vs_dense_torch_conv3d(dev):
+    """independent check of the whole K4+K5 pair against torch's dense conv3d on a small grid (SubM semantics)."""
+    rng = np.random.default_rng(0)
+    shape = [9, 24, 20]
+    occ = rng.random((2, *shape)) < 0.15
+    idx = np.argwhere(occ).astype(np.int32)
+    cin, cout = 16, 32
+    feats = rng.standard_normal((len(idx), cin)).astype(np.float32)
+    W = (rng.standard_normal((27, cin, cout)) * 0.1).astype(np.float32)
+    t = torch.from_numpy(idx).to(dev)
+    table = ops.coord_table_build(t, shape, 2)
+    nbr, _ = ops.rulebook_subm(t, shape, [3, 3, 3], table)
+    got = ops.spconv_fwd(torch.from_numpy(feats).to(dev), torch.from_numpy(W).to(dev), nbr).cpu().numpy()
+    dense = np.zeros((2, cin, *shape), np.float32)
+    dense[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]] = feats
+    w5 = torch.from_numpy(W.reshape(3, 3, 3, cin, cout)).permute(4, 3, 0, 1, 2).contiguous()
+    full = torch.nn.functional.conv3d(torch.from_numpy(dense).double(), w5.double(), padding=1).numpy()
+    ref = full[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]]
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_densify_exact(dev):
+    idx = _level1(n=5000)
+    oi, _, _, osh = O.rulebook_strided(idx, SHAPE1, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    small = oi[(oi[:, 2] < 64) & (oi[:, 3] < 48)]
+    shape = [osh[0], 64, 48]
+    rng = np.random.default_rng(1)
+    f = rng.standard_normal((len(small), 16)).astype(np.float32)
+    ref = O.densify(f, small, 1, shape)
+    got = ops.densify(torch.from_numpy(f).to(dev), torch.from_numpy(small).to(dev), 1, shape)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    assert got.view(1, 16 * shape[0], 64, 48).shape == (1, 16 * shape[0], 64, 48)
