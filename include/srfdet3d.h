@@ -165,6 +165,16 @@ int srf_box_rois(float *boxes, int B, int P, int box_dim, const float *pc_range 
                  const float *voxel_size /*host[3]*/, int mutate_centres, float *rois_bev, const float *lidar2img,
                  int n_cam, float *rois_img, srf_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * K8  rotated BEV NMS.
+ * Replaces mmcv nms_rotated behind mmdet3d box3d_multiclass_nms, called at srfdet_head.py:1288-1293.
+ * boxes: (n,5) [cx, cy, w, h, angle(rad)] already sorted by descending score; keep[i] = 1 if box i survives
+ * greedy suppression at IoU > iou_threshold.  n <= 4096.
+ * ------------------------------------------------------------------------------------------------------- */
+size_t srf_nms_rotated_workspace_bytes(int n);
+int srf_nms_rotated(const float *boxes, int n, float iou_threshold, int *keep, void *workspace, size_t workspace_bytes,
+                    srf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,8 @@ SIGNATURES = {
     "srf_densify": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "srf_roi_extract": (c_int, [POINTER(FeatMap), c_int, c_int, _P, c_int, c_int, c_int, c_float, _P, c_int64,
                                 c_int64, c_int64, c_int, _P, _P]),
+    "srf_nms_rotated_workspace_bytes": (c_size_t, [c_int]),
+    "srf_nms_rotated": (c_int, [_P, c_int, c_float, _P, _P, c_size_t, _P]),
     "srf_box_rois": (c_int, [_P, c_int, c_int, c_int, _HF, _HF, c_int, _P, _P, c_int, _P, _P]),
 }
 

@@ -1,0 +1,152 @@
+// nms.hip -- rotated BEV IoU and greedy NMS for the decode step (gfx950).
+//
+// Reference call site: box3d_multiclass_nms(...) at mmdet3d_plugin/models/sparse_heads/srfdet_head.py:1288-1293
+// (mmdet3d box3d_nms.py -> mmcv nms_rotated / box_iou_rotated).  Boxes are (cx, cy, w, h,
+// angle[rad]); box j is suppressed by an earlier kept box i when IoU(i, j) > threshold.
+//
+// Two launches: a 64x64-tiled pass writes, for every box, a bit mask of the later boxes it overlaps; one wave then
+// walks the boxes in score order keeping the running "removed" set in registers (one 64-bit word per lane, so up
+// to 4096 boxes), which replaces the device->host copy + CPU loop of the third-party op.
+#include "common.hpp"
+
+struct P2 {
+    float x, y;
+};
+__device__ __forceinline__ float cross2(P2 a, P2 b) { return a.x * b.y - a.y * b.x; }
+__device__ __forceinline__ float dot2(P2 a, P2 b) { return a.x * b.x + a.y * b.y; }
+
+__device__ void srf_rot_vertices(const float *b, float sx, float sy, P2 *p)
+{
+    const float cx = b[0] - sx, cy = b[1] - sy, w = b[2], h = b[3];
+    const float c = cosf(b[4]) * 0.5f, s = sinf(b[4]) * 0.5f;
+    p[0] = {cx - s * h - c * w, cy + c * h - s * w};
+    p[1] = {cx + s * h - c * w, cy - c * h - s * w};
+    p[2] = {2 * cx - p[0].x, 2 * cy - p[0].y};
+    p[3] = {2 * cx - p[1].x, 2 * cy - p[1].y};
+}
+
+__device__ float srf_rotated_iou(const float *a, const float *b)
+{
+    const float area1 = a[2] * a[3], area2 = b[2] * b[3];
+    if (area1 < 1e-14f || area2 < 1e-14f) return 0.0f;
+    const float sx = (a[0] + b[0]) * 0.5f, sy = (a[1] + b[1]) * 0.5f;  // shift to the common centre for precision
+    P2 p1[4], p2[4], v1[4], v2[4], pts[24];
+    srf_rot_vertices(a, sx, sy, p1);
+    srf_rot_vertices(b, sx, sy, p2);
+    for (int i = 0; i < 4; ++i) {
+        v1[i] = {p1[(i + 1) & 3].x - p1[i].x, p1[(i + 1) & 3].y - p1[i].y};
+        v2[i] = {p2[(i + 1) & 3].x - p2[i].x, p2[(i + 1) & 3].y - p2[i].y};
+    }
+    int n = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            const float det = cross2(v2[j], v1[i]);
+            if (fabsf(det) <= 1e-14f) continue;
+            const P2 d = {p2[j].x - p1[i].x, p2[j].y - p1[i].y};
+            const float t1 = cross2(v2[j], d) / det, t2 = cross2(v1[i], d) / det;
+            if (t1 >= 0.0f && t1 <= 1.0f && t2 >= 0.0f && t2 <= 1.0f) pts[n++] = {p1[i].x + v1[i].x * t1, p1[i].y + v1[i].y * t1};
+        }
+    {  // vertices of 1 inside 2
+        const P2 AB = v2[0], DA = v2[3];
+        const float abab = dot2(AB, AB), adad = dot2(DA, DA);
+        for (int i = 0; i < 4; ++i) {
+            const P2 AP = {p1[i].x - p2[0].x, p1[i].y - p2[0].y};
+            const float apab = dot2(AP, AB), apad = -dot2(AP, DA);
+            if (apab >= 0 && apad >= 0 && apab <= abab && apad <= adad) pts[n++] = p1[i];
+        }
+    }
+    {  // vertices of 2 inside 1
+        const P2 AB = v1[0], DA = v1[3];
+        const float abab = dot2(AB, AB), adad = dot2(DA, DA);
+        for (int i = 0; i < 4; ++i) {
+            const P2 AP = {p2[i].x - p1[0].x, p2[i].y - p1[0].y};
+            const float apab = dot2(AP, AB), apad = -dot2(AP, DA);
+            if (apab >= 0 && apad >= 0 && apab <= abab && apad <= adad) pts[n++] = p2[i];
+        }
+    }
+    if (n <= 2) return 0.0f;
+    // the intersection is convex: order its points by angle about their centroid, then the shoelace formula
+    float mx = 0.f, my = 0.f;
+    for (int i = 0; i < n; ++i) {
+        mx += pts[i].x;
+        my += pts[i].y;
+    }
+    mx /= n;
+    my /= n;
+    float ang[24];
+    for (int i = 0; i < n; ++i) ang[i] = atan2f(pts[i].y - my, pts[i].x - mx);
+    for (int i = 1; i < n; ++i) {
+        const float av = ang[i];
+        const P2 pv = pts[i];
+        int j = i - 1;
+        while (j >= 0 && ang[j] > av) {
+            ang[j + 1] = ang[j];
+            pts[j + 1] = pts[j];
+            --j;
+        }
+        ang[j + 1] = av;
+        pts[j + 1] = pv;
+    }
+    float area = 0.f;
+    for (int i = 0; i < n; ++i) area += cross2(pts[i], pts[(i + 1) % n]);
+    area = fabsf(area) * 0.5f;
+    return area / (area1 + area2 - area);
+}
+
+__global__ __launch_bounds__(64) void srf_nms_mask_k(const float *__restrict__ boxes, int n, float thr,
+                                                   unsigned long long *__restrict__ mask, int words)
+{
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb) return;  // only later boxes can be suppressed
+    __shared__ float sb[64 * 5];
+    const int ncol = min(n - cb * 64, 64);
+    if ((int)threadIdx.x < ncol)
+        for (int t = 0; t < 5; ++t) sb[threadIdx.x * 5 + t] = boxes[(size_t)(cb * 64 + threadIdx.x) * 5 + t];
+    __syncthreads();
+    const int i = rb * 64 + threadIdx.x;
+    if (i >= n) return;
+    float me[5];
+    for (int t = 0; t < 5; ++t) me[t] = boxes[(size_t)i * 5 + t];
+    unsigned long long bits = 0;
+    const int start = rb == cb ? threadIdx.x + 1 : 0;
+    for (int j = start; j < ncol; ++j)
+        if (srf_rotated_iou(me, sb + j * 5) > thr) bits |= 1ull << j;
+    mask[(size_t)i * words + cb] = bits;
+}
+
+// one wave; lane l owns word l of the removed set
+__global__ __launch_bounds__(64) void srf_nms_reduce_k(const unsigned long long *__restrict__ mask, int n, int words,
+                                                     int *__restrict__ keep)
+{
+    const int lane = threadIdx.x;
+    unsigned long long removed = 0;
+    for (int i = 0; i < n; ++i) {
+        const unsigned long long w = __shfl(removed, i >> 6, 64);
+        const bool dead = (w >> (i & 63)) & 1ull;
+        if (lane == 0) keep[i] = dead ? 0 : 1;
+        if (!dead && lane < words && lane >= (i >> 6)) removed |= mask[(size_t)i * words + lane];
+    }
+}
+
+extern "C" size_t srf_nms_rotated_workspace_bytes(int n)
+{
+    if (n <= 0) return 0;
+    return (size_t)n * ((n + 63) / 64) * 8;
+}
+
+extern "C" int srf_nms_rotated(const float *boxes, int n, float iou_threshold, int *keep, void *workspace,
+                               size_t workspace_bytes, srf_stream_t stream)
+{
+    if (n < 0 || n > 4096) return n < 0 ? SRF_EINVAL : SRF_EUNSUPPORTED;
+    if (n == 0) return SRF_OK;
+    if (!boxes || !keep || !workspace) return SRF_EINVAL;
+    if (workspace_bytes < srf_nms_rotated_workspace_bytes(n)) return SRF_EWORKSPACE;
+    const int words = (n + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    SRF_HIP_TRY(hipMemsetAsync(workspace, 0, srf_nms_rotated_workspace_bytes(n), st));
+    hipLaunchKernelGGL(srf_nms_mask_k, dim3(words, words), dim3(64), 0, st, boxes, n, iou_threshold,
+                       (unsigned long long *)workspace, words);
+    hipLaunchKernelGGL(srf_nms_reduce_k, dim3(1), dim3(64), 0, st, (const unsigned long long *)workspace, n, words, keep);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}

@@ -240,3 +240,21 @@ def box_rois(boxes, pc_range, voxel_size, mutate_centres=True, want_bev=True, li
     check(_lib.lib().srf_box_rois(_ptr(boxes), B, P, D, hf(pc_range), hf(voxel_size), int(bool(mutate_centres)), _ptr(rb),
                                   _ptr(lidar2img), n_cam, _ptr(ri), _stream()), "box_rois")
     return rb, ri
+
+
+# ---------------------------------------------------------------------------------------------- NMS
+def nms_rotated(boxes_xywhr, scores, iou_threshold):
+    """Greedy rotated NMS; returns indices (into the input) of the kept boxes, in descending score order."""
+    boxes_xywhr = _dev(boxes_xywhr, "boxes", torch.float32)
+    n = boxes_xywhr.shape[0]
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.long, device=boxes_xywhr.device)
+    order = scores.sort(0, descending=True)[1]
+    sorted_boxes = boxes_xywhr[order].contiguous()
+    L = _lib.lib()
+    keep = _empty((n,), torch.int32, boxes_xywhr.device)
+    ws_bytes = L.srf_nms_rotated_workspace_bytes(n)
+    ws = _empty((ws_bytes,), torch.uint8, boxes_xywhr.device)
+    check(L.srf_nms_rotated(_ptr(sorted_boxes), n, float(iou_threshold), _ptr(keep), _ptr(ws), ws_bytes, _stream()),
+          "nms_rotated")
+    return order[keep.bool()]

@@ -1,0 +1,142 @@
+"""`SRFDet` / `SRFDetWaymo` detectors (mmdet3d_plugin/models/detectors/srfdet.py:13-343, srfdetwaymo.py:6-41):
+voxelize -> voxel encoder -> sparse middle encoder -> SECOND -> FPN -> SRFDetHead.  Same registry names,
+constructor arguments, sub-module attribute names and forward signatures as the reference."""
+import torch
+import torch.nn.functional as F
+
+from ..compat.boxes import bbox3d2result
+from ..compat.cnn import BaseModule
+from ..compat.registry import (DETECTORS, build_backbone, build_head, build_middle_encoder, build_neck,
+                               build_voxel_encoder)
+from ..voxel_layer import Voxelization
+from .voxel_encoders import HardSimpleVFE
+
+
+@DETECTORS.register_module()
+class SRFDet(BaseModule):
+    def __init__(self, use_img=False, freeze_img=True, use_grid_mask=False, img_backbone=None, img_neck=None,
+                 pts_voxel_layer=None, pts_voxel_encoder=None, pts_middle_encoder=None, pts_backbone=None,
+                 pts_neck=None, bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None, init_cfg=None):
+        super().__init__(init_cfg)
+        self.use_img = use_img
+        self.freeze_img = freeze_img
+        self.use_grid_mask = use_grid_mask
+        if use_img:
+            self.img_backbone = build_backbone(img_backbone) if img_backbone is not None else None
+            self.img_neck = build_neck(img_neck) if img_neck is not None else None
+            self.grid_mask = None  # train-time augmentation only; identity in eval (grid_mask.py:89)
+        if pts_voxel_layer:
+            self.pts_voxel_layer = Voxelization(**pts_voxel_layer)
+            self.pts_voxel_layer_cfg = pts_voxel_layer
+        if pts_voxel_encoder:
+            self.pts_voxel_encoder = build_voxel_encoder(pts_voxel_encoder)
+            if isinstance(self.pts_voxel_encoder, HardSimpleVFE) and pts_voxel_layer:
+                # the voxelization kernel can emit the per-voxel mean in the same pass
+                self.pts_voxel_layer.fused_mean_features = self.pts_voxel_encoder.num_features
+        if pts_middle_encoder:
+            self.pts_middle_encoder = build_middle_encoder(pts_middle_encoder)
+        if pts_backbone:
+            self.pts_backbone = build_backbone(pts_backbone)
+        if pts_neck is not None:
+            self.pts_neck = build_neck(pts_neck)
+        else:
+            self.pts_neck = None
+        bbox_head = dict(bbox_head)
+        bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg, use_img=use_img)
+        self.bbox_head = build_head(bbox_head)
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+
+    def init_weights(self):
+        super().init_weights()
+        if self.freeze_img and self.use_img and self.img_backbone is not None:
+            for p in self.img_backbone.parameters():
+                p.requires_grad = False
+
+    # ---- entry points (srfdet.py:91-139, :278-340) -----------------------------------------------------------
+    def forward(self, img=None, points=None, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, points, **kwargs)
+        return self.forward_test(img, points, **kwargs)
+
+    def forward_train(self, img, points, gt_bboxes_3d, gt_labels_3d, img_metas, gt_bboxes_3d_ignore=None):
+        img_feats, point_feats = self.extract_feat(img, points, img_metas)
+        return self.bbox_head.forward_train(img_feats, point_feats, gt_bboxes_3d, gt_labels_3d, gt_bboxes_3d_ignore,
+                                            img_metas)
+
+    def forward_test(self, img, points, img_metas, **kwargs):
+        if img is None:
+            img = [img]
+        elif points is None:
+            points = [points]
+        return self.simple_test(img[0], points[0], img_metas[0], **kwargs)
+
+    def simple_test(self, img, points, img_metas, rescale=False):
+        img_feats, point_feats = self.extract_feat(img, points, img_metas)
+        bbox_list = self.bbox_head.simple_test_bboxes(img_feats, point_feats, img_metas)
+        return [dict(pts_bbox=bbox3d2result(b, s, l)) for b, s, l in bbox_list]
+
+    # ---- features ------------------------------------------------------------------------------------------------
+    def extract_feat(self, img, points, img_metas=None):
+        img_feats = self.extract_img_feat(img, img_metas) if img is not None else None
+        point_feats = self.extract_point_features(points) if points is not None else None
+        return img_feats, point_feats
+
+    def extract_img_feat(self, img, img_metas):
+        """(B, N, 3, H, W) -> list of (B, N, C, h, w) per pyramid level (srfdet.py:175-202)."""
+        B = img.size(0)
+        for meta in img_metas:
+            meta.update(input_shape=img.shape[-2:])
+        if img.dim() == 5:
+            img = img.reshape(-1, *img.shape[2:])
+        feats = self.img_backbone(img)
+        if isinstance(feats, dict):
+            feats = list(feats.values())
+        if self.img_neck is not None:
+            feats = self.img_neck(feats)
+        return [f.view(B, f.shape[0] // B, *f.shape[1:]) for f in feats]
+
+    @torch.no_grad()
+    def voxelize(self, points):
+        """list of (N_i, C) point clouds -> hard: (voxels, num_points, coors (M,4) b,z,y,x); dynamic: (points, coors (sum N,4))
+        (srfdet.py:204-247)."""
+        if self.pts_voxel_layer_cfg["max_num_points"] != -1:
+            voxels, coors, nums = [], [], []
+            for i, res in enumerate(points):
+                v, c, n = self.pts_voxel_layer(res)
+                voxels.append(v)
+                nums.append(n)
+                coors.append(F.pad(c, (1, 0), mode="constant", value=i))
+            if len(points) == 1:
+                return voxels[0], nums[0], coors[0]
+            return torch.cat(voxels, 0), torch.cat(nums, 0), torch.cat(coors, 0)
+        coors = [F.pad(self.pts_voxel_layer(res), (1, 0), mode="constant", value=i) for i, res in enumerate(points)]
+        if len(points) == 1:
+            return points[0], coors[0]
+        return torch.cat(points, 0), torch.cat(coors, 0)
+
+    def extract_point_features(self, points):
+        batch_size = len(points)
+        if self.pts_voxel_layer_cfg["max_num_points"] != -1:
+            voxels, num_points, coors = self.voxelize(points)
+            voxel_features = self.pts_voxel_encoder(voxels, num_points, coors)
+        else:
+            pts, pt_coors = self.voxelize(points)
+            voxel_features, coors = self.pts_voxel_encoder(pts, pt_coors)
+        # the reference derives batch_size from coors[-1, 0] + 1 (srfdet.py:258, :271), a device->host sync; the
+        # number of point clouds handed in is the same number whenever the last sample has at least one voxel
+        x = self.pts_middle_encoder(voxel_features, coors, batch_size)
+        x = self.pts_backbone(x)
+        if self.pts_neck is not None:
+            x = self.pts_neck(x)
+        return x
+
+
+@DETECTORS.register_module()
+class SRFDetWaymo(SRFDet):
+    """Same model; results are returned without the `pts_bbox` wrapper (srfdetwaymo.py:13-41)."""
+
+    def simple_test(self, img, points, img_metas, rescale=False):
+        img_feats, point_feats = self.extract_feat(img, points, img_metas)
+        bbox_list = self.bbox_head.simple_test_bboxes(img_feats, point_feats, img_metas)
+        return [bbox3d2result(b, s, l) for b, s, l in bbox_list]

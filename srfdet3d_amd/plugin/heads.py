@@ -1,0 +1,454 @@
+"""The sparse-region-fusion decoder: `SRFDetHead`, `SingleSRFDetHeadLiDAR`, `SingleSRFDetHead`, `DynamicConv`.
+
+Mirrors mmdet3d_plugin/models/sparse_heads/srfdet_head.py (SRFDetHead :48-1344, SingleSRFDetHeadLiDAR :1347-1689,
+SingleSRFDetHead :2103-2630, DynamicConv :2633-2693): same registry names, constructor arguments, parameter names
+(so checkpoints load by key) and call signatures.  What differs is how a stage is executed:
+
+  * proposal box -> corners -> BEV / per-camera RoIs is ONE kernel (srf_box_rois) instead of ~60 small torch ops,
+    and it keeps the reference's in-place overwrite of the box centres with metres (srfdet_head.py:1646, :2587),
+    which apply_deltas relies on;
+  * the RoI gather writes (R, 49, C) directly -- the layout DynamicConv multiplies -- from channels-last feature
+    maps, so the permutes of :1480-1481 / :2257-2263 and :2667 disappear and every tap is a 512-byte read;
+  * lidar2img is uploaded once per frame, not once per stage (:2452-2456);
+  * the camera sum (:2551-2561) keeps the reference's roi indexing b + cam*bs against maps flattened b*n_cam + cam
+    (SURVEY.md finding 7); `corrected_cam_indexing=True` switches to the consistent indexing and is off by default.
+"""
+import copy
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops
+from ..compat.cnn import BaseModule, ConvModule, ModuleList, build_activation_layer, build_conv_layer
+from ..compat.registry import HEADS, LOSSES, BBOX_ASSIGNERS, build_head, build_roi_extractor
+from ..roi import SingleRoIExtractor
+from .bbox_util import denormalize_bbox
+
+_DEFAULT_SCALE_CLAMP = math.log(100000.0 / 16)
+
+
+def _channels_last(feats):
+    return [f if f.is_contiguous(memory_format=torch.channels_last) else f.contiguous(memory_format=torch.channels_last)
+            for f in feats]
+
+
+class DynamicConv(nn.Module):
+    """Per-proposal two-layer 1x1 'dynamic' conv on the 7x7 RoI feature, then a 49C -> C projection
+    (srfdet_head.py:2633-2693)."""
+
+    def __init__(self, feat_channels, dynamic_dim=64, dynamic_num=2, pooler_resolution=7):
+        super().__init__()
+        self.feat_channels = feat_channels
+        self.dynamic_dim = dynamic_dim
+        self.dynamic_num = dynamic_num
+        self.num_params = feat_channels * dynamic_dim
+        self.dynamic_layer = nn.Linear(feat_channels, dynamic_num * self.num_params)
+        self.norm1 = nn.LayerNorm(dynamic_dim)
+        self.norm2 = nn.LayerNorm(feat_channels)
+        self.activation = nn.ReLU(inplace=True)
+        self.out_layer = nn.Linear(feat_channels * pooler_resolution ** 2, feat_channels)
+        self.norm3 = nn.LayerNorm(feat_channels)
+
+    def forward(self, prop_feats, roi_feats):
+        """prop_feats (1,R,C) or (R,C); roi_feats (S,R,C) as the reference passes it, or (R,S,C) when
+        `roi_feats.srf_bin_major` is set by the fused gather.  -> (R,C)."""
+        C, d = self.feat_channels, self.dynamic_dim
+        feats = roi_feats if getattr(roi_feats, "srf_bin_major", False) else roi_feats.permute(1, 0, 2)
+        params = self.dynamic_layer(prop_feats.reshape(-1, C))
+        w1 = params[:, :self.num_params].view(-1, C, d)
+        w2 = params[:, self.num_params:].view(-1, d, C)
+        x = F.relu(self.norm1(torch.bmm(feats, w1)))
+        x = F.relu(self.norm2(torch.bmm(x, w2)))
+        x = self.out_layer(x.flatten(1))
+        return F.relu(self.norm3(x))
+
+
+class _StageBase(BaseModule):
+    """One refinement stage (shared by the LiDAR-only and the fusion class; attribute names as in the reference)."""
+
+    def __init__(self, num_classes=80, feat_channels=256, pooler_resolution=7, use_focal_loss=True, use_fed_loss=False,
+                 dim_feedforward=2048, num_cls_convs=1, num_reg_convs=3, num_heads=8, dropout=0.0,
+                 scale_clamp=_DEFAULT_SCALE_CLAMP, bbox_weights=(1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2),
+                 act_cfg=dict(type="ReLU", inplace=True), dynamic_conv=dict(dynamic_dim=64, dynamic_num=2),
+                 pc_range=None, voxel_size=None, init_cfg=None, is_kitti=None, use_fusion=False):
+        super().__init__(init_cfg)
+        C = feat_channels
+        self.feat_channels = self.feat_channels_lidar = C
+        self.pc_range_lidar = pc_range
+        self.voxel_size_lidar = voxel_size
+        self.is_kitti = bool(is_kitti)
+        self.use_fusion = use_fusion
+        self.self_attn_lidar = nn.MultiheadAttention(C, num_heads, dropout=dropout)
+        self.inst_interact_lidar = DynamicConv(C, dynamic_conv["dynamic_dim"], dynamic_conv["dynamic_num"],
+                                               pooler_resolution)
+        self.linear1_lidar = nn.Linear(C, dim_feedforward)
+        self.dropout_lidar = nn.Dropout(dropout)
+        self.linear2_lidar = nn.Linear(dim_feedforward, C)
+        self.norm1_lidar, self.norm2_lidar, self.norm3_lidar = nn.LayerNorm(C), nn.LayerNorm(C), nn.LayerNorm(C)
+        self.dropout1_lidar, self.dropout2_lidar, self.dropout3_lidar = (nn.Dropout(dropout) for _ in range(3))
+        self.activation_lidar = build_activation_layer(act_cfg)
+
+        def tower(n):
+            mods = []
+            for _ in range(n):
+                mods += [nn.Linear(C, C, False), nn.LayerNorm(C), nn.ReLU(inplace=True)]
+            return ModuleList(mods)
+
+        self.cls_module_lidar = tower(num_cls_convs)
+        self.reg_module_lidar = tower(num_reg_convs)
+        self.use_focal_loss, self.use_fed_loss = use_focal_loss, use_fed_loss
+        self.class_logits_lidar = nn.Linear(C, num_classes if (use_focal_loss or use_fed_loss) else num_classes + 1)
+        self.bboxes_delta_lidar = nn.Linear(C, len(bbox_weights))
+        self.scale_clamp = scale_clamp
+        self.bbox_weights = list(bbox_weights)
+        if use_fusion:
+            self.output_fused_proj = nn.Linear(2 * C, C)
+        if init_cfg is None:
+            self.init_cfg = [dict(type="Normal", std=0.01, override=dict(name="class_logits_lidar")),
+                             dict(type="Normal", std=0.001, override=dict(name="bboxes_delta_lidar"))]
+
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        nn.init.constant_(self.class_logits_lidar.bias, -math.log((1 - 0.01) / 0.01))
+        nn.init.constant_(self.bboxes_delta_lidar.bias.data[2:], 0.0)
+
+    # ---- geometry + gather ----------------------------------------------------------------------------------
+    def _gather(self, feats, rois, pooler):
+        """RoI features as (R, S, C).  The fused path asks the extractor for that layout directly."""
+        if isinstance(pooler, SingleRoIExtractor):
+            out = pooler(_channels_last(feats[:pooler.num_inputs]), rois, bin_major=True)
+        else:  # any object with the mmdet call surface (feats, rois) -> (R, C, 7, 7)
+            out = pooler(feats[:pooler.num_inputs], rois)
+            out = out.flatten(2).permute(0, 2, 1).contiguous()
+        return out
+
+    def points_feats_sampling_bboxes_roi(self, points_feats, bboxes, pooler, img_metas=None):
+        """BEV RoI features of each proposal, (bs*n_p, C, 7, 7); overwrites bboxes[..., :3] with metres in place
+        (srfdet_head.py:1627-1689 / :2568-2630)."""
+        rois, _ = ops.box_rois(bboxes, self.pc_range_lidar, self.voxel_size_lidar, mutate_centres=True)
+        r = self._gather(points_feats, rois, pooler)
+        return r.permute(0, 2, 1).reshape(r.shape[0], r.shape[2], 7, 7)
+
+    @staticmethod
+    def _lidar2img(img_metas, like):
+        cached = img_metas[0].get("srf_lidar2img_dev") if isinstance(img_metas[0], dict) else None
+        if cached is not None and cached.device == like.device:
+            return cached
+        m = np.asarray([meta["lidar2img"] for meta in img_metas], dtype=np.float32)
+        if m.ndim == 3:  # KITTI: one camera, (bs,4,4) (srfdet_head.py:2462-2464)
+            m = m[:, None]
+        t = torch.from_numpy(np.ascontiguousarray(m)).to(like.device)
+        if isinstance(img_metas[0], dict):
+            img_metas[0]["srf_lidar2img_dev"] = t
+        return t
+
+    def _img_rois_feats(self, img_feats, rois_img, pooler_img, bs, n_p, n_cam):
+        """gather over all cameras and sum them per proposal -> (bs*n_p, S, C) (srfdet_head.py:2543-2562)."""
+        flat = [f.reshape(f.shape[0] * f.shape[1], *f.shape[2:]) for f in img_feats]
+        r = self._gather(flat, rois_img, pooler_img)  # (n_cam*bs*n_p, S, C), cam-major rows
+        return r.view(n_cam, bs * n_p, r.shape[1], r.shape[2]).sum(dim=0)
+
+    def img_feats_sampling_bboxes_roi(self, img_feats, bboxes, pooler, img_metas):
+        """image RoI features summed over cameras, (bs*n_p, C, 7, 7); leaves `bboxes` untouched (:2424-2566)."""
+        bs, n_p = bboxes.shape[:2]
+        l2i = self._lidar2img(img_metas, bboxes)
+        _, rois_img = ops.box_rois(bboxes.clone(), self.pc_range_lidar, self.voxel_size_lidar, mutate_centres=False,
+                                   want_bev=False, lidar2img=l2i)
+        r = self._img_rois_feats(img_feats, rois_img, pooler, bs, n_p, l2i.shape[1])
+        return r.permute(0, 2, 1).reshape(r.shape[0], r.shape[2], 7, 7)
+
+    # ---- stage arithmetic -----------------------------------------------------------------------------------
+    def _refine(self, roi_feats, boxes_m, prop_feats, bs, n_p):
+        """roi_feats (R,S,C); boxes_m (bs,n_p,D) with centres in metres; prop_feats (bs,n_p,C)-viewable or None."""
+        C = self.feat_channels_lidar
+        R = bs * n_p
+        if prop_feats is None:
+            prop_feats = roi_feats.mean(dim=1)
+        q = prop_feats.reshape(bs, n_p, C).permute(1, 0, 2)
+        q = self.norm1_lidar(q + self.dropout1_lidar(self.self_attn_lidar(q, q, value=q)[0]))
+        q = q.permute(1, 0, 2).reshape(R, C)
+        roi_feats.srf_bin_major = True
+        inter = self.inst_interact_lidar(q, roi_feats)
+        obj = self.norm2_lidar(q + self.dropout2_lidar(inter))
+        ffn = self.linear2_lidar(self.dropout_lidar(self.activation_lidar(self.linear1_lidar(obj))))
+        obj = self.norm3_lidar(obj + self.dropout3_lidar(ffn))
+        cls_f, reg_f = obj, obj
+        for layer in self.cls_module_lidar:
+            cls_f = layer(cls_f)
+        for layer in self.reg_module_lidar:
+            reg_f = layer(reg_f)
+        logits = self.class_logits_lidar(cls_f)
+        deltas = self.bboxes_delta_lidar(reg_f)
+        pred = self.apply_deltas_lidar(deltas, boxes_m.reshape(R, -1))
+        return logits.view(bs, n_p, -1), pred.view(bs, n_p, -1), obj.view(1, R, C)
+
+    def apply_deltas_lidar(self, deltas, boxes):
+        """deltas (N,D) applied to boxes (N,D) [cx,cy,cz (m), log w,l,h, sin, cos, (vx,vy)] -> boxes with centres
+        normalised to [0,1] by the range; sin/cos/velocity are taken from the deltas (srfdet_head.py:1534-1625)."""
+        boxes = boxes.to(deltas.dtype)
+        w = deltas.new_tensor(self.bbox_weights[:6])
+        d = deltas[:, :6] / w
+        size = boxes[:, 3:6].exp()
+        ctr = d[:, :3] * size + boxes[:, :3]
+        new_size = d[:, 3:6].clamp(max=self.scale_clamp).exp() * size
+        r = self.pc_range_lidar
+        lo = deltas.new_tensor(r[:3])
+        ext = deltas.new_tensor([r[3] - r[0], r[4] - r[1], r[5] - r[2]])
+        ctr = ((ctr - lo) / ext).clamp(min=0.0, max=1.0)
+        return torch.cat([ctr, new_size.log(), deltas[:, 6:]], dim=-1)
+
+
+@HEADS.register_module()
+class SingleSRFDetHeadLiDAR(_StageBase):
+    def forward(self, point_feats, bboxes, prop_feats, pooler, img_metas=None):
+        """(bs,n_p,D) boxes with normalised centres -> (logits (bs,n_p,#cls), boxes (bs,n_p,D), obj (1,bs*n_p,C)).
+        `bboxes[..., :3]` is overwritten with metres, as in the reference."""
+        bs, n_p = bboxes.shape[:2]
+        rois, _ = ops.box_rois(bboxes, self.pc_range_lidar, self.voxel_size_lidar, mutate_centres=True)
+        roi_feats = self._gather(point_feats, rois, pooler)
+        return self._refine(roi_feats, bboxes, prop_feats, bs, n_p)
+
+
+@HEADS.register_module()
+class SingleSRFDetHead(_StageBase):
+    def __init__(self, *args, use_fusion=False, **kwargs):
+        super().__init__(*args, use_fusion=use_fusion, **kwargs)
+
+    def forward(self, img_feats, point_feats, bboxes, prop_feats, pooler, img_metas, pooler_img=None):
+        bs, n_p = bboxes.shape[:2]
+        l2i = self._lidar2img(img_metas, bboxes) if img_feats is not None else None
+        rois_bev, rois_img = ops.box_rois(bboxes, self.pc_range_lidar, self.voxel_size_lidar, mutate_centres=True,
+                                          want_bev=point_feats is not None, lidar2img=l2i)
+        img_roi = self._img_rois_feats(img_feats, rois_img, pooler_img, bs, n_p, l2i.shape[1]) \
+            if img_feats is not None else None
+        pts_roi = self._gather(point_feats, rois_bev, pooler) if point_feats is not None else None
+        if img_roi is not None and pts_roi is not None and self.use_fusion:
+            roi_feats = self.output_fused_proj(torch.cat((img_roi, pts_roi), dim=-1))
+        elif not self.use_fusion and img_roi is not None and pts_roi is None:
+            roi_feats = img_roi
+        elif not self.use_fusion and pts_roi is not None and img_roi is None:
+            roi_feats = pts_roi
+        else:
+            raise ValueError("unsupported combination of modalities / use_fusion")
+        return self._refine(roi_feats, bboxes, prop_feats, bs, n_p)
+
+
+@HEADS.register_module()
+class SingleSRFDetHeadImg(_StageBase):
+    """Registered because the configs carry a `single_head_img` dict; never built into the model
+    (its construction is commented out upstream, srfdet_head.py:159-173)."""
+
+
+@HEADS.register_module()
+class SRFDetHead(BaseModule):
+    def __init__(self, use_img=False, num_classes=4, feat_channels_lidar=256, feat_channels_img=256, hidden_dim=128,
+                 lidar_feat_lvls=4, img_feat_lvls=4, num_proposals=128, num_heads=6, deep_supervision=True,
+                 prior_prob=0.01, is_kitti=False, with_lidar_encoder=False, grid_size=None, out_size_factor=8,
+                 lidar_encoder_cfg=None, code_weights=None, with_dpg=True, num_dpg_exp=4, single_head_lidar=None,
+                 single_head_img=None, roi_extractor_lidar=None, roi_extractor_img=None, sync_cls_avg_factor=True,
+                 loss_cls=None, loss_bbox=None, train_cfg=None, test_cfg=None, init_cfg=None, pretrained=None):
+        super().__init__(init_cfg)
+        assert not with_lidar_encoder, "with_lidar_encoder=False in every SRFDet3D config (SURVEY.md finding 8)"
+        self.num_classes = num_classes
+        self.use_img = use_img
+        self.feat_channels_lidar = feat_channels_lidar
+        self.feat_channels_img = feat_channels_img
+        self.hidden_dim = hidden_dim
+        self.lidar_feat_lvls = lidar_feat_lvls
+        self.img_feat_lvls = img_feat_lvls
+        self.num_proposals = num_proposals
+        self.num_heads = num_heads
+        self.deep_supervision = deep_supervision
+        self.prior_prob = prior_prob
+        self.is_kitti = is_kitti
+        self.pc_range = single_head_lidar["pc_range"]
+        self.test_cfg = test_cfg
+        self.train_cfg = train_cfg
+        self.with_dpg = with_dpg
+        self.num_dpg_exp = num_dpg_exp
+        self.grid_size = grid_size
+        self.out_size_factor = out_size_factor
+        self.sync_cls_avg_factor = sync_cls_avg_factor
+        self.with_lidar_encoder = False
+        self.use_fed_loss, self.use_focal_loss = False, True
+        self._code_size = len(code_weights)
+
+        if with_dpg:
+            self._build_dynamic_prop_gen()
+        else:
+            self.init_proposal_boxes = nn.Embedding(num_proposals, self._code_size)
+            self.init_proposal_feats = nn.Embedding(num_proposals, feat_channels_lidar)
+
+        stage_cfg = dict(copy.deepcopy(single_head_lidar))
+        stage_cfg.update(num_classes=num_classes, feat_channels=feat_channels_lidar,
+                         pooler_resolution=roi_extractor_lidar["roi_layer"].get("output_size"),
+                         use_focal_loss=self.use_focal_loss, use_fed_loss=self.use_fed_loss, is_kitti=is_kitti)
+        stage = build_head(stage_cfg)
+        self.head_series_lidar = ModuleList([copy.deepcopy(stage) for _ in range(num_heads)])
+        self.roi_extractor_lidar = build_roi_extractor(roi_extractor_lidar)
+        if use_img:
+            if hidden_dim != feat_channels_img:
+                self.img_convs = nn.ModuleList([
+                    build_conv_layer(dict(type="Conv2d"), feat_channels_img, hidden_dim, kernel_size=3, padding=1,
+                                     bias="auto") for _ in range(img_feat_lvls)])
+            self.roi_extractor_img = build_roi_extractor(roi_extractor_img)
+        else:
+            self.roi_extractor_img = None
+
+        self.loss_cls = LOSSES.build(loss_cls) if loss_cls and loss_cls["type"] in LOSSES else None
+        self.loss_bbox = LOSSES.build(loss_bbox) if loss_bbox and loss_bbox["type"] in LOSSES else None
+        self.assigner = None
+        if train_cfg and train_cfg.get("assigner") and train_cfg["assigner"]["type"] in BBOX_ASSIGNERS:
+            self.assigner_type = train_cfg["assigner"]["type"]
+            self.assigner = BBOX_ASSIGNERS.build(train_cfg["assigner"])
+        self.code_weights = nn.Parameter(torch.tensor(code_weights, requires_grad=False), requires_grad=False)
+        self.use_nms = (test_cfg or {}).get("use_nms", True)
+        self._init_weights()
+
+    # ---- construction helpers -------------------------------------------------------------------------------
+    def _dw_stair(self, channels, levels):
+        return ModuleList([ConvModule(channels * (l + 1), channels * (l + 1), kernel_size=3, stride=2, padding=1,
+                                      groups=channels * (l + 1), norm_cfg=dict(type="BN2d", eps=1e-3, momentum=0.01))
+                           for l in range(levels - 1)])
+
+    def _build_dynamic_prop_gen(self):
+        n = self.num_dpg_exp * self.num_proposals
+        self.init_proposal_boxes = nn.Embedding(n, self._code_size)
+        self.init_proposal_feats = nn.Embedding(n, self.feat_channels_lidar)
+        self.dpg_dw_convs_lidar = self._dw_stair(self.feat_channels_lidar, self.lidar_feat_lvls)
+        down = self.out_size_factor * (2 ** (self.lidar_feat_lvls - 1))
+        fx, fy = int(self.grid_size[0] / down), int(self.grid_size[1] / down)
+        self.dpg_fc1_lidar = nn.Linear(fx * fy, 1024)
+        self.dpg_act_lidar = nn.ReLU(inplace=True)
+        self.dpg_fc2_lidar = nn.Linear(1024, n)
+        if self.use_img:
+            self.dpg_dw_convs_img = self._dw_stair(self.hidden_dim, self.img_feat_lvls)
+            self.dpg_fc1_img = nn.Linear(30 * 15 if self.is_kitti else 30 * 30, 1500)
+            self.dpg_act_img = nn.ReLU(inplace=True)
+            self.dpg_fc2_img = nn.Linear(1500, n)
+
+    def _init_weights(self):
+        bias_value = -math.log((1 - self.prior_prob) / self.prior_prob)
+        for name, p in self.named_parameters():
+            if name in ("code_weights", "init_proposal_boxes.weight", "init_proposal_feats.weight"):
+                continue
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+            if p.shape[-1] in (self.num_classes, self.num_classes + 1):
+                nn.init.constant_(p, bias_value)
+
+    # ---- proposals ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _stair(convs, feats):
+        """depthwise stride-2 stair over the pyramid with channel concat (srfdet_head.py:525-536)."""
+        x = convs[0](feats[0])
+        for lvl in range(1, len(feats)):
+            x = torch.cat([feats[lvl], x], dim=1)
+            if lvl < len(convs):
+                x = convs[lvl](x)
+        return x
+
+    def _get_init_proposals(self, img_feats, point_feats):
+        bs = point_feats[0].shape[0]
+        boxes_w, feats_w = self.init_proposal_boxes.weight, self.init_proposal_feats.weight
+        if not self.with_dpg:
+            return boxes_w[None].repeat(bs, 1, 1), feats_w[None].repeat(bs, 1, 1)
+        E, P = self.num_dpg_exp, self.num_proposals
+        w = self._stair(self.dpg_dw_convs_lidar, point_feats[:self.lidar_feat_lvls]).sum(dim=1).flatten(1, 2)
+        w = self.dpg_fc2_lidar(self.dpg_act_lidar(self.dpg_fc1_lidar(w))).reshape(bs, E, P)
+        if self.use_img:
+            flat = [f.reshape(f.shape[0] * f.shape[1], *f.shape[2:]) for f in img_feats[:self.img_feat_lvls]]
+            n_cam = img_feats[0].shape[1]
+            x = self._stair(self.dpg_dw_convs_img, flat)
+            x = F.interpolate(x, [30, 15] if self.is_kitti else [30, 30])
+            x = x.view(bs, n_cam, *x.shape[1:]).sum(dim=1).sum(dim=1).flatten(1, 2)
+            wi = self.dpg_fc2_img(self.dpg_act_img(self.dpg_fc1_img(x))).reshape(bs, E, P)
+            w = (w + wi) / 2
+        w = w.softmax(1).unsqueeze(-1)
+        boxes = (w * boxes_w.view(1, E, P, -1)).sum(1)
+        feats = (w * feats_w.view(1, E, P, -1)).sum(1)
+        return boxes, feats
+
+    # ---- forward --------------------------------------------------------------------------------------------
+    def forward(self, img_feats, point_feats, img_metas):
+        """-> logits (#stage, bs, n_p, #cls), boxes (#stage, bs, n_p, D) with centres in metres, log sizes."""
+        point_feats = list(point_feats)
+        if self.use_img and self.hidden_dim != self.feat_channels_img:
+            img_feats = list(img_feats)
+            for i, f in enumerate(img_feats):
+                bs, n_cam, C, H, W = f.shape
+                g = self.img_convs[i](f.reshape(bs * n_cam, C, H, W))
+                img_feats[i] = g.reshape(bs, n_cam, *g.shape[1:])
+        boxes, prop_feats = self._get_init_proposals(img_feats, point_feats)
+        boxes = boxes.contiguous()
+        boxes[..., :3] = boxes[..., :3].sigmoid()
+
+        # channels-last copies of the pyramids, made once: every RoI tap then reads C contiguous floats
+        if point_feats[0].is_cuda:
+            point_feats_g = _channels_last(point_feats)
+            img_feats_g = None
+            if self.use_img:
+                img_feats_g = [f.reshape(f.shape[0] * f.shape[1], *f.shape[2:]) for f in img_feats]
+                img_feats_g = [f.view(img_feats[i].shape[0], img_feats[i].shape[1], *f.shape[1:])
+                               for i, f in enumerate(_channels_last(img_feats_g))]
+        else:
+            point_feats_g, img_feats_g = point_feats, img_feats
+
+        logits_all, boxes_all = [], []
+        for stage in self.head_series_lidar:
+            if not self.use_img:
+                logits, pred, prop_feats = stage(point_feats_g, boxes, prop_feats, self.roi_extractor_lidar, img_metas)
+            else:
+                logits, pred, prop_feats = stage(img_feats_g, point_feats_g, boxes, prop_feats,
+                                                 self.roi_extractor_lidar, img_metas, pooler_img=self.roi_extractor_img)
+            if self.deep_supervision:
+                logits_all.append(logits)
+                boxes_all.append(pred)
+            boxes = pred.detach().clone()
+
+        r = self.pc_range
+        lo = point_feats[0].new_tensor(r[:3])
+        ext = point_feats[0].new_tensor([r[3] - r[0], r[4] - r[1], r[5] - r[2]])
+        if self.deep_supervision:
+            logits_all, boxes_all = torch.stack(logits_all), torch.stack(boxes_all)
+        else:
+            logits_all, boxes_all = logits[None], pred[None].clone()
+        boxes_all[..., :3] = boxes_all[..., :3] * ext + lo
+        return logits_all, boxes_all
+
+    def simple_test_bboxes(self, img_feats, point_feats, img_metas):
+        logits, boxes = self(img_feats, point_feats, img_metas)
+        return self.get_bboxes(logits, boxes, img_metas)
+
+    def decode(self, pred_logits, pred_bboxes):
+        """last-stage outputs -> (scores (bs,n_p,#cls), boxes (bs,n_p,7|9) with bottom-centre z): the tensors the
+        reference hands to box3d_multiclass_nms (srfdet_head.py:1246-1271); the parity contract is on these."""
+        scores = torch.sigmoid(pred_logits[-1])
+        boxes = denormalize_bbox(pred_bboxes[-1], self.pc_range)
+        boxes[..., 2] = boxes[..., 2] - boxes[..., 5] * 0.5
+        return scores, boxes
+
+    def get_bboxes(self, pred_logits, pred_bboxes, img_metas):
+        from ..postprocess import box3d_multiclass_nms
+        cfg = self.test_cfg
+        scores_all, boxes_all = self.decode(pred_logits, pred_bboxes)
+        results = []
+        for i in range(scores_all.shape[0]):
+            scores, boxes = scores_all[i], boxes_all[i]
+            box_type = img_metas[i]["box_type_3d"]
+            if self.use_nms:
+                boxes, scores, labels = box3d_multiclass_nms(boxes, scores, cfg["score_thr"], cfg["max_per_img"],
+                                                             cfg["nms_thr"])
+            else:
+                scores, idx = scores.flatten(0, 1).topk(cfg["max_per_img"])
+                labels = idx % self.num_classes
+                boxes = boxes[idx // self.num_classes]
+            rng = torch.tensor(cfg["post_center_range"], device=scores.device)
+            keep = (boxes[..., :3] >= rng[:3]).all(1) & (boxes[..., :3] <= rng[3:]).all(1)
+            results.append([box_type(boxes[keep], boxes.shape[-1]), scores[keep], labels[keep]])
+        return results

@@ -1,0 +1,73 @@
+"""`SparseEncoderCustom` (mmdet3d_plugin/models/middle_encoders/sparse_encoder_custom.py:19-216): the 3-D sparse
+conv encoder that turns voxel features into the dense BEV map.  Same constructor arguments, same module names
+(conv_input / encoder_layers.encoder_layer{i} / conv_out), so checkpoints load by key."""
+from ..compat.cnn import BaseModule
+from ..compat.registry import MIDDLE_ENCODERS
+from ..sparse import SparseBasicBlock, SparseConvTensor, SparseSequential, make_sparse_convmodule
+
+
+@MIDDLE_ENCODERS.register_module()
+class SparseEncoderCustom(BaseModule):
+    def __init__(self, in_channels, sparse_shape, order=("conv", "norm", "act"),
+                 norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01), base_channels=16, output_channels=128,
+                 encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
+                 encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)), block_type="conv_module",
+                 init_cfg=None):
+        super().__init__(init_cfg=init_cfg)
+        assert block_type in ("conv_module", "basicblock")
+        assert isinstance(order, tuple) and set(order) == {"conv", "norm", "act"}
+        self.sparse_shape = list(sparse_shape)
+        self.in_channels = in_channels
+        self.order = order
+        self.base_channels = base_channels
+        self.output_channels = output_channels
+        self.encoder_channels = encoder_channels
+        self.encoder_paddings = encoder_paddings
+        self.stage_num = len(encoder_channels)
+        self.fp16_enabled = False
+
+        pre_act = order[0] != "conv"
+        self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, norm_cfg=norm_cfg, padding=1,
+                                                 indice_key="subm1", conv_type="SubMConv3d",
+                                                 order=("conv",) if pre_act else ("conv", "norm", "act"))
+        last = self._make_stages(norm_cfg, base_channels, block_type)
+        self.conv_out = make_sparse_convmodule(last, output_channels, kernel_size=(3, 1, 1), stride=(2, 1, 1),
+                                               norm_cfg=norm_cfg, padding=0, indice_key="spconv_down2",
+                                               conv_type="SparseConv3d")
+
+    def _make_stages(self, norm_cfg, in_channels, block_type):
+        self.encoder_layers = SparseSequential()
+        n_stage = len(self.encoder_channels)
+        out_channels = in_channels
+        for i, widths in enumerate(self.encoder_channels):
+            widths = tuple(widths)
+            blocks = []
+            for j, out_channels in enumerate(widths):
+                padding = tuple(self.encoder_paddings[i])[j]
+                down = dict(stride=2, padding=padding, indice_key=f"spconv{i + 1}", conv_type="SparseConv3d")
+                if block_type == "conv_module" and i != 0 and j == 0:
+                    blocks.append(make_sparse_convmodule(in_channels, out_channels, 3, norm_cfg=norm_cfg, **down))
+                elif block_type == "basicblock":
+                    if j == len(widths) - 1 and i != n_stage - 1:
+                        blocks.append(make_sparse_convmodule(in_channels, out_channels, 3, norm_cfg=norm_cfg, **down))
+                    else:
+                        blocks.append(SparseBasicBlock(out_channels, out_channels, norm_cfg=norm_cfg,
+                                                       conv_cfg=dict(type="SubMConv3d")))
+                else:
+                    blocks.append(make_sparse_convmodule(in_channels, out_channels, 3, norm_cfg=norm_cfg,
+                                                         padding=padding, indice_key=f"subm{i + 1}",
+                                                         conv_type="SubMConv3d"))
+                in_channels = out_channels
+            self.encoder_layers.add_module(f"encoder_layer{i + 1}", SparseSequential(*blocks))
+        return out_channels
+
+    def forward(self, voxel_features, coors, batch_size):
+        """(M,C) voxel features + (M,4) int (b,z,y,x) -> (B, C*D, H, W) BEV map."""
+        x = SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, int(batch_size))
+        x = self.conv_input(x)
+        for stage in self.encoder_layers._modules.values():
+            x = stage(x)
+        out = self.conv_out(x)
+        dense = out.dense()
+        N, C, D, H, W = dense.shape
+        return dense.view(N, C * D, H, W)

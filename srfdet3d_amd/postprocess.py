@@ -1,0 +1,37 @@
+"""Decode-side post-processing: per-class rotated NMS.
+
+Mirrors mmdet3d `box3d_multiclass_nms` as called at mmdet3d_plugin/models/sparse_heads/srfdet_head.py:1276-1293:
+per class keep score > score_thr, rotated NMS on the BEV boxes, concatenate, then top `max_num` by score.
+All classes go through ONE NMS launch: boxes of different classes are moved apart by a per-class offset larger
+than any box, so they never overlap (the standard batched-NMS trick), which gives the same keeps as the
+reference's per-class Python loop.
+"""
+import torch
+
+from . import ops
+
+
+def box3d_multiclass_nms(boxes, scores, score_thr, max_num, nms_thr):
+    """boxes (n, 7|9) [x,y,z,dx,dy,dz,yaw,...]; scores (n, #cls) -> (boxes, scores, labels), class-major order as
+    the reference produces before its final top-k."""
+    n, num_classes = scores.shape
+    cand = (scores > score_thr).nonzero(as_tuple=False)  # (m, 2): box index, class -- row-major in box index
+    if cand.shape[0] == 0:
+        return boxes.new_zeros((0, boxes.shape[1])), scores.new_zeros((0,)), scores.new_zeros((0,), dtype=torch.long)
+    # class-major order, original box order inside a class (what the per-class loop yields)
+    order = torch.argsort(cand[:, 1] * n + cand[:, 0])
+    bi, ci = cand[order, 0], cand[order, 1]
+    s = scores[bi, ci]
+    bev = boxes[bi][:, [0, 1, 3, 4, 6]].clone()
+    span = (bev[:, :2].abs().max() + bev[:, 2:4].abs().max()) * 4 + 1
+    bev[:, 0] = bev[:, 0] + ci.to(bev.dtype) * span
+    keep = ops.nms_rotated(bev, s, nms_thr)
+    keep = keep.sort()[0]  # back to class-major / in-class score order is not needed before the top-k below
+    # the reference appends, per class, boxes in descending score order
+    k2 = torch.argsort(ci[keep] * 4 - s[keep].clamp(0, 1) * 2, stable=True)
+    keep = keep[k2]
+    out_b, out_s, out_l = boxes[bi[keep]], s[keep], ci[keep]
+    if out_b.shape[0] > max_num:
+        top = out_s.sort(descending=True)[1][:max_num]
+        out_b, out_s, out_l = out_b[top], out_s[top], out_l[top]
+    return out_b, out_s, out_l
