@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the SRFDet3D hot path on synthetic nuScenes-shaped sweeps (BASELINE.json metric).
+
+A step = one frame through the whole path (voxelize -> VFE -> sparse encoder -> SECOND -> FPN -> 5-stage decoder ->
+decode + rotated NMS -> results on the host), inputs already resident in HBM.  One process per GPU; for N > 1 the
+driver launches this file under torch.distributed.run and every rank runs K frames of its own (weak scaling, frames
+are independent: no data-path collective); the job's time is the max over ranks.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline     -- the dominant hand-written kernel (the 128->128 SubM sparse conv on the f32 MFMA pipe), its
+                  algorithmic FLOPs per launch (2 * pairs * Cin * Cout) over its mean duration measured with HIP
+                  events on the launch stream inside the timed region, against the 157.3 TFLOP/s f32 MFMA peak;
+  cpu_baseline -- oracle/pipeline.py (the CPU port of the same path: C/OpenMP operators + torch-CPU dense layers)
+                  timed on this host, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+WORKLOADS = {
+    "nusc_L": dict(cfg="srfdet_voxel_nusc_L", desc="srfdet_voxel_nusc_L inference (LiDAR-only), synthetic 30k-pt sweep, "
+                   "grid 1472x1472x41, end-to-end incl. NMS"),
+    "nusc_LC": dict(cfg="srfdet_voxel_nusc_LC", desc="srfdet_voxel_nusc_LC inference (LiDAR + 6 cameras), synthetic 30k-pt "
+                    "sweep + 6x928x1600 images, end-to-end incl. NMS"),
+}
+
+
+def randomize_bn(model, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="nusc_L", choices=sorted(WORKLOADS))
+    ap.add_argument("--np", type=int, default=200, help="num_proposals override (BASELINE.json: np~200)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from srfdet3d_amd import ops, synthetic, workloads
+    from srfdet3d_amd.compat.boxes import LiDARInstance3DBoxes
+
+    wl = WORKLOADS[args.workload]
+    torch.manual_seed(0)
+    model_cpu = workloads.build(wl["cfg"], args.np).eval()
+    randomize_bn(model_cpu)
+    import copy
+    model = copy.deepcopy(model_cpu).to(dev)
+
+    # a small pool of distinct frames, resident in HBM before the timed region; rank r starts at frame r
+    n_pool = 8
+    frames = [torch.from_numpy(synthetic.nuscenes_sweep(2000 + i)).to(dev) for i in range(n_pool)]
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes)]
+    img = None
+    if model.use_img:
+        img = torch.from_numpy(synthetic.camera_images(3000)).to(dev)
+        metas[0]["lidar2img"] = [m for m in synthetic.camera_rig()]
+
+    def step(i):
+        with torch.no_grad():
+            return model.simple_test(img, [frames[(rank + i) % n_pool]], metas)
+
+    for i in range(args.warmup):
+        step(i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ops.KERNEL_TIMING = {"spconv": []}  # HIP-event pairs around every sparse-conv launch of the timed region
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    records = ops.KERNEL_TIMING["spconv"]
+    ops.KERNEL_TIMING = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        # dominant kernel: the 128 -> 128, 27-offset SubM conv (4 launches per frame on the 5x184x184 level)
+        dom = [(s.elapsed_time(e), flops, byts) for (s, e, cin, cout, K, flops, byts) in records
+               if cin == 128 and cout == 128 and K == 27]
+        roofline = None
+        if dom:
+            ms = sum(d[0] for d in dom) / len(dom)
+            flops = sum(d[1] for d in dom) / len(dom)
+            achieved = flops / (ms * 1e-3) / 1e12
+            roofline = dict(kernel="srf_spconv_mfma32_k<128,64,2,2> (SubM 3x3x3, 128->128)", bound="mfma",
+                            achieved=round(achieved, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                            launches=len(dom), avg_us=round(ms * 1e3, 2), algorithmic_flops_per_launch=int(flops),
+                            algorithmic_bytes_per_launch=int(sum(d[2] for d in dom) / len(dom)))
+        cpu_baseline = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import pipeline
+            torch.set_num_threads(os.cpu_count())
+            os.environ["OMP_NUM_THREADS"] = str(os.cpu_count())
+            pts = frames[0].cpu().numpy()
+            tc = time.perf_counter()
+            nfr = 0
+            while nfr < 1 or (time.perf_counter() - tc < 10.0 and nfr < 3):
+                pipeline.forward_to_decode(model_cpu, [pts], metas, img.cpu() if img is not None else None)
+                nfr += 1
+            dt = time.perf_counter() - tc
+            cpu_baseline = dict(value=round(nfr / dt, 4), unit="frames/s", cores=os.cpu_count(), kind="port",
+                                sample=f"{nfr} frame(s) of the same workload through oracle/pipeline.py "
+                                       f"(C/OpenMP operators + torch-CPU dense layers), {dt:.1f} s")
+        total_frames = args.steps * world
+        out = dict(metric=f"frames/sec, {wl['cfg']} synthetic 30k-pt sweeps", value=round(total_frames / elapsed, 3),
+                   unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
+                   vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=wl["desc"], num_proposals=args.np, points_per_frame=30000,
+                               frames_per_rank=args.steps, weights="seeded random init, randomised BN statistics",
+                               parallelism=f"replica per GPU x{world}, frames sharded, no data-path collective"),
+                   roofline=roofline, cpu_baseline=cpu_baseline)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

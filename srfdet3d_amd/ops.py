@@ -168,7 +168,11 @@ def rulebook_strided(indices, spatial_shape, batch, ksize, stride, pad):
 
 
 # ---------------------------------------------------------------------------------------------- sparse conv
-def spconv_fwd(feats, weight, nbr, alpha=None, beta=None, residual=None, relu=False):
+# bench.py sets this to {"spconv": []}: every sparse-conv launch is then bracketed by HIP events on the launch stream
+KERNEL_TIMING = None
+
+
+def spconv_fwd(feats, weight, nbr, alpha=None, beta=None, residual=None, relu=False, pair_counts=None):
     """feats (A_in,Cin); weight (K,Cin,Cout); nbr (K,A_out) (row stride nbr.stride(0)) -> (A_out,Cout)."""
     feats = _dev(feats, "feats", torch.float32)
     weight = _dev(weight, "weight", torch.float32)
@@ -179,11 +183,34 @@ def spconv_fwd(feats, weight, nbr, alpha=None, beta=None, residual=None, relu=Fa
     out = _empty((A_out, Cout), torch.float32, feats.device)
     if residual is not None:
         residual = _dev(residual, "residual", torch.float32)
+    timing = KERNEL_TIMING
+    if timing is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(_lib.lib().srf_spconv_fwd(_ptr(feats), feats.shape[0], Cin, _ptr(weight), K, _ptr(nbr),
                                     nbr.stride(0) if A_out > 0 else 0, A_out, Cout,
                                     _ptr(alpha), _ptr(beta), _ptr(residual), int(bool(relu)), _ptr(out), _stream()),
           "spconv_fwd")
+    if timing is not None:
+        ev1.record()
+        timing["spconv"].append(_SpconvRecord(ev0, ev1, Cin, Cout, K, feats.shape[0], A_out, pair_counts))
     return out
+
+
+class _SpconvRecord:
+    """(start, end, Cin, Cout, K, algorithmic flops, algorithmic bytes) of one launch; the pair count is read from the
+    rulebook's device counters only when the record is unpacked, after the timed region."""
+
+    def __init__(self, ev0, ev1, cin, cout, K, a_in, a_out, pair_counts):
+        self.v = (ev0, ev1, cin, cout, K)
+        self.a_in, self.a_out, self.pair_counts = a_in, a_out, pair_counts
+
+    def __iter__(self):
+        ev0, ev1, cin, cout, K = self.v
+        pairs = int(self.pair_counts.sum().item()) if self.pair_counts is not None else 0
+        flops = 2 * pairs * cin * cout
+        byts = 4 * (self.a_in * cin + self.a_out * cout) + 4 * K * cin * cout + 8 * pairs
+        return iter((ev0, ev1, cin, cout, K, flops, byts))
 
 
 def densify(feats, indices, batch, spatial_shape):

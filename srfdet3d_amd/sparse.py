@@ -116,8 +116,8 @@ class _SparseConv(SparseModule):
 
     def _rulebook(self, x):
         if self.subm:
-            nbr, _ = x.subm_rulebook(self.kernel_size)
-            return nbr, x.indices, x.spatial_shape
+            nbr, counts = x.subm_rulebook(self.kernel_size)
+            return nbr, counts, x.indices, x.spatial_shape
         key = ("strided", self.indice_key, tuple(self.kernel_size), tuple(self.stride), tuple(self.padding)) + \
             x._level_key()
         if key not in x.indice_dict:
@@ -125,12 +125,12 @@ class _SparseConv(SparseModule):
                                                                        self.kernel_size, self.stride, self.padding)
             x.indice_dict[key] = (out_idx, nbr, counts, oshape)
             x.indice_dict[("table", out_idx.data_ptr(), out_idx.shape[0], tuple(oshape))] = table
-        out_idx, nbr, _, oshape = x.indice_dict[key]
-        return nbr, out_idx, oshape
+        out_idx, nbr, counts, oshape = x.indice_dict[key]
+        return nbr, counts, out_idx, oshape
 
     def forward(self, x, bn=None, relu=False, residual=None):
         """conv, optionally with an eval-mode BatchNorm1d, residual rows and ReLU fused into the same kernel."""
-        nbr, out_idx, oshape = self._rulebook(x)
+        nbr, counts, out_idx, oshape = self._rulebook(x)
         K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
         w = self.weight.view(K, self.in_channels, self.out_channels)
         alpha = beta = None
@@ -140,7 +140,7 @@ class _SparseConv(SparseModule):
                 beta = beta + self.bias * alpha
         elif self.bias is not None:
             alpha, beta = torch.ones_like(self.bias), self.bias
-        feats = ops.spconv_fwd(x.features, w, nbr, alpha, beta, residual, relu)
+        feats = ops.spconv_fwd(x.features, w, nbr, alpha, beta, residual, relu, pair_counts=counts)
         return SparseConvTensor(feats, out_idx, oshape, x.batch_size, x.indice_dict)
 
 

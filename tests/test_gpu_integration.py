@@ -1,0 +1,74 @@
+"""Integration parity: the whole hot path of srfdet_voxel_nusc_L (np=200, seeded random weights, randomised BN
+statistics) on one synthetic 30k-point sweep, HIP path vs the CPU oracle pipeline (oracle/pipeline.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline
+from srfdet3d_amd import synthetic as S, workloads
+from srfdet3d_amd.compat.boxes import LiDARInstance3DBoxes
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomize_bn(model, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+
+
+@pytest.fixture(scope="module")
+def setup(dev):
+    torch.manual_seed(0)
+    cpu = workloads.build("srfdet_voxel_nusc_L", 200).eval()
+    _randomize_bn(cpu)
+    import copy
+    gpu = copy.deepcopy(cpu).to(dev)
+    pts = S.nuscenes_sweep(2000)
+    return cpu, gpu, pts
+
+
+def test_sparse_stage_is_exact_and_dense_stage_close(setup, dev):
+    cpu, gpu, pts = setup
+    vf, coors = pipeline.voxel_features(cpu, [pts])
+    bev_ref = pipeline.sparse_encoder(cpu.pts_middle_encoder, vf, coors, 1)
+    with torch.no_grad():
+        voxels, num, gc = gpu.voxelize([torch.from_numpy(pts).to(dev)])
+        gvf = gpu.pts_voxel_encoder(voxels, num, gc)
+        np.testing.assert_array_equal(gc.cpu().numpy(), coors)          # bit-exact voxel indices, first-seen order
+        np.testing.assert_array_equal(gvf.cpu().numpy(), vf)            # mean in slot order: exact
+        bev = gpu.pts_middle_encoder(gvf, gc, 1)
+        assert bev.shape == (1, 256, 184, 184)
+        # 21 sparse convs + BN + ReLU + residuals: identical f32 fma chains on both sides
+        assert np.array_equal(bev.cpu().numpy(), bev_ref), f"max diff {np.abs(bev.cpu().numpy() - bev_ref).max()}"
+        feats = gpu.pts_neck(gpu.pts_backbone(bev))
+        ref = cpu.pts_neck(cpu.pts_backbone(torch.from_numpy(bev_ref)))
+    for f, r in zip(feats, ref):
+        scale = r.abs().max().item()
+        assert (f.cpu() - r).abs().max().item() <= 2e-4 * scale  # MIOpen vs CPU conv: different summation order
+
+
+def test_decoder_stage_by_stage_on_real_features(setup, dev):
+    """GPU decoder vs the CPU oracle decoder on the SAME (GPU-produced) pyramid, every stage fed the GPU stage's inputs."""
+    cpu, gpu, pts = setup
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes)]
+    rec = []
+    hooks = [st.register_forward_pre_hook(lambda m, a: rec.append((a[1].detach().clone().cpu().numpy(),
+                                                                  a[2].detach().clone().cpu().numpy().reshape(1, 200, -1))))
+             for st in gpu.bbox_head.head_series_lidar]
+    with torch.no_grad():
+        feats = gpu.extract_point_features([torch.from_numpy(pts).to(dev)])
+        logits, boxes = gpu.bbox_head(None, feats, metas)
+    for h in hooks:
+        h.remove()
+    ref_logits, ref_boxes = pipeline.head_forward(cpu.bbox_head, None, [f.cpu() for f in feats], metas, stage_inputs=rec)
+    np.testing.assert_allclose(boxes.cpu().numpy(), ref_boxes.numpy(), rtol=0, atol=1e-4)   # north-star tolerance
+    np.testing.assert_allclose(logits.cpu().numpy(), ref_logits.numpy(), rtol=1e-4, atol=2e-4)
+    # decode (pre-NMS tensors, the parity contract of SURVEY.md a18)
+    s, b = gpu.bbox_head.decode(logits, boxes)
+    rs, rb = cpu.bbox_head.decode(ref_logits, ref_boxes)
+    np.testing.assert_allclose(b.cpu().numpy(), rb.numpy(), rtol=1e-5, atol=2e-4)
+    res = gpu.simple_test(None, [torch.from_numpy(pts).to(dev)], metas)
+    assert set(res[0]["pts_bbox"].keys()) == {"boxes_3d", "scores_3d", "labels_3d"}
