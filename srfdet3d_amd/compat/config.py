@@ -31,6 +31,11 @@ def _wrap(obj):
 
 
 class Config(ConfigDict):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        for k, v in dict(*args, **kwargs).items():
+            self[k] = _wrap(v)
+
     @staticmethod
     def fromfile(path):
         path = os.path.abspath(path)

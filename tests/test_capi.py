@@ -1,0 +1,64 @@
+"""The C-ABI library: loads without a GPU, exports every symbol include/srfdet3d.h declares, host-side helpers
+behave, and the Python layer refuses CPU tensors (there is no CPU fallback).  No compute call is made here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from srfdet3d_amd import _lib, ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "srfdet3d.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(srf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared()
+    assert len(names) >= 20
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in include/srfdet3d.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes signature table and header disagree"
+
+
+def test_host_side_helpers():
+    L = _lib.lib()
+    assert L.srf_abi_version() == 1
+    assert L.srf_error_string(0) == b"ok" and L.srf_error_string(-2) == b"workspace too small"
+    cap = L.srf_coord_table_capacity(30000)
+    assert cap >= 60000 and cap & (cap - 1) == 0
+    assert L.srf_coord_table_bytes(cap) == cap * 8
+    assert L.srf_hard_voxelize_workspace_bytes(30000, 10) > 65536 * 12 * 4
+    hi = _lib.hi
+    assert L.srf_strided_max_outputs(1000, 1, hi([41, 1472, 1472]), hi([3, 3, 3]), hi([2, 2, 2]), hi([1, 1, 1])) == 8000
+    assert L.srf_strided_max_outputs(1000, 1, hi([5, 184, 184]), hi([3, 1, 1]), hi([2, 1, 1]), hi([0, 0, 0])) == 2000
+    assert L.srf_strided_max_outputs(10 ** 6, 1, hi([5, 8, 8]), hi([3, 1, 1]), hi([2, 1, 1]), hi([0, 0, 0])) == 2 * 8 * 8
+    assert L.srf_nms_rotated_workspace_bytes(900) == 900 * 15 * 8
+    assert L.srf_voxel_unique_workspace_bytes(1000, hi([40, 1600, 1408]), 1) > 40 * 1600 * 1408 // 8
+    assert L.srf_voxel_unique_workspace_bytes(1000, hi([41, 1472, 1472]), 64) == 0  # exceeds 32-bit keys
+    # argument validation happens before any HIP call
+    assert L.srf_spconv_fwd(None, 0, 16, None, 27, None, 0, 10, 24, None, None, None, 0, None, None) == -1
+    assert L.srf_roi_extract(None, 0, 128, None, 0, 7, 2, 56.0, None, 0, 0, 0, 0, None, None) == -1
+
+
+def test_ops_refuse_cpu_tensors():
+    pts = torch.zeros(10, 5)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ops.hard_voxelize(pts, [0.1, 0.1, 0.1], [0, 0, 0, 1, 1, 1], 5, 10)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ops.coord_table_build(torch.zeros(4, 4, dtype=torch.int32), [4, 4, 4], 1)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ops.box_rois(torch.zeros(1, 4, 10), [0, 0, 0, 1, 1, 1], [0.1, 0.1, 0.1])
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()

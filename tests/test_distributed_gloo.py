@@ -1,0 +1,70 @@
+"""world_size-2 gloo tests of the multi-process pieces: the synchronised BN statistics
+(collectives C2/C3) and the frame sharding / max-over-ranks timing reduction that bench.py uses."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from srfdet3d_amd.plugin.norm import NaiveSyncBatchNorm1dCustom
+    torch.manual_seed(0)
+    full = torch.randn(64, 5)
+    x = full[rank::world].clone().requires_grad_(True)
+    bn = NaiveSyncBatchNorm1dCustom(5, eps=1e-3, momentum=0.1).train()
+    y = bn(x)
+    y.square().sum().backward()
+    # frame sharding: rank r takes frames r, r+world, ...; job time = max over ranks
+    frames = list(range(rank, 10, world))
+    t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    q.put((rank, y.detach(), bn.running_mean.clone(), bn.running_var.clone(), x.grad.clone(), frames, t.item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_bn_and_sharding_two_ranks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    full = torch.randn(64, 5)
+    # equal shards: mean of per-rank means == global mean; the reference uses biased var (E[x^2]-E[x]^2) for
+    # both the normalisation and the running estimate (norm.py:72-75)
+    mean = full.mean(0)
+    var = (full * full).mean(0) - mean * mean
+    want = (full - mean) / torch.sqrt(var + 1e-3)
+    for rank, y, rm, rv, grad, frames, tmax in res:
+        torch.testing.assert_close(y, want[rank::world], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(rm, 0.1 * mean, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(rv, 0.9 * torch.ones(5) + 0.1 * var, rtol=1e-5, atol=1e-6)
+        assert frames == list(range(rank, 10, world))
+        assert abs(tmax - 0.2) < 1e-12
+    # gradient through the synchronised statistics equals single-process autograd on the concatenated batch
+    xf = full.clone().requires_grad_(True)
+    m = xf.mean(0)
+    v = (xf * xf).mean(0) - m * m
+    (((xf - m) / torch.sqrt(v + 1e-3)).square().sum()).backward()
+    for rank, *_rest in res:
+        torch.testing.assert_close(res[rank][4], xf.grad[rank::world], rtol=1e-4, atol=1e-5)
+    assert sorted(res[0][5] + res[1][5]) == list(range(10))

@@ -1,0 +1,91 @@
+"""Host-side modules that are plain torch (dense backbone, FPN, VFE, BN folding, weight-layout conversion)."""
+import numpy as np
+import torch
+
+import srfdet3d_amd as S
+from srfdet3d_amd import sparse, workloads
+from srfdet3d_amd.compat import necks
+from srfdet3d_amd.plugin import backbones, norm, voxel_encoders
+
+
+def test_second_and_fpn_shapes_nusc():
+    m = workloads.model_cfg("srfdet_voxel_nusc_L")
+    bb = S.compat.build_backbone(m.pts_backbone).eval()
+    neck = S.compat.build_neck(m.pts_neck).eval()
+    x = torch.randn(1, 256, 48, 40)
+    with torch.no_grad():
+        o = bb(x)
+        f = neck(o)
+    assert [tuple(t.shape) for t in o] == [(1, 128, 48, 40), (1, 256, 24, 20)]
+    assert [tuple(t.shape) for t in f] == [(1, 128, 48, 40), (1, 128, 24, 20), (1, 128, 12, 10), (1, 128, 6, 5)]
+    assert sum(isinstance(l, torch.nn.Conv2d) for l in bb.modules()) == 12  # SURVEY.md finding 5: 12 dense 3x3 convs
+
+
+def test_fpn_without_extra_convs_uses_maxpool_kitti():
+    m = workloads.model_cfg("srfdet_voxel_kitti_L")
+    neck = S.compat.build_neck(m.pts_neck).eval()
+    assert len(neck.fpn_convs) == 2
+    with torch.no_grad():
+        f = neck((torch.randn(1, 128, 40, 36), torch.randn(1, 256, 20, 18)))
+    assert [tuple(t.shape) for t in f] == [(1, 256, 40, 36), (1, 256, 20, 18), (1, 256, 10, 9), (1, 256, 5, 5)]
+    torch.testing.assert_close(f[2], f[1][:, :, ::2, ::2])
+
+
+def test_hard_simple_vfe_mean():
+    vfe = voxel_encoders.HardSimpleVFE(5)
+    v = torch.zeros(3, 10, 5)
+    v[0, :2] = torch.tensor([[1., 2, 3, 4, 5], [3., 4, 5, 6, 7]])
+    v[1, :1] = 1.0
+    v[2, :10] = torch.arange(50.).view(10, 5)
+    out = vfe(v, torch.tensor([2, 1, 10]), None)
+    torch.testing.assert_close(out[0], torch.tensor([2., 3, 4, 5, 6]))
+    torch.testing.assert_close(out[2], v[2].mean(0))
+
+
+def test_bn_fold_matches_eval_batchnorm():
+    bn = torch.nn.BatchNorm1d(32, eps=1e-3).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+        bn.running_mean.normal_(0, 0.1)
+        bn.running_var.uniform_(0.5, 1.5)
+    a, b = sparse._fold_bn(bn)
+    x = torch.randn(100, 32)
+    torch.testing.assert_close(torch.addcmul(b, x, a), bn(x), rtol=1e-6, atol=1e-6)
+    a2, _ = sparse._fold_bn(bn)
+    assert a2.data_ptr() == a.data_ptr()  # cached
+    with torch.no_grad():
+        bn.running_var.mul_(2.0)
+    a3, _ = sparse._fold_bn(bn)
+    assert not torch.equal(a3, a)  # cache invalidated by the in-place update
+
+
+def test_spconv2_weight_layout_is_converted_on_load():
+    conv = sparse.SubMConv3d(4, 8, 3, padding=1, bias=False)
+    w1 = torch.randn(3, 3, 3, 4, 8)
+    conv.load_state_dict({"weight": w1.permute(4, 0, 1, 2, 3).contiguous()})  # spconv 2.x: (Cout, kD, kH, kW, Cin)
+    torch.testing.assert_close(conv.weight.data, w1)
+    conv.load_state_dict({"weight": w1 * 2})
+    torch.testing.assert_close(conv.weight.data, w1 * 2)
+
+
+def test_sparse_encoder_layer_inventory_nusc():
+    enc = S.compat.build_middle_encoder(workloads.model_cfg("srfdet_voxel_nusc_L").pts_middle_encoder)
+    convs = [m for m in enc.modules() if isinstance(m, sparse._SparseConv)]
+    assert sum(c.subm for c in convs) == 17 and sum(not c.subm for c in convs) == 4
+    assert enc.conv_out[0].kernel_size == [3, 1, 1] and enc.conv_out[0].stride == [2, 1, 1]
+    l3 = enc.encoder_layers.encoder_layer3[2][0]
+    assert l3.padding == [0, 1, 1] and l3.out_channels == 128
+    enc_k = S.compat.build_middle_encoder(workloads.model_cfg("srfdet_voxel_kitti_L").pts_middle_encoder)
+    convs = [m for m in enc_k.modules() if isinstance(m, sparse._SparseConv)]
+    assert [c.out_channels for c in convs] == [16, 16, 32, 32, 32, 64, 64, 64, 64, 64, 64, 128]
+
+
+def test_naive_sync_bn_single_process_is_plain_bn():
+    bn = norm.NaiveSyncBatchNorm1dCustom(6, eps=1e-3, momentum=0.01)
+    ref = torch.nn.BatchNorm1d(6, eps=1e-3, momentum=0.01)
+    ref.load_state_dict(bn.state_dict())
+    x = torch.randn(50, 6)
+    torch.testing.assert_close(bn(x), ref(x))
+    bn.eval(), ref.eval()
+    torch.testing.assert_close(bn(x), ref(x))
