@@ -119,7 +119,7 @@ int srf_rulebook_strided_pairs(int A, const int *ksize, const void *out_table, i
  * make_sparse_convmodule / SparseBasicBlock) on the path sparse_encoder_custom.py:125-134.
  * out[o] = sum_k W[k]^T in[nbr[k][o]] accumulated as an f32 fma chain (k ascending, c ascending);
  * then y = fma(x, alpha, beta) if alpha, y += residual[o] if residual, y = max(y,0) if relu.
- * W: (K, Cin, Cout) row-major.  Supported Cout: 16, 32, 64, 128; Cin: 1..128.
+ * W: (K, Cin, Cout) row-major.  Supported Cout: 16 (any Cin <= 512) and 32, 64, 128 (Cin a multiple of 4).
  * ------------------------------------------------------------------------------------------------------- */
 int srf_spconv_fwd(const float *in, int A_in, int Cin, const float *W, int K, const int *nbr, int nbr_stride,
                    int A_out, int Cout, const float *alpha, const float *beta, const float *residual, int relu,

@@ -76,7 +76,73 @@ __device__ __forceinline__ void srf_load_nbr_tile(const int *__restrict__ nbr, i
     __syncthreads();
 }
 
-// COUT in {32, 64, 128}: waves arranged WR x WC, each owning 32 x (CT*32) outputs
+// ---- pipelined wide kernel (COUT in {32, 64, 128}) ------------------------------------------------------------------
+// Branch-free loads (Cin % 4 == 0 is required by the launcher): a missing neighbour or a channel beyond Cin reads a
+// valid clamped address and is zeroed by a select, so all loads of a step stay in flight together.  The staging
+// registers are native vectors (f32x4), not HIP's float4 struct: arrays of the union-based struct are not split into
+// registers by the compiler and end up round-tripping through LDS.
+template <int COUT, int TM, int NA, int NW>
+__device__ __forceinline__ void srf_step_load(const float *__restrict__ in, int Cin, const float *__restrict__ W,
+                                              const int *nbr_k /* this offset's TM entries: LDS tile or nbr + k*stride + row0 */, int rows_left,
+                                              int k, int c0, f32x4 (&ra)[NA], f32x4 (&rw)[NW], unsigned &okmask)
+{
+    const int tid = threadIdx.x;
+    const float *Wk = W + (size_t)k * Cin * COUT;
+    // the zeroing select is applied at store time (srf_step_store): touching the loaded value here would make the
+    // compiler wait for the load before the MFMA block it is meant to overlap
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int e = tid + j * 256;
+        const int r = e / (SRF_KC / 4), q = e % (SRF_KC / 4);
+        const int i = r < rows_left ? nbr_k[r] : -1;  // L2-resident; 8 lanes share one entry
+        const int c = c0 + q * 4;
+        const bool ok = (i >= 0) & (c < Cin);
+        const int ii = i >= 0 ? i : 0;
+        const int cc = c < Cin ? c : Cin - 4;
+        ra[j] = *reinterpret_cast<const f32x4 *>(in + (size_t)ii * Cin + cc);
+        m |= (ok ? 1u : 0u) << j;
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int e = tid + j * 256;
+        const int c = e / (COUT / 4), q = e % (COUT / 4);
+        const bool ok = c0 + c < Cin;
+        const int cc = ok ? c0 + c : Cin - 1;
+        rw[j] = *reinterpret_cast<const f32x4 *>(Wk + (size_t)cc * COUT + q * 4);
+        m |= (ok ? 1u : 0u) << (NA + j);
+    }
+    okmask = m;
+}
+
+template <int COUT, int TM, int NA, int NW>
+__device__ __forceinline__ void srf_step_store(float (*s_a)[SRF_KC + 1], float (*s_w)[COUT], const f32x4 (&ra)[NA],
+                                               const f32x4 (&rw)[NW], unsigned okmask)
+{
+    const int tid = threadIdx.x;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int e = tid + j * 256;
+        float *dst = &s_a[e / (SRF_KC / 4)][(e % (SRF_KC / 4)) * 4];
+        const f32x4 v = ((okmask >> j) & 1u) ? ra[j] : zero;
+        dst[0] = v[0];
+        dst[1] = v[1];
+        dst[2] = v[2];
+        dst[3] = v[3];
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int e = tid + j * 256;
+        *reinterpret_cast<f32x4 *>(&s_w[e / (COUT / 4)][(e % (COUT / 4)) * 4]) = ((okmask >> (NA + j)) & 1u) ? rw[j] : zero;
+    }
+}
+
+// Waves arranged WR x WC, each owning 32 x (CT*32) outputs.  Software pipeline: the global loads of step t+1 (gathered
+// rows + W slab, held in registers) are in flight while the MFMAs of step t run from LDS buffer t&1; they are written
+// to buffer (t+1)&1 afterwards; one barrier per step.  Steps enumerate (active kernel offset, 32-channel chunk)
+// pairs; offsets that no row of the tile uses are not visited.  A chunk is always 32 deep (zero padded), so the MFMA
+// loop is fully unrolled and its LDS reads are hoisted ahead of the MFMAs by the compiler.
 template <int COUT, int TM, int WR, int WC>
 __global__ __launch_bounds__(256) void srf_spconv_mfma32_k(const float *__restrict__ in, int Cin,
                                                          const float *__restrict__ W, int K,
@@ -87,15 +153,40 @@ __global__ __launch_bounds__(256) void srf_spconv_mfma32_k(const float *__restri
 {
     static_assert(WR * WC == 4 && TM == WR * 32, "one 32-row tile per wave row");
     constexpr int CT = COUT / WC / 32;
-    __shared__ int s_nbr[SRF_KMAX * TM];
+    constexpr int NA = TM * (SRF_KC / 4) / 256;    // float4 gathers per thread and step
+    constexpr int NW = SRF_KC * (COUT / 4) / 256;  // float4 weight loads per thread and step
+    // COUT = 128 leaves the 27 x TM neighbour tile in L2 (it would cost the third resident workgroup per CU);
+    // the narrower kernels have LDS to spare and keep it on chip
+    constexpr bool NBR_LDS = COUT < 128;
+    __shared__ int s_nbr[NBR_LDS ? SRF_KMAX * TM : 1];
     __shared__ int s_any[SRF_KMAX];
-    __shared__ float s_a[TM][SRF_KC + 1];
-    __shared__ __attribute__((aligned(16))) float s_w[SRF_KC][COUT];
+    __shared__ int s_klist[SRF_KMAX + 1];
+    __shared__ float s_a[2][TM][SRF_KC + 1];
+    __shared__ __attribute__((aligned(16))) float s_w[2][SRF_KC][COUT];
 
     const int row0 = blockIdx.x * TM;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
-    srf_load_nbr_tile<TM>(nbr, nbr_stride, K, row0, A_out, s_nbr, s_any);
+    const int rows_left = A_out - row0;
+    if (tid < SRF_KMAX) s_any[tid] = 0;
+    __syncthreads();
+    for (int t = tid; t < K * TM; t += 256) {
+        const int k = t / TM, r = t % TM;
+        const int v = r < rows_left ? nbr[(size_t)k * nbr_stride + row0 + r] : -1;
+        if (NBR_LDS) s_nbr[t] = v;
+        if (v >= 0) s_any[k] = 1;  // benign race: every writer stores 1
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int k = 0; k < K; ++k)
+            if (s_any[k]) s_klist[n++] = k;
+        s_klist[SRF_KMAX] = n;
+    }
+    __syncthreads();
+    const int nchunk = (Cin + SRF_KC - 1) / SRF_KC;
+    const int T = s_klist[SRF_KMAX] * nchunk;
 
     f32x16 acc[CT];
 #pragma unroll
@@ -103,25 +194,41 @@ __global__ __launch_bounds__(256) void srf_spconv_mfma32_k(const float *__restri
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[ct][j] = 0.0f;
 
+    f32x4 ra[NA], rw[NW];
+    unsigned okmask = 0;
     const int ar = wr * 32 + (lane & 31);
     const int kh = lane >> 5;
-    for (int k = 0; k < K; ++k) {
-        if (!s_any[k]) continue;  // block-uniform
-        const float *Wk = W + (size_t)k * Cin * COUT;
-        for (int c0 = 0; c0 < Cin; c0 += SRF_KC) {
-            __syncthreads();
-            srf_stage_tile<TM, COUT>(in, Cin, Wk, c0, s_nbr + k * TM, s_a, s_w);
-            __syncthreads();
-            const int kc = (Cin - c0) < SRF_KC ? (Cin - c0) : SRF_KC;
-            for (int kk = 0; kk < kc; kk += 2) {
-                const float a = s_a[ar][kk + kh];
+    if (T > 0) {
+        const int k0 = s_klist[0];
+        srf_step_load<COUT, TM, NA, NW>(in, Cin, W, NBR_LDS ? s_nbr + k0 * TM : nbr + (size_t)k0 * nbr_stride + row0,
+                                        NBR_LDS ? TM : rows_left, k0, 0, ra, rw, okmask);
+        srf_step_store<COUT, TM, NA, NW>(s_a[0], s_w[0], ra, rw, okmask);
+    }
+    __syncthreads();
+    int tk = 0, tc = 0;  // (offset index, chunk index) of step t+1
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        if (++tc == nchunk) {
+            tc = 0;
+            ++tk;
+        }
+        const bool more = t + 1 < T;
+        if (more) {
+            const int kn = s_klist[tk];
+            srf_step_load<COUT, TM, NA, NW>(in, Cin, W, NBR_LDS ? s_nbr + kn * TM : nbr + (size_t)kn * nbr_stride + row0,
+                                            NBR_LDS ? TM : rows_left, kn, tc * SRF_KC, ra, rw, okmask);
+        }
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const float b = s_w[kk + kh][(wc * CT + ct) * 32 + (lane & 31)];
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ct], 0, 0, 0);
-                }
+        for (int kk = 0; kk < SRF_KC; kk += 2) {
+            const float a = s_a[buf][ar][kk + kh];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const float b = s_w[buf][kk + kh][(wc * CT + ct) * 32 + (lane & 31)];
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ct], 0, 0, 0);
             }
         }
+        if (more) srf_step_store<COUT, TM, NA, NW>(s_a[buf ^ 1], s_w[buf ^ 1], ra, rw, okmask);
+        __syncthreads();
     }
 
     // epilogue: C/D layout of 32x32: col = lane & 31, row = (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5)
@@ -207,6 +314,7 @@ extern "C" int srf_spconv_fwd(const float *in, int A_in, int Cin, const float *W
     if ((alpha == nullptr) != (beta == nullptr)) return SRF_EINVAL;
     if (A_out == 0) return SRF_OK;
     if (!in || !W || !nbr || !out) return SRF_EINVAL;
+    if (Cout != 16 && ((Cin & 3) || A_in == 0)) return SRF_EUNSUPPORTED;  // the wide kernels gather whole float4s
     hipStream_t st = (hipStream_t)stream;
 #define SRF_ARGS in, Cin, W, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out
     switch (Cout) {
