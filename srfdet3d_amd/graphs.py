@@ -1,0 +1,55 @@
+"""HIP-graph replay of the static-shape tail of the path.
+
+Everything after `SparseConvTensor.dense()` has shapes fixed by the config (BEV map -> SECOND -> FPN -> 5 decoder
+stages -> decode), and at 30k points it is launch-bound: ~500 small launches per frame.  `GraphedTail` captures that
+tail once per input shape into a hipGraph (through torch.cuda.CUDAGraph, which is hipGraph on ROCm) and replays it;
+the data-dependent head of the path (voxelization, rulebooks, sparse convs) and the NMS stay eager.
+
+Capture is legal because nothing in the tail allocates through hipMalloc, synchronises or reads back to the host:
+the C-ABI entry points only enqueue on the current stream, and workspaces come from torch's graph-private pool.
+"""
+import torch
+
+
+class GraphedTail:
+    def __init__(self, model, warmup=3):
+        self.model = model
+        self.warmup = warmup
+        self.entries = {}
+
+    def _run(self, bev, img_feats, img_metas):
+        m = self.model
+        x = m.pts_backbone(bev)
+        if m.pts_neck is not None:
+            x = m.pts_neck(x)
+        logits, boxes = m.bbox_head(img_feats, x, img_metas)
+        return m.bbox_head.decode(logits, boxes)
+
+    def __call__(self, bev, img_feats, img_metas):
+        key = (tuple(bev.shape), None if img_feats is None else tuple(tuple(f.shape) for f in img_feats))
+        e = self.entries.get(key)
+        if e is None:
+            e = self._capture(key, bev, img_feats, img_metas)
+        e["bev"].copy_(bev)
+        if img_feats is not None:
+            for dst, src in zip(e["img"], img_feats):
+                dst.copy_(src)
+        e["graph"].replay()
+        return e["scores"], e["boxes"]
+
+    def _capture(self, key, bev, img_feats, img_metas):
+        static_bev = bev.clone()
+        static_img = [f.clone() for f in img_feats] if img_feats is not None else None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(self.warmup):  # MIOpen / rocBLAS pick their kernels here, outside the capture
+                self._run(static_bev, static_img, img_metas)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            scores, boxes = self._run(static_bev, static_img, img_metas)
+        e = dict(graph=graph, bev=static_bev, img=static_img, scores=scores, boxes=boxes)
+        self.entries[key] = e
+        return e

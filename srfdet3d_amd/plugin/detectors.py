@@ -46,6 +46,15 @@ class SRFDet(BaseModule):
         self.bbox_head = build_head(bbox_head)
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
+        self._graphed_tail = None
+
+    def enable_hip_graphs(self, enabled=True):
+        """Replay the static-shape tail (SECOND -> FPN -> decoder -> decode) as a captured hipGraph in `simple_test`
+        (see srfdet3d_amd/graphs.py).  Results are identical to the eager path; opt-in because a graph pins its
+        buffers for the lifetime of the model."""
+        from ..graphs import GraphedTail
+        self._graphed_tail = GraphedTail(self) if enabled else None
+        return self
 
     def init_weights(self):
         super().init_weights()
@@ -71,9 +80,17 @@ class SRFDet(BaseModule):
             points = [points]
         return self.simple_test(img[0], points[0], img_metas[0], **kwargs)
 
-    def simple_test(self, img, points, img_metas, rescale=False):
+    def _test_bboxes(self, img, points, img_metas):
+        if self._graphed_tail is not None and not self.training and points is not None:
+            img_feats = self.extract_img_feat(img, img_metas) if img is not None else None
+            bev = self.extract_bev(points)
+            scores, boxes = self._graphed_tail(bev, img_feats, img_metas)
+            return self.bbox_head.get_bboxes(None, None, img_metas, decoded=(scores, boxes))
         img_feats, point_feats = self.extract_feat(img, points, img_metas)
-        bbox_list = self.bbox_head.simple_test_bboxes(img_feats, point_feats, img_metas)
+        return self.bbox_head.simple_test_bboxes(img_feats, point_feats, img_metas)
+
+    def simple_test(self, img, points, img_metas, rescale=False):
+        bbox_list = self._test_bboxes(img, points, img_metas)
         return [dict(pts_bbox=bbox3d2result(b, s, l)) for b, s, l in bbox_list]
 
     # ---- features ------------------------------------------------------------------------------------------------
@@ -116,6 +133,13 @@ class SRFDet(BaseModule):
         return torch.cat(points, 0), torch.cat(coors, 0)
 
     def extract_point_features(self, points):
+        x = self.pts_backbone(self.extract_bev(points))
+        if self.pts_neck is not None:
+            x = self.pts_neck(x)
+        return x
+
+    def extract_bev(self, points):
+        """points -> dense BEV map (B, C*D, H, W): the data-dependent part of the path (voxelize, VFE, sparse encoder)."""
         batch_size = len(points)
         if self.pts_voxel_layer_cfg["max_num_points"] != -1:
             voxels, num_points, coors = self.voxelize(points)
@@ -125,11 +149,7 @@ class SRFDet(BaseModule):
             voxel_features, coors = self.pts_voxel_encoder(pts, pt_coors)
         # the reference derives batch_size from coors[-1, 0] + 1 (srfdet.py:258, :271), a device->host sync; the
         # number of point clouds handed in is the same number whenever the last sample has at least one voxel
-        x = self.pts_middle_encoder(voxel_features, coors, batch_size)
-        x = self.pts_backbone(x)
-        if self.pts_neck is not None:
-            x = self.pts_neck(x)
-        return x
+        return self.pts_middle_encoder(voxel_features, coors, batch_size)
 
 
 @DETECTORS.register_module()
@@ -137,6 +157,4 @@ class SRFDetWaymo(SRFDet):
     """Same model; results are returned without the `pts_bbox` wrapper (srfdetwaymo.py:13-41)."""
 
     def simple_test(self, img, points, img_metas, rescale=False):
-        img_feats, point_feats = self.extract_feat(img, points, img_metas)
-        bbox_list = self.bbox_head.simple_test_bboxes(img_feats, point_feats, img_metas)
-        return [bbox3d2result(b, s, l) for b, s, l in bbox_list]
+        return [bbox3d2result(b, s, l) for b, s, l in self._test_bboxes(img, points, img_metas)]

@@ -30,6 +30,20 @@ from .bbox_util import denormalize_bbox
 _DEFAULT_SCALE_CLAMP = math.log(100000.0 / 16)
 
 
+_CONSTS = {}
+
+
+def _const(values, like):
+    """small constant tensor on `like`'s device, uploaded once (a host->device copy per call would also be illegal
+    inside a hipGraph capture)."""
+    key = (tuple(float(v) for v in values), like.device, like.dtype)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = torch.tensor(key[0], dtype=like.dtype, device=like.device)
+        _CONSTS[key] = t
+    return t
+
+
 def _channels_last(feats):
     return [f if f.is_contiguous(memory_format=torch.channels_last) else f.contiguous(memory_format=torch.channels_last)
             for f in feats]
@@ -191,14 +205,14 @@ class _StageBase(BaseModule):
         """deltas (N,D) applied to boxes (N,D) [cx,cy,cz (m), log w,l,h, sin, cos, (vx,vy)] -> boxes with centres
         normalised to [0,1] by the range; sin/cos/velocity are taken from the deltas (srfdet_head.py:1534-1625)."""
         boxes = boxes.to(deltas.dtype)
-        w = deltas.new_tensor(self.bbox_weights[:6])
+        w = _const(self.bbox_weights[:6], deltas)
         d = deltas[:, :6] / w
         size = boxes[:, 3:6].exp()
         ctr = d[:, :3] * size + boxes[:, :3]
         new_size = d[:, 3:6].clamp(max=self.scale_clamp).exp() * size
         r = self.pc_range_lidar
-        lo = deltas.new_tensor(r[:3])
-        ext = deltas.new_tensor([r[3] - r[0], r[4] - r[1], r[5] - r[2]])
+        lo = _const(r[:3], deltas)
+        ext = _const([r[3] - r[0], r[4] - r[1], r[5] - r[2]], deltas)
         ctr = ((ctr - lo) / ext).clamp(min=0.0, max=1.0)
         return torch.cat([ctr, new_size.log(), deltas[:, 6:]], dim=-1)
 
@@ -412,8 +426,8 @@ class SRFDetHead(BaseModule):
             boxes = pred.detach().clone()
 
         r = self.pc_range
-        lo = point_feats[0].new_tensor(r[:3])
-        ext = point_feats[0].new_tensor([r[3] - r[0], r[4] - r[1], r[5] - r[2]])
+        lo = _const(r[:3], point_feats[0])
+        ext = _const([r[3] - r[0], r[4] - r[1], r[5] - r[2]], point_feats[0])
         if self.deep_supervision:
             logits_all, boxes_all = torch.stack(logits_all), torch.stack(boxes_all)
         else:
@@ -433,10 +447,10 @@ class SRFDetHead(BaseModule):
         boxes[..., 2] = boxes[..., 2] - boxes[..., 5] * 0.5
         return scores, boxes
 
-    def get_bboxes(self, pred_logits, pred_bboxes, img_metas):
+    def get_bboxes(self, pred_logits, pred_bboxes, img_metas, decoded=None):
         from ..postprocess import box3d_multiclass_nms
         cfg = self.test_cfg
-        scores_all, boxes_all = self.decode(pred_logits, pred_bboxes)
+        scores_all, boxes_all = decoded if decoded is not None else self.decode(pred_logits, pred_bboxes)
         results = []
         for i in range(scores_all.shape[0]):
             scores, boxes = scores_all[i], boxes_all[i]
@@ -448,7 +462,7 @@ class SRFDetHead(BaseModule):
                 scores, idx = scores.flatten(0, 1).topk(cfg["max_per_img"])
                 labels = idx % self.num_classes
                 boxes = boxes[idx // self.num_classes]
-            rng = torch.tensor(cfg["post_center_range"], device=scores.device)
+            rng = _const(cfg["post_center_range"], scores)
             keep = (boxes[..., :3] >= rng[:3]).all(1) & (boxes[..., :3] <= rng[3:]).all(1)
             results.append([box_type(boxes[keep], boxes.shape[-1]), scores[keep], labels[keep]])
         return results

@@ -72,3 +72,17 @@ def test_decoder_stage_by_stage_on_real_features(setup, dev):
     np.testing.assert_allclose(b.cpu().numpy(), rb.numpy(), rtol=1e-5, atol=2e-4)
     res = gpu.simple_test(None, [torch.from_numpy(pts).to(dev)], metas)
     assert set(res[0]["pts_bbox"].keys()) == {"boxes_3d", "scores_3d", "labels_3d"}
+
+
+def test_hip_graph_tail_equals_eager(setup, dev):
+    cpu, gpu, pts = setup
+    import copy
+    g = copy.deepcopy(gpu).enable_hip_graphs()
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes)]
+    for seed in (2000, 2001, 2000):
+        p = torch.from_numpy(S.nuscenes_sweep(seed)).to(dev)
+        with torch.no_grad():
+            a = gpu.simple_test(None, [p], metas)[0]["pts_bbox"]
+            b = g.simple_test(None, [p], metas)[0]["pts_bbox"]
+        assert torch.equal(a["scores_3d"], b["scores_3d"]) and torch.equal(a["labels_3d"], b["labels_3d"])
+        assert torch.equal(a["boxes_3d"].tensor, b["boxes_3d"].tensor)
