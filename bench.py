@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--np", type=int, default=200, help="num_proposals override (BASELINE.json: np~200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not replay the static tail as a hipGraph")
+    ap.add_argument("--img-dtype", default="fp32", choices=["fp32", "fp16", "bf16"],
+                    help="LC only: run the image backbone+neck under autocast (the reference's auto_fp16 mode); "
+                         "fp32 is the default and the only setting the headline number may use")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -76,6 +79,9 @@ def main():
     model = copy.deepcopy(model_cpu).to(dev)
     if not args.eager:
         model.enable_hip_graphs()
+    if args.img_dtype != "fp32":
+        model.img_autocast_dtype = dict(fp16=torch.float16, bf16=torch.bfloat16)[args.img_dtype]
+        model.img_backbone.to(memory_format=torch.channels_last)
 
     # a small pool of distinct frames, resident in HBM before the timed region; rank r starts at frame r
     n_pool = 8
@@ -150,7 +156,8 @@ def main():
         out = dict(metric=f"frames/sec, {wl['cfg']} synthetic 30k-pt sweeps", value=round(total_frames / elapsed, 3),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
-                   vs_baseline=None, dtype="f32", data="synthetic",
+                   vs_baseline=None, dtype="f32" if args.img_dtype == "fp32" else f"f32 (image branch {args.img_dtype})",
+                   data="synthetic",
                    config=dict(workload=wl["desc"], num_proposals=args.np, points_per_frame=30000,
                                frames_per_rank=args.steps, hip_graph_tail=not args.eager, weights="seeded random init, randomised BN statistics",
                                parallelism=f"replica per GPU x{world}, frames sharded, no data-path collective"),

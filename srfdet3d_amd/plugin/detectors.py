@@ -47,6 +47,10 @@ class SRFDet(BaseModule):
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
         self._graphed_tail = None
+        # None = fp32 (the configs' default).  torch.float16 / torch.bfloat16 run the image backbone + neck under
+        # autocast with fp32 outputs, i.e. the reference's `auto_fp16(apply_to=('img'), out_fp32=True)` mode
+        # (srfdet.py:141); opt-in, never the default.
+        self.img_autocast_dtype = None
 
     def enable_hip_graphs(self, enabled=True):
         """Replay the static-shape tail (SECOND -> FPN -> decoder -> decode) as a captured hipGraph in `simple_test`
@@ -106,12 +110,13 @@ class SRFDet(BaseModule):
             meta.update(input_shape=img.shape[-2:])
         if img.dim() == 5:
             img = img.reshape(-1, *img.shape[2:])
-        feats = self.img_backbone(img)
-        if isinstance(feats, dict):
-            feats = list(feats.values())
-        if self.img_neck is not None:
-            feats = self.img_neck(feats)
-        return [f.view(B, f.shape[0] // B, *f.shape[1:]) for f in feats]
+        with torch.autocast(img.device.type, dtype=self.img_autocast_dtype, enabled=self.img_autocast_dtype is not None):
+            feats = self.img_backbone(img)
+            if isinstance(feats, dict):
+                feats = list(feats.values())
+            if self.img_neck is not None:
+                feats = self.img_neck(feats)
+        return [f.float().view(B, f.shape[0] // B, *f.shape[1:]) for f in feats]
 
     @torch.no_grad()
     def voxelize(self, points):

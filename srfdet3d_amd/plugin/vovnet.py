@@ -1,0 +1,135 @@
+"""`VoVNet` image backbone (mmdet3d_plugin/models/backbones/vovnet.py:268-374): one-shot-aggregation stages with eSE
+attention; V-99-eSE feeds the LC configs (configs/nus/srfdet_voxel_nusc_LC.py:44-54).
+
+Plain dense convolutions (torch -> MIOpen): SURVEY.md ranks it "next" (8f-2), not a hand-kernel target.  It is here
+so that the LC workload runs end to end; module and parameter names follow the reference so its checkpoints load
+(`stem.stem_1/conv.weight`, `stage3.OSA3_2.layers.0.OSA3_2_0/conv.weight`, `...concat.OSA3_2_concat/conv.weight`,
+`...ese.fc.weight`).
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.modules.batchnorm import _BatchNorm
+
+from ..compat.cnn import BaseModule
+from ..compat.registry import BACKBONES
+
+# name: (stem widths, per-stage conv width, per-stage output width, layers per block, blocks per stage, depthwise)
+SPECS = {
+    "V-19-slim-dw-eSE": ((64, 64, 64), (64, 80, 96, 112), (112, 256, 384, 512), 3, (1, 1, 1, 1), True),
+    "V-19-dw-eSE": ((64, 64, 64), (128, 160, 192, 224), (256, 512, 768, 1024), 3, (1, 1, 1, 1), True),
+    "V-19-slim-eSE": ((64, 64, 128), (64, 80, 96, 112), (112, 256, 384, 512), 3, (1, 1, 1, 1), False),
+    "V-19-eSE": ((64, 64, 128), (128, 160, 192, 224), (256, 512, 768, 1024), 3, (1, 1, 1, 1), False),
+    "V-39-eSE": ((64, 64, 128), (128, 160, 192, 224), (256, 512, 768, 1024), 5, (1, 1, 2, 2), False),
+    "V-57-eSE": ((64, 64, 128), (128, 160, 192, 224), (256, 512, 768, 1024), 5, (1, 1, 4, 3), False),
+    "V-99-eSE": ((64, 64, 128), (128, 160, 192, 224), (256, 512, 768, 1024), 5, (1, 3, 9, 3), False),
+}
+
+
+def _cbr(cin, cout, name, k, stride=1):
+    """conv(k x k, no bias) -> BN -> ReLU with the reference's '<name>/conv|norm|relu' child names."""
+    return [(f"{name}/conv", nn.Conv2d(cin, cout, k, stride, k // 2, bias=False)),
+            (f"{name}/norm", nn.BatchNorm2d(cout)), (f"{name}/relu", nn.ReLU(inplace=True))]
+
+
+def _dw(cin, cout, name, stride=1):
+    return [(f"{name}/dw_conv3x3", nn.Conv2d(cin, cout, 3, stride, 1, groups=cout, bias=False)),
+            (f"{name}/pw_conv1x1", nn.Conv2d(cin, cout, 1, bias=False)),
+            (f"{name}/pw_norm", nn.BatchNorm2d(cout)), (f"{name}/pw_relu", nn.ReLU(inplace=True))]
+
+
+class eSEModule(nn.Module):
+    def __init__(self, channel):
+        super().__init__()
+        self.fc = nn.Conv2d(channel, channel, kernel_size=1)
+
+    def forward(self, x):
+        gate = F.relu6(self.fc(x.mean(dim=(2, 3), keepdim=True)) + 3.0) / 6.0
+        return x * gate
+
+
+class OSAModule(nn.Module):
+    def __init__(self, cin, width, cout, n_layers, name, identity=False, depthwise=False):
+        super().__init__()
+        self.identity = identity
+        self.reduce = None
+        c = cin
+        if depthwise and cin != width:
+            self.conv_reduction = nn.Sequential(OrderedDict(_cbr(cin, width, f"{name}_reduction_0", 1)))
+            self.reduce = self.conv_reduction
+        self.layers = nn.ModuleList()
+        for i in range(n_layers):
+            seq = _dw(width, width, f"{name}_{i}") if depthwise else _cbr(c, width, f"{name}_{i}", 3)
+            self.layers.append(nn.Sequential(OrderedDict(seq)))
+            c = width
+        self.concat = nn.Sequential(OrderedDict(_cbr(cin + n_layers * width, cout, f"{name}_concat", 1)))
+        self.ese = eSEModule(cout)
+
+    def forward(self, x):
+        feats = [x]
+        y = self.reduce(x) if self.reduce is not None else x
+        for layer in self.layers:
+            y = layer(y)
+            feats.append(y)
+        out = self.ese(self.concat(torch.cat(feats, dim=1)))
+        return out + x if self.identity else out
+
+
+def _stage(cin, width, cout, n_blocks, n_layers, idx, depthwise):
+    mods = OrderedDict()
+    if idx != 2:
+        mods["Pooling"] = nn.MaxPool2d(kernel_size=3, stride=2, ceil_mode=True)
+    mods[f"OSA{idx}_1"] = OSAModule(cin, width, cout, n_layers, f"OSA{idx}_1", depthwise=depthwise)
+    for i in range(n_blocks - 1):
+        name = f"OSA{idx}_{i + 2}"
+        mods[name] = OSAModule(cout, width, cout, n_layers, name, identity=True, depthwise=depthwise)
+    return nn.Sequential(mods)
+
+
+@BACKBONES.register_module()
+class VoVNet(BaseModule):
+    def __init__(self, spec_name, input_ch=3, out_features=None, frozen_stages=-1, norm_eval=True, pretrained=None,
+                 init_cfg=None):
+        super().__init__(init_cfg)
+        self.frozen_stages = frozen_stages
+        self.norm_eval = norm_eval
+        stem_w, widths, outs, n_layers, n_blocks, dw = SPECS[spec_name]
+        self._out_features = list(out_features)
+        two = _dw if dw else (lambda a, b, n, s=1: _cbr(a, b, n, 3, s))
+        self.stem = nn.Sequential(OrderedDict(_cbr(input_ch, stem_w[0], "stem_1", 3, 2) + two(stem_w[0], stem_w[1], "stem_2", 1)
+                                              + two(stem_w[1], stem_w[2], "stem_3", 2)))
+        ins = (stem_w[2],) + tuple(outs[:-1])
+        self.stage_names = []
+        for i in range(4):
+            name = f"stage{i + 2}"
+            self.stage_names.append(name)
+            self.add_module(name, _stage(ins[i], widths[i], outs[i], n_blocks[i], n_layers, i + 2, dw))
+
+    def forward(self, x):
+        out = OrderedDict()
+        x = self.stem(x)
+        if "stem" in self._out_features:
+            out["stem"] = x
+        for name in self.stage_names:
+            x = getattr(self, name)(x)
+            if name in self._out_features:
+                out[name] = x
+        return out
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            for m in [self.stem] + [getattr(self, f"stage{i + 1}") for i in range(1, self.frozen_stages + 1)]:
+                m.eval()
+                for p in m.parameters():
+                    p.requires_grad = False
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, _BatchNorm):
+                    m.eval()
+        return self

@@ -110,6 +110,7 @@ def install_stand_ins():
         multi_apply=_raiser("multi_apply"), build_sampler=_raiser("build_sampler"))
     mod("mmdet.core.utils", reduce_mean=_raiser("reduce_mean"))
     mod("mmdet.models")
+    mod("mmdet.models.builder", BACKBONES=_Registry())
     mod("mmdet.models.dense_heads")
     mod("mmdet.models.dense_heads.base_dense_head", BaseDenseHead=_BaseModule)
     mod("mmdet3d")
@@ -117,7 +118,7 @@ def install_stand_ins():
     mod("mmdet3d.models", HEADS=_Registry(), build_loss=_raiser("build_loss"), build_head=_raiser("build_head"),
         build_roi_extractor=_raiser("build_roi_extractor"))
     for pkg in ("mmdet3d_plugin", "mmdet3d_plugin.core", "mmdet3d_plugin.core.bbox", "mmdet3d_plugin.models",
-                "mmdet3d_plugin.models.sparse_heads"):
+                "mmdet3d_plugin.models.sparse_heads", "mmdet3d_plugin.models.backbones"):
         m = types.ModuleType(pkg)
         m.__path__ = []
         sys.modules[pkg] = m
@@ -133,6 +134,7 @@ def load_reference(ref):
 
     util = load("mmdet3d_plugin.core.bbox.util", "mmdet3d_plugin/core/bbox/util.py")
     head = load("mmdet3d_plugin.models.sparse_heads.srfdet_head", "mmdet3d_plugin/models/sparse_heads/srfdet_head.py")
+    head.vovnet = load("mmdet3d_plugin.models.backbones.vovnet", "mmdet3d_plugin/models/backbones/vovnet.py")
     return util, head
 
 
@@ -312,6 +314,52 @@ def main():
     path = os.path.join(HERE, "decoder_nusc.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, {k: v.shape for k, v in out.items()})
+
+    # ---- LiDAR + camera: VoVNet, image DPG, fusion head loop (srfdet_head.py:404-416, :442-458, :552-600) ----------
+    lc = {}
+    vov = head.vovnet.VoVNet("V-99-eSE", input_ch=3, out_features=["stage2", "stage3", "stage4", "stage5"])
+    vov.eval()  # the reference's train() override returns None
+    detgen.load_det_params(vov, "vov.")
+    with torch.no_grad():
+        vo = vov(t(detgen.det("vov.img", (1, 3, 32, 48))))
+    for k, v in vo.items():
+        lc["vov." + k] = v.numpy()
+
+    Pc, n_cam = 16, 6
+    hl = object.__new__(head.SRFDetHead)
+    nn.Module.__init__(hl)
+    hl.use_img, hl.with_lidar_encoder, hl.with_dpg, hl.deep_supervision, hl.is_kitti = True, False, True, True, False
+    hl.num_dpg_exp, hl.num_proposals, hl.feat_channels_lidar, hl.lidar_feat_lvls, hl.img_feat_lvls = 4, Pc, 128, 4, 4
+    hl.hidden_dim, hl.feat_channels_img = 128, 256
+    hl.grid_size, hl.out_size_factor, hl.pc_range = [1472, 1472, 40], 8, NUSC_RANGE
+    hl.code_weights = [1.0] * 8 + [0.2, 0.2]
+    hl._build_dynamic_prop_gen()
+    hl.img_convs = nn.ModuleList([nn.Conv2d(256, 128, 3, padding=1) for _ in range(4)])
+    hl.head_series_lidar = nn.ModuleList([head.SingleSRFDetHead(use_fusion=True, **STAGE_KW) for _ in range(5)])
+    hl.eval()
+    detgen.load_det_params(hl, "headlc.")
+    pfeats = [t(detgen.det(f"headlc.feat{i}", (1, 128, s, s), scale=0.5)) for i, s in enumerate((184, 92, 46, 23))]
+    # a 128 x 224 px "image" pyramid (strides 4..32) and a camera rig scaled to it
+    ifeats = [t(detgen.det(f"headlc.img{i}", (1, n_cam, 256, h, w), scale=0.5)) for i, (h, w) in
+              enumerate(((32, 56), (16, 28), (8, 14), (4, 7)))]
+    l2i = synthetic.camera_rig(f=177.0, cx=112.0, cy=64.0)
+    metas = [dict(lidar2img=[m for m in l2i])]
+    hl.roi_extractor_lidar = OraclePooler([8, 16, 32, 64])
+    hl.roi_extractor_img = OraclePooler([4, 8, 16, 32])
+    stage_in = []
+    for st_mod in hl.head_series_lidar:
+        st_mod.register_forward_pre_hook(lambda mod, a: stage_in.append(
+            (a[2].detach().clone().numpy(), a[3].detach().clone().numpy().reshape(1, Pc, 128))))
+    with torch.no_grad():
+        lg, bxs = hl([f.clone() for f in ifeats], pfeats, metas)
+    lc["headlc.logits"], lc["headlc.boxes"] = lg.numpy(), bxs.numpy()
+    lc["headlc.rois_lidar"] = np.stack(hl.roi_extractor_lidar.rois, 0)
+    lc["headlc.rois_img"] = np.stack(hl.roi_extractor_img.rois, 0)
+    lc["headlc.stage_in_boxes"] = np.stack([b for b, _ in stage_in], 0)
+    lc["headlc.stage_in_prop"] = np.stack([f for _, f in stage_in], 0)
+    path = os.path.join(HERE, "fusion_nusc.npz")
+    np.savez_compressed(path, **lc)
+    print("wrote", path, {k: v.shape for k, v in lc.items()})
 
 
 if __name__ == "__main__":

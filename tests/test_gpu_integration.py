@@ -86,3 +86,36 @@ def test_hip_graph_tail_equals_eager(setup, dev):
             b = g.simple_test(None, [p], metas)[0]["pts_bbox"]
         assert torch.equal(a["scores_3d"], b["scores_3d"]) and torch.equal(a["labels_3d"], b["labels_3d"])
         assert torch.equal(a["boxes_3d"].tensor, b["boxes_3d"].tensor)
+
+
+@pytest.mark.parametrize("name,sweep,npts,np_", [("srfdet_voxel_kitti_L", "kitti_sweep", 17000, 100),
+                                                 ("srfdet_dvoxel_waymo_L", "waymo_sweep", 60000, 64)])
+def test_dynamic_voxel_configs_against_oracle(name, sweep, npts, np_, dev):
+    """KITTI (config C1) and Waymo (C5) paths: dynamic voxelization -> DynamicVFECustom -> sparse encoder, HIP vs the CPU
+    oracle pipeline.  Voxel coordinates (sorted unique) must be bit-exact; voxel features go through a Linear+BN on
+    rocBLAS vs CPU BLAS, so they and everything downstream are compared with a float tolerance."""
+    import copy
+    torch.manual_seed(1)
+    cpu = workloads.build(name, np_).eval()
+    _randomize_bn(cpu, 1)
+    gpu = copy.deepcopy(cpu).to(dev)
+    seed = 1000 if "kitti" in name else 5000
+    pts = getattr(S, sweep)(seed, npts)
+    vf, vc = pipeline.voxel_features(cpu, [pts])
+    with torch.no_grad():
+        gp, gcoors = gpu.voxelize([torch.from_numpy(pts).to(dev)])
+        gvf, gvc = gpu.pts_voxel_encoder(gp, gcoors)
+        np.testing.assert_array_equal(gvc.cpu().numpy(), vc)
+        np.testing.assert_allclose(gvf.cpu().numpy(), vf, rtol=1e-4, atol=1e-5)
+        bev = gpu.pts_middle_encoder(gvf, gvc, 1)
+    # same voxel features on both sides -> the sparse encoder must agree exactly
+    bev_ref = pipeline.sparse_encoder(cpu.pts_middle_encoder, gvf.cpu().numpy(), vc, 1)
+    assert np.array_equal(bev.cpu().numpy(), bev_ref)
+    expect = (1, 256, 200, 176) if "kitti" in name else (1, 256, 192, 192)
+    assert tuple(bev.shape) == expect
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes)]
+    with torch.no_grad():
+        res = gpu.simple_test(None, [torch.from_numpy(pts).to(dev)], metas)
+    out = res[0]["pts_bbox"] if "pts_bbox" in res[0] else res[0]
+    assert set(out.keys()) == {"boxes_3d", "scores_3d", "labels_3d"}
+    assert out["boxes_3d"].tensor.shape[1] == (7 if "kitti" in name or "waymo" in name else 9)
