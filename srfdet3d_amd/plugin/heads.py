@@ -359,12 +359,15 @@ class SRFDetHead(BaseModule):
     # ---- proposals ------------------------------------------------------------------------------------------
     @staticmethod
     def _stair(convs, feats):
-        """depthwise stride-2 stair over the pyramid with channel concat (srfdet_head.py:525-536)."""
-        x = convs[0](feats[0])
-        for lvl in range(1, len(feats)):
-            x = torch.cat([feats[lvl], x], dim=1)
-            if lvl < len(convs):
-                x = convs[lvl](x)
+        """depthwise stride-2 stair over the pyramid with channel concat (srfdet_head.py:525-536).
+        MIOpen resolves these depthwise convs to its naive reference kernel (34 ms on the 6 x 128 x 232 x 400 image
+        level, measured); torch's own depthwise kernel takes 0.2 ms, so MIOpen is bypassed for the stair."""
+        with torch.backends.cudnn.flags(enabled=not feats[0].is_cuda):
+            x = convs[0](feats[0])
+            for lvl in range(1, len(feats)):
+                x = torch.cat([feats[lvl], x], dim=1)
+                if lvl < len(convs):
+                    x = convs[lvl](x)
         return x
 
     def _get_init_proposals(self, img_feats, point_feats):
