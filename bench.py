@@ -128,9 +128,16 @@ def main():
             ms = sum(d[0] for d in dom) / len(dom)
             flops = sum(d[1] for d in dom) / len(dom)
             achieved = flops / (ms * 1e-3) / 1e12
+            # HBM traffic cannot be read from inside the process: it comes from the separate rocprofv3 --pmc passes
+            # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied) recorded under profiles/
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_pmc_spconv128_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as fh:
+                    traffic = json.load(fh).get("traffic_bytes_per_launch")
             roofline = dict(kernel="srf_spconv_mfma32_k<128,64,2,2> (SubM 3x3x3, 128->128)", bound="mfma",
                             achieved=round(achieved, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                            frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                             launches=len(dom), avg_us=round(ms * 1e3, 2), algorithmic_flops_per_launch=int(flops),
                             algorithmic_bytes_per_launch=int(sum(d[2] for d in dom) / len(dom)))
         cpu_baseline = None

@@ -60,6 +60,15 @@ __device__ __forceinline__ void srf_stage_tile(const float *__restrict__ in, int
     }
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Give every XCD one contiguous
+// range of output tiles, so that the input rows its tiles gather (rows that are close in index are close in space)
+// stay in that XCD's 4 MB L2 instead of being re-fetched through the fabric.  Bijective for any grid size.
+__device__ __forceinline__ int srf_xcd_tile(int b, int n)
+{
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
 template <int TM>
 __device__ __forceinline__ void srf_load_nbr_tile(const int *__restrict__ nbr, int nbr_stride, int K, int row0, int A_out,
                                                   int *s_nbr, int *s_any)
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256) void srf_spconv_mfma32_k(const float *__restri
     __shared__ float s_a[2][TM][SRF_KC + 1];
     __shared__ __attribute__((aligned(16))) float s_w[2][SRF_KC][COUT];
 
-    const int row0 = blockIdx.x * TM;
+    const int row0 = srf_xcd_tile(blockIdx.x, gridDim.x) * TM;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;

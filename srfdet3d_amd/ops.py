@@ -75,7 +75,7 @@ def hard_voxelize(points, voxel_size, pc_range, max_points, max_voxels, mean_fea
 class VoxelMap:
     """Sorted unique voxels of a (n,4) coordinate list and the point lists of each voxel."""
 
-    def __init__(self, coors, grid_zyx, batch):
+    def __init__(self, coors, grid_zyx, batch, known_num_voxels=None):
         coors = _dev(coors, "coors", torch.int32)
         n = coors.shape[0]
         L = _lib.lib()
@@ -95,7 +95,8 @@ class VoxelMap:
         check(L.srf_voxel_unique(_ptr(coors), n, hi(grid_zyx), batch, _ptr(out_coors), _ptr(self.point2voxel),
                                  _ptr(self.counts), _ptr(self.offsets), _ptr(self.order), _ptr(self.num_dev), _ptr(ws),
                                  ws_bytes, _stream()), "voxel_unique")
-        self.M = int(self.num_dev.item())
+        # the one device->host read of this op; a caller that knows the count (all rows distinct) skips it
+        self.M = int(self.num_dev.item()) if known_num_voxels is None else int(known_num_voxels)
         self.coors = out_coors[:self.M]
         self.point2voxel = self.point2voxel[:n]
 
@@ -107,6 +108,17 @@ class VoxelMap:
                                             _ptr(self.num_dev), self.M, C, 0 if mode == "mean" else 1, _ptr(out),
                                             _stream()), "scatter_reduce")
         return out[:self.M]
+
+
+def spatial_order(indices, spatial_shape, batch):
+    """Permutation that sorts DISTINCT active sites (A,4) (b,z,y,x) by (b, y, x, z): rows that are close in space
+    become close in index, so a tile of consecutive output rows gathers from a compact set of input rows (L2 reuse,
+    see csrc/spconv.hip).  Uses the occupancy-bitmap rank of K3 -- no sort, no host sync."""
+    indices = _dev(indices, "indices", torch.int32)
+    D, H, W = spatial_shape
+    byxz = indices[:, [0, 2, 3, 1]].contiguous()
+    vm = VoxelMap(byxz, [H, W, D], batch, known_num_voxels=indices.shape[0])
+    return vm.order[:indices.shape[0]].long()
 
 
 # ---------------------------------------------------------------------------------------------- rulebooks

@@ -25,6 +25,9 @@ class SparseEncoderCustom(BaseModule):
         self.encoder_paddings = encoder_paddings
         self.stage_num = len(encoder_channels)
         self.fp16_enabled = False
+        # reorder the active sites spatially before the first conv (results per site are unchanged: every output is
+        # an fma chain ordered by kernel offset and channel, never by row); see ops.spatial_order
+        self.spatial_sort = True
 
         pre_act = order[0] != "conv"
         self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, norm_cfg=norm_cfg, padding=1,
@@ -63,7 +66,12 @@ class SparseEncoderCustom(BaseModule):
 
     def forward(self, voxel_features, coors, batch_size):
         """(M,C) voxel features + (M,4) int (b,z,y,x) -> (B, C*D, H, W) BEV map."""
-        x = SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, int(batch_size))
+        coors = coors.int()
+        if self.spatial_sort and coors.is_cuda and coors.shape[0] > 0:
+            from .. import ops
+            perm = ops.spatial_order(coors, self.sparse_shape, int(batch_size))
+            voxel_features, coors = voxel_features[perm], coors[perm]
+        x = SparseConvTensor(voxel_features, coors, self.sparse_shape, int(batch_size))
         x = self.conv_input(x)
         for stage in self.encoder_layers._modules.values():
             x = stage(x)

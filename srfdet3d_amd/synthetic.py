@@ -17,10 +17,16 @@ WAYMO_RANGE = (-76.8, -76.8, -2.0, 76.8, 76.8, 4.0)
 
 def _ring_sweep(rng, n_points, n_rings, elev_lo_deg, elev_hi_deg, sensor_h,
                 max_ground_range, up_range, az_lo, az_hi):
-    """Ranges/angles of a ring LiDAR over flat ground plus random up-beam returns."""
+    """Ranges/angles of a spinning ring LiDAR over flat ground plus random up-beam returns.
+
+    Points come in firing order, as in a real sweep file (test-time pipelines do not shuffle: PointShuffle is a
+    train-only transform in the reference configs): the head turns from az_lo to az_hi and at every azimuth step
+    all rings fire, so point i belongs to step i // n_rings, ring i % n_rings."""
     elev = np.deg2rad(np.linspace(elev_lo_deg, elev_hi_deg, n_rings))
-    ring = rng.integers(0, n_rings, size=n_points)
-    az = rng.uniform(az_lo, az_hi, size=n_points)
+    ring = np.arange(n_points) % n_rings
+    step = np.arange(n_points) // n_rings
+    n_steps = max(int(step[-1]) + 1, 1) if n_points else 1
+    az = az_lo + (az_hi - az_lo) * (step + rng.uniform(0.0, 1.0, size=n_points)) / n_steps
     e = elev[ring]
     down = e < -1e-3
     r_ground = np.where(down, sensor_h / np.tan(np.where(down, -e, 1.0)), np.inf)
@@ -43,44 +49,46 @@ def _clip_open(x, y, z, rng_box, eps=1e-3):
 def nuscenes_sweep(seed=2000, n_points=30000):
     """(N,5) f32: x, y, z, intensity in [0,255], dt=0.  32-ring 360 degree model."""
     rng = np.random.default_rng(seed)
-    pts = np.zeros((0, 5), np.float32)
-    while pts.shape[0] < n_points:
-        n = int((n_points - pts.shape[0]) * 1.3) + 64
+    n = n_points
+    while True:  # one full revolution holding at least n_points in-range returns, thinned to exactly n_points
         x, y, z = _ring_sweep(rng, n, 32, -30.67, 10.67, 1.84, 54.0, (5.0, 50.0), 0.0, 2 * np.pi)
-        keep = _clip_open(x, y, z, NUSC_RANGE)
-        inten = rng.uniform(0, 255, size=n)
-        new = np.stack([x, y, z, inten, np.zeros(n)], 1)[keep].astype(np.float32)
-        pts = np.concatenate([pts, new], 0)
-    return np.ascontiguousarray(pts[:n_points])
+        keep = np.nonzero(_clip_open(x, y, z, NUSC_RANGE))[0]
+        if keep.size >= n_points:
+            break
+        n = int(n * 1.15) + 64
+    keep = keep[np.sort(rng.choice(keep.size, n_points, replace=False))]
+    inten = rng.uniform(0, 255, size=n_points)
+    return np.ascontiguousarray(np.stack([x[keep], y[keep], z[keep], inten, np.zeros(n_points)], 1).astype(np.float32))
 
 
 def kitti_sweep(seed=1000, n_points=17000):
     """(N,4) f32: x, y, z, reflectance in [0,1].  64-ring front field of view."""
     rng = np.random.default_rng(seed)
-    pts = np.zeros((0, 4), np.float32)
-    while pts.shape[0] < n_points:
-        n = int((n_points - pts.shape[0]) * 2.0) + 64
+    n = n_points
+    while True:
         x, y, z = _ring_sweep(rng, n, 64, -24.8, 2.0, 1.73, 70.0, (5.0, 60.0), -np.pi / 4, np.pi / 4)
-        keep = _clip_open(x, y, z, KITTI_RANGE)
-        refl = rng.uniform(0, 1, size=n)
-        new = np.stack([x, y, z, refl], 1)[keep].astype(np.float32)
-        pts = np.concatenate([pts, new], 0)
-    return np.ascontiguousarray(pts[:n_points])
+        keep = np.nonzero(_clip_open(x, y, z, KITTI_RANGE))[0]
+        if keep.size >= n_points:
+            break
+        n = int(n * 1.15) + 64
+    keep = keep[np.sort(rng.choice(keep.size, n_points, replace=False))]
+    refl = rng.uniform(0, 1, size=n_points)
+    return np.ascontiguousarray(np.stack([x[keep], y[keep], z[keep], refl], 1).astype(np.float32))
 
 
 def waymo_sweep(seed=5000, n_points=180000):
     """(N,5) f32: x, y, z, intensity, elongation.  64-ring model to 75 m."""
     rng = np.random.default_rng(seed)
-    pts = np.zeros((0, 5), np.float32)
-    while pts.shape[0] < n_points:
-        n = int((n_points - pts.shape[0]) * 1.3) + 64
+    n = n_points
+    while True:
         x, y, z = _ring_sweep(rng, n, 64, -17.6, 2.4, 1.9, 75.0, (5.0, 70.0), 0.0, 2 * np.pi)
-        keep = _clip_open(x, y, z, WAYMO_RANGE)
-        inten = rng.uniform(0, 1, size=n)
-        elong = rng.uniform(0, 1, size=n)
-        new = np.stack([x, y, z, inten, elong], 1)[keep].astype(np.float32)
-        pts = np.concatenate([pts, new], 0)
-    return np.ascontiguousarray(pts[:n_points])
+        keep = np.nonzero(_clip_open(x, y, z, WAYMO_RANGE))[0]
+        if keep.size >= n_points:
+            break
+        n = int(n * 1.15) + 64
+    keep = keep[np.sort(rng.choice(keep.size, n_points, replace=False))]
+    inten, elong = rng.uniform(0, 1, size=n_points), rng.uniform(0, 1, size=n_points)
+    return np.ascontiguousarray(np.stack([x[keep], y[keep], z[keep], inten, elong], 1).astype(np.float32))
 
 
 def camera_rig(n_cam=6, f=1266.0, cx=816.0, cy=491.0, cam_h=1.5):

@@ -84,8 +84,11 @@ def test_hip_graph_tail_equals_eager(setup, dev):
         with torch.no_grad():
             a = gpu.simple_test(None, [p], metas)[0]["pts_bbox"]
             b = g.simple_test(None, [p], metas)[0]["pts_bbox"]
-        assert torch.equal(a["scores_3d"], b["scores_3d"]) and torch.equal(a["labels_3d"], b["labels_3d"])
-        assert torch.equal(a["boxes_3d"].tensor, b["boxes_3d"].tensor)
+        # same kernels, same order; MIOpen may pick a different conv solver between the eager and the captured run,
+        # so equality is asserted to float tolerance rather than bitwise
+        assert torch.equal(a["labels_3d"], b["labels_3d"])
+        torch.testing.assert_close(a["scores_3d"], b["scores_3d"], rtol=0, atol=1e-5)
+        torch.testing.assert_close(a["boxes_3d"].tensor, b["boxes_3d"].tensor, rtol=0, atol=1e-4)
 
 
 @pytest.mark.parametrize("name,sweep,npts,np_", [("srfdet_voxel_kitti_L", "kitti_sweep", 17000, 100),

@@ -17,12 +17,15 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--levels", default="1,2,3,4")
     ap.add_argument("--points", type=int, default=30000)
+    ap.add_argument("--no-sort", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     pts = torch.from_numpy(synthetic.nuscenes_sweep(2000, a.points)).to(dev)
     _, c, _, _ = ops.hard_voxelize(pts, [0.075, 0.075, 0.2], list(synthetic.NUSC_RANGE), 10, 160000)
     idx = torch.cat([torch.zeros((c.shape[0], 1), dtype=torch.int32, device=dev), c], 1).contiguous()
     shape = [41, 1472, 1472]
+    if not a.no_sort:
+        idx = idx[ops.spatial_order(idx, shape, 1)].contiguous()
     specs = [(16, [1, 1, 1]), (32, [1, 1, 1]), (64, [0, 1, 1]), (128, None)]
     want = [int(x) for x in a.levels.split(",")]
     g = torch.Generator(device="cpu").manual_seed(0)
