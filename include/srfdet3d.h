@@ -125,6 +125,15 @@ int srf_spconv_fwd(const float *in, int A_in, int Cin, const float *W, int K, co
                    int A_out, int Cout, const float *alpha, const float *beta, const float *residual, int relu,
                    float *out, srf_stream_t stream);
 
+/* Fast path of K5 for constant weights: re-lay W once (srf_spconv_pack_weights -> packed, of
+ * srf_spconv_packed_weight_bytes bytes) into the LDS operand image of the kernel, then call srf_spconv_fwd_packed with
+ * the same remaining arguments.  Results are bit-identical to srf_spconv_fwd.  Cout in {32, 64, 128}, Cin % 4 == 0. */
+size_t srf_spconv_packed_weight_bytes(int K, int Cin, int Cout);
+int srf_spconv_pack_weights(const float *W, int K, int Cin, int Cout, float *packed, srf_stream_t stream);
+int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const float *W_packed, int K, const int *nbr,
+                          int nbr_stride, int A_out, int Cout, const float *alpha, const float *beta,
+                          const float *residual, int relu, float *out, srf_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * K6  SparseConvTensor.dense() (+ the view to (B, C*D, H, W), which is a no-op on this layout).
  * Replaces sparse_encoder_custom.py:135-138.  out: (B, C, D, H, W) contiguous; zero_fill != 0 clears it first.

@@ -260,6 +260,250 @@ __global__ __launch_bounds__(256) void srf_spconv_mfma32_k(const float *__restri
     }
 }
 
+// =====================================================================================================================
+// Packed-weight kernel (the fast path; weights are constants at inference, so they are re-laid-out once per layer).
+//
+// Operand images in LDS are built so that a lane fetches its 16 k-values of a 32-channel chunk with four ds_read_b128:
+//   row of the image = one gathered input row (A) or one output column (B), 32 floats = 8 slots of 16 B;
+//   logical slot s = 4*h + g holds channels c0 + 2*(4g + i) + h, i = 0..3  (h = parity of the channel: the f32 32x32x2
+//   MFMA takes channel 2j from lanes 0-31 and 2j+1 from lanes 32-63);
+//   physical slot = s ^ ((row >> 1) & 7): with 128-B rows this XOR swizzle puts the 16 lanes of every ds_read_b128
+//   lane group on 16 different (half, slot) pairs, i.e. conflict-free without padding (48 KB per workgroup -> three
+//   workgroups per CU).
+// srf_spconv_pack_weights writes W in exactly that image, per (offset k, chunk), so the slab copy global -> LDS is
+// linear.  The accumulation order per output element is unchanged (k ascending, channel ascending): results stay
+// bit-identical to srf_spconv_fwd and to the oracle.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void srf_pack_weights_k(const float *__restrict__ W, int K, int Cin, int Cout, int nchunk,
+                                                        float *__restrict__ P)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)K * nchunk * Cout * 32;
+    if (t >= total) return;
+    const int e = (int)(t & 31);
+    long long rest = t >> 5;
+    const int col = (int)(rest % Cout);
+    rest /= Cout;
+    const int chunk = (int)(rest % nchunk), k = (int)(rest / nchunk);
+    const int phys = e >> 2, i = e & 3;
+    const int sl = phys ^ ((col >> 1) & 7);
+    const int c = chunk * 32 + 2 * ((sl & 3) * 4 + i) + (sl >> 2);
+    P[t] = c < Cin ? W[((size_t)k * Cin + c) * Cout + col] : 0.0f;
+}
+
+extern "C" size_t srf_spconv_packed_weight_bytes(int K, int Cin, int Cout)
+{
+    if (K <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)K * ((Cin + 31) / 32) * Cout * 32 * sizeof(float);
+}
+
+extern "C" int srf_spconv_pack_weights(const float *W, int K, int Cin, int Cout, float *packed, srf_stream_t stream)
+{
+    if (!W || !packed || K <= 0 || K > SRF_KMAX || Cin <= 0 || Cout <= 0) return SRF_EINVAL;
+    const int nchunk = (Cin + 31) / 32;
+    const long long total = (long long)K * nchunk * Cout * 32;
+    hipLaunchKernelGGL(srf_pack_weights_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, W, K, Cin, Cout,
+                       nchunk, packed);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+template <int COUT, int TM, int NA, int NW>
+__device__ __forceinline__ void srf_pk_load(const float *__restrict__ in, int Cin, const float *__restrict__ slab,
+                                            const int *nbr_k, int rows_left, int c0, f32x4 (&ra)[NA], f32x4 (&rw)[NW],
+                                            unsigned &okmask)
+{
+    const int tid = threadIdx.x;
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int e = tid + j * 256;
+        const int r = e >> 3, q = e & 7;
+        const int i = r < rows_left ? nbr_k[r] : -1;
+        const int c = c0 + q * 4;
+        const bool ok = (i >= 0) & (c < Cin);
+        const int ii = i >= 0 ? i : 0;
+        const int cc = c < Cin ? c : Cin - 4;
+        ra[j] = *reinterpret_cast<const f32x4 *>(in + (size_t)ii * Cin + cc);
+        m |= (ok ? 1u : 0u) << j;
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) rw[j] = *reinterpret_cast<const f32x4 *>(slab + (size_t)(tid + j * 256) * 4);
+    okmask = m;
+}
+
+template <int COUT, int TM, int NA, int NW>
+__device__ __forceinline__ void srf_pk_store(float *s_a, float *s_w, const f32x4 (&ra)[NA], const f32x4 (&rw)[NW],
+                                             unsigned okmask)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int e = tid + j * 256;
+        const int r = e >> 3, q = e & 7;
+        const f32x4 v = ((okmask >> j) & 1u) ? ra[j] : zero;
+        const int swz = (r >> 1) & 7;
+        const int off = 2 * (q & 1);
+        const f32x2 ev = {v[0], v[2]}, od = {v[1], v[3]};
+        *reinterpret_cast<f32x2 *>(s_a + r * 32 + (((q >> 1)) ^ swz) * 4 + off) = ev;
+        *reinterpret_cast<f32x2 *>(s_a + r * 32 + ((4 + (q >> 1)) ^ swz) * 4 + off) = od;
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) *reinterpret_cast<f32x4 *>(s_w + (size_t)(tid + j * 256) * 4) = rw[j];
+}
+
+template <int COUT, int TM, int WR, int WC>
+__global__ __launch_bounds__(256) void srf_spconv_packed_k(const float *__restrict__ in, int Cin,
+                                                         const float *__restrict__ Wp, int K,
+                                                         const int *__restrict__ nbr, int nbr_stride, int A_out,
+                                                         const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                         const float *__restrict__ residual, int relu,
+                                                         float *__restrict__ out)
+{
+    static_assert(WR * WC == 4 && TM == WR * 32, "one 32-row tile per wave row");
+    constexpr int CT = COUT / WC / 32;
+    constexpr int NA = TM * 8 / 256;
+    constexpr int NW = COUT * 8 / 256;
+    constexpr bool NBR_LDS = COUT < 128;
+    __shared__ int s_nbr[NBR_LDS ? SRF_KMAX * TM : 1];
+    __shared__ int s_any[SRF_KMAX];
+    __shared__ int s_klist[SRF_KMAX + 1];
+    __shared__ __attribute__((aligned(16))) float s_a[2][TM * 32];
+    __shared__ __attribute__((aligned(16))) float s_w[2][COUT * 32];
+
+    const int row0 = srf_xcd_tile(blockIdx.x, gridDim.x) * TM;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const int rows_left = A_out - row0;
+    if (tid < SRF_KMAX) s_any[tid] = 0;
+    __syncthreads();
+    for (int t = tid; t < K * TM; t += 256) {
+        const int k = t / TM, r = t % TM;
+        const int v = r < rows_left ? nbr[(size_t)k * nbr_stride + row0 + r] : -1;
+        if (NBR_LDS) s_nbr[t] = v;
+        if (v >= 0) s_any[k] = 1;  // benign race: every writer stores 1
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int k = 0; k < K; ++k)
+            if (s_any[k]) s_klist[n++] = k;
+        s_klist[SRF_KMAX] = n;
+    }
+    __syncthreads();
+    const int nchunk = (Cin + SRF_KC - 1) / SRF_KC;
+    const int T = s_klist[SRF_KMAX] * nchunk;
+    const size_t slab_floats = (size_t)COUT * 32;
+
+    f32x16 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[ct][j] = 0.0f;
+
+    f32x4 ra[NA], rw[NW];
+    unsigned okmask = 0;
+    const int kh = lane >> 5;
+    const int arow = wr * 32 + (lane & 31);
+    const int a_swz = (arow >> 1) & 7;
+    if (T > 0) {
+        const int k0 = s_klist[0];
+        srf_pk_load<COUT, TM, NA, NW>(in, Cin, Wp + (size_t)k0 * nchunk * slab_floats,
+                                      NBR_LDS ? s_nbr + k0 * TM : nbr + (size_t)k0 * nbr_stride + row0,
+                                      NBR_LDS ? TM : rows_left, 0, ra, rw, okmask);
+        srf_pk_store<COUT, TM, NA, NW>(s_a[0], s_w[0], ra, rw, okmask);
+    }
+    __syncthreads();
+    int tk = 0, tc = 0;
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        if (++tc == nchunk) {
+            tc = 0;
+            ++tk;
+        }
+        const bool more = t + 1 < T;
+        if (more) {
+            const int kn = s_klist[tk];
+            srf_pk_load<COUT, TM, NA, NW>(in, Cin, Wp + ((size_t)kn * nchunk + tc) * slab_floats,
+                                          NBR_LDS ? s_nbr + kn * TM : nbr + (size_t)kn * nbr_stride + row0,
+                                          NBR_LDS ? TM : rows_left, tc * SRF_KC, ra, rw, okmask);
+        }
+        // operand fragments of this step: 4 + 4*CT ds_read_b128, then the MFMAs run without further LDS waits
+        f32x4 af[4], bf[CT][4];
+        const float *pa = s_a[buf] + arow * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) af[g] = *reinterpret_cast<const f32x4 *>(pa + (((kh << 2) + g) ^ a_swz) * 4);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int col = (wc * CT + ct) * 32 + (lane & 31);
+            const float *pb = s_w[buf] + col * 32;
+            const int b_swz = (col >> 1) & 7;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bf[ct][g] = *reinterpret_cast<const f32x4 *>(pb + (((kh << 2) + g) ^ b_swz) * 4);
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j >> 2][j & 3], bf[ct][j >> 2][j & 3], acc[ct], 0, 0, 0);
+        if (more) srf_pk_store<COUT, TM, NA, NW>(s_a[buf ^ 1], s_w[buf ^ 1], ra, rw, okmask);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = (wc * CT + ct) * 32 + (lane & 31);
+        const float al = alpha ? alpha[col] : 1.0f;
+        const float be = alpha ? beta[col] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = row0 + wr * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+            if (row < A_out) {
+                float v = acc[ct][j];
+                if (alpha) v = __fmaf_rn(v, al, be);
+                if (residual) v = __fadd_rn(v, residual[(size_t)row * COUT + col]);
+                if (relu) v = v > 0.0f ? v : 0.0f;
+                out[(size_t)row * COUT + col] = v;
+            }
+        }
+    }
+}
+
+extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const float *W_packed, int K, const int *nbr,
+                                     int nbr_stride, int A_out, int Cout, const float *alpha, const float *beta,
+                                     const float *residual, int relu, float *out, srf_stream_t stream)
+{
+    if (A_in < 0 || A_out < 0 || Cin <= 0 || Cin > 512 || K <= 0 || K > SRF_KMAX || nbr_stride < A_out) return SRF_EINVAL;
+    if ((alpha == nullptr) != (beta == nullptr)) return SRF_EINVAL;
+    if (A_out == 0) return SRF_OK;
+    if (!in || !W_packed || !nbr || !out) return SRF_EINVAL;
+    if ((Cin & 3) || A_in == 0) return SRF_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+#define SRF_ARGS in, Cin, W_packed, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out
+    switch (Cout) {
+    case 32:
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_packed_k<32, 128, 4, 1>), dim3(srf_ceil_div(A_out, 128)), dim3(256),
+                           0, st, SRF_ARGS);
+        break;
+    case 64:
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_packed_k<64, 64, 2, 2>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0,
+                           st, SRF_ARGS);
+        break;
+    case 128:
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_packed_k<128, 64, 2, 2>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0,
+                           st, SRF_ARGS);
+        break;
+    default:
+        return SRF_EUNSUPPORTED;
+    }
+#undef SRF_ARGS
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
 // COUT = 16: four waves, each 16 rows x 16 cols on v_mfma_f32_16x16x4_f32
 template <int TM>
 __global__ __launch_bounds__(256) void srf_spconv_mfma16_k(const float *__restrict__ in, int Cin,

@@ -184,8 +184,19 @@ def rulebook_strided(indices, spatial_shape, batch, ksize, stride, pad):
 KERNEL_TIMING = None
 
 
-def spconv_fwd(feats, weight, nbr, alpha=None, beta=None, residual=None, relu=False, pair_counts=None):
-    """feats (A_in,Cin); weight (K,Cin,Cout); nbr (K,A_out) (row stride nbr.stride(0)) -> (A_out,Cout)."""
+def pack_spconv_weights(weight):
+    """(K,Cin,Cout) -> the LDS operand image srf_spconv_fwd_packed streams (once per layer; weights are constants)."""
+    weight = _dev(weight, "weight", torch.float32)
+    K, Cin, Cout = weight.shape
+    L = _lib.lib()
+    packed = _empty((L.srf_spconv_packed_weight_bytes(K, Cin, Cout) // 4,), torch.float32, weight.device)
+    check(L.srf_spconv_pack_weights(_ptr(weight), K, Cin, Cout, _ptr(packed), _stream()), "spconv_pack_weights")
+    return packed
+
+
+def spconv_fwd(feats, weight, nbr, alpha=None, beta=None, residual=None, relu=False, pair_counts=None, packed=None):
+    """feats (A_in,Cin); weight (K,Cin,Cout); nbr (K,A_out) (row stride nbr.stride(0)) -> (A_out,Cout).
+    `packed` = pack_spconv_weights(weight) selects the packed-weight kernel (Cout >= 32, Cin % 4 == 0)."""
     feats = _dev(feats, "feats", torch.float32)
     weight = _dev(weight, "weight", torch.float32)
     if not nbr.is_cuda or nbr.dtype != torch.int32 or nbr.stride(1) != 1:
@@ -199,10 +210,15 @@ def spconv_fwd(feats, weight, nbr, alpha=None, beta=None, residual=None, relu=Fa
     if timing is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(_lib.lib().srf_spconv_fwd(_ptr(feats), feats.shape[0], Cin, _ptr(weight), K, _ptr(nbr),
-                                    nbr.stride(0) if A_out > 0 else 0, A_out, Cout,
-                                    _ptr(alpha), _ptr(beta), _ptr(residual), int(bool(relu)), _ptr(out), _stream()),
-          "spconv_fwd")
+    if packed is not None and Cout >= 32 and Cin % 4 == 0 and feats.shape[0] > 0:
+        check(_lib.lib().srf_spconv_fwd_packed(_ptr(feats), feats.shape[0], Cin, _ptr(packed), K, _ptr(nbr),
+                                               nbr.stride(0) if A_out > 0 else 0, A_out, Cout, _ptr(alpha), _ptr(beta),
+                                               _ptr(residual), int(bool(relu)), _ptr(out), _stream()), "spconv_fwd_packed")
+    else:
+        check(_lib.lib().srf_spconv_fwd(_ptr(feats), feats.shape[0], Cin, _ptr(weight), K, _ptr(nbr),
+                                        nbr.stride(0) if A_out > 0 else 0, A_out, Cout,
+                                        _ptr(alpha), _ptr(beta), _ptr(residual), int(bool(relu)), _ptr(out), _stream()),
+              "spconv_fwd")
     if timing is not None:
         ev1.record()
         timing["spconv"].append(_SpconvRecord(ev0, ev1, Cin, Cout, K, feats.shape[0], A_out, pair_counts))

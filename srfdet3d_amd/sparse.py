@@ -140,7 +140,16 @@ class _SparseConv(SparseModule):
                 beta = beta + self.bias * alpha
         elif self.bias is not None:
             alpha, beta = torch.ones_like(self.bias), self.bias
-        feats = ops.spconv_fwd(x.features, w, nbr, alpha, beta, residual, relu, pair_counts=counts)
+        packed = None
+        if not self.training and self.out_channels >= 32 and self.in_channels % 4 == 0:
+            vers = (self.weight._version, self.weight.data_ptr())
+            cache = getattr(self, "_srf_packed", None)
+            if cache is None or cache[0] != vers:
+                with torch.no_grad():
+                    cache = (vers, ops.pack_spconv_weights(w.detach()))
+                self._srf_packed = cache
+            packed = cache[1]
+        feats = ops.spconv_fwd(x.features, w, nbr, alpha, beta, residual, relu, pair_counts=counts, packed=packed)
         return SparseConvTensor(feats, out_idx, oshape, x.batch_size, x.indice_dict)
 
 

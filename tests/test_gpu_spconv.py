@@ -104,6 +104,10 @@ def test_spconv_fwd_exact(dev, cin, cout, K):
                              tt(res) if use_res else None, relu).cpu().numpy()
         # exact: both sides are the same f32 fma chain (k ascending, c ascending); == treats +0/-0 alike
         assert np.array_equal(got, ref), f"max abs diff {np.abs(got - ref).max()}"
+        if cout >= 32 and cin % 4 == 0:  # packed-weight kernel: same chain, different operand staging
+            got = ops.spconv_fwd(tt(feats), tt(W), tt(nbr), tt(alpha) if use_bn else None, tt(beta) if use_bn else None,
+                                 tt(res) if use_res else None, relu, packed=ops.pack_spconv_weights(tt(W))).cpu().numpy()
+            assert np.array_equal(got, ref), f"packed: max abs diff {np.abs(got - ref).max()}"
 
 
 def test_spconv_vs_dense_torch_conv3d(dev):

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--levels", default="1,2,3,4")
     ap.add_argument("--points", type=int, default=30000)
     ap.add_argument("--no-sort", action="store_true")
+    ap.add_argument("--unpacked", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     pts = torch.from_numpy(synthetic.nuscenes_sweep(2000, a.points)).to(dev)
@@ -37,13 +38,14 @@ def main():
             f = torch.randn(A, C, generator=g).to(dev)
             W = (torch.randn(27, C, C, generator=g) * 0.05).to(dev)
             al, be = torch.rand(C, generator=g).to(dev) + 0.5, torch.randn(C, generator=g).to(dev)
+            pk = ops.pack_spconv_weights(W) if (C >= 32 and not a.unpacked) else None
             for _ in range(3):
-                ops.spconv_fwd(f, W, nbr, al, be, f, True)
+                ops.spconv_fwd(f, W, nbr, al, be, f, True, packed=pk)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             e0.record()
             for _ in range(a.reps):
-                ops.spconv_fwd(f, W, nbr, al, be, f, True)
+                ops.spconv_fwd(f, W, nbr, al, be, f, True, packed=pk)
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / a.reps
