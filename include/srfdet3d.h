@@ -175,6 +175,33 @@ int srf_box_rois(float *boxes, int B, int P, int box_dim, const float *pc_range 
                  int n_cam, float *rois_img, srf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * a14-a17  dense arithmetic of a decoder stage (SingleSRFDetHeadLiDAR.forward / SingleSRFDetHead.forward,
+ * srfdet_head.py:1484-1525 == :2281-2322; DynamicConv :2633-2693; fused projection :2255-2264).
+ *
+ * srf_linear: Y (M x N, row stride ldy) = chain(X (M x K, ldx) . W^T (W is N x K, ldw) + bias) where chain is
+ *   [LayerNorm(ln1, eps1)] -> [ReLU if relu1] -> [+ residual (M x N, ldr)] -> [LayerNorm(ln2, eps2)] -> [ReLU if relu2];
+ *   null pointers skip a step.  Replaces nn.Linear + nn.LayerNorm + ReLU (+ the residual adds) call chains, e.g.
+ *   out_layer -> norm3 -> ReLU -> (+prop) -> norm2 (srfdet_head.py:2689-2691, :1502-1503).  K % 4 == 0; K >= 2048 is
+ *   split over K and needs the workspace (srf_linear_workspace_bytes); LayerNorm steps need N <= 1024.
+ * srf_self_attention: qkv (P x 3E) = [q | k | v] rows after in_proj -> out (P x E), heads H, head dim E/H <= 32;
+ *   replaces the attention core of nn.MultiheadAttention(batch 1) at srfdet_head.py:1489.
+ * srf_dynconv_mid: feats (R x S x C) bin-major RoI features, params (R x 2*C*D) from dynamic_layer ->
+ *   relu(LN_C(relu(LN_D(feats W1)) W2)) (R x S x C); srfdet_head.py:2671-2686.  (C, D) in {(128,32), (256,64)}, S <= 64.
+ * srf_apply_deltas: srfdet_head.py:1534-1625; weights6 / pc_range are host arrays.
+ * ------------------------------------------------------------------------------------------------------- */
+size_t srf_linear_workspace_bytes(int M, int N, int K);
+int srf_linear(const float *X, int M, int K, int ldx, const float *W, int N, int ldw, const float *bias,
+               const float *ln1_g, const float *ln1_b, float eps1, int relu1, const float *residual, int ldr,
+               const float *ln2_g, const float *ln2_b, float eps2, int relu2, float *Y, int ldy, void *workspace,
+               size_t workspace_bytes, srf_stream_t stream);
+int srf_self_attention(const float *qkv, int P, int E, int H, float *out, srf_stream_t stream);
+int srf_dynconv_mid(const float *feats, const float *params, int R, int S, int C, int D, const float *g1,
+                    const float *b1, float eps1, const float *g2, const float *b2, float eps2, float *out,
+                    srf_stream_t stream);
+int srf_apply_deltas(const float *deltas, const float *boxes, int R, int Dd, const float *weights6 /*host[6]*/,
+                     const float *pc_range /*host[6]*/, float scale_clamp, float *out, srf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * K8  rotated BEV NMS.
  * Replaces mmcv nms_rotated behind mmdet3d box3d_multiclass_nms, called at srfdet_head.py:1288-1293.
  * boxes: (n,5) [cx, cy, w, h, angle(rad)] already sorted by descending score; keep[i] = 1 if box i survives

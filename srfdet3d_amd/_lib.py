@@ -51,6 +51,12 @@ SIGNATURES = {
     "srf_densify": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "srf_roi_extract": (c_int, [POINTER(FeatMap), c_int, c_int, _P, c_int, c_int, c_int, c_float, _P, c_int64,
                                 c_int64, c_int64, c_int, _P, _P]),
+    "srf_linear_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "srf_linear": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, c_float, c_int, _P, c_int, _P, _P, c_float,
+                           c_int, _P, c_int, _P, c_size_t, _P]),
+    "srf_self_attention": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "srf_dynconv_mid": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, c_float, _P, _P]),
+    "srf_apply_deltas": (c_int, [_P, _P, c_int, c_int, _HF, _HF, c_float, _P, _P]),
     "srf_nms_rotated_workspace_bytes": (c_size_t, [c_int]),
     "srf_nms_rotated": (c_int, [_P, c_int, c_float, _P, _P, c_size_t, _P]),
     "srf_box_rois": (c_int, [_P, c_int, c_int, c_int, _HF, _HF, c_int, _P, _P, c_int, _P, _P]),

@@ -1,0 +1,572 @@
+// decoder.hip -- the dense arithmetic of one decoder stage on the f32 MFMA pipe (gfx950).
+//
+// Reference: SingleSRFDetHeadLiDAR.forward / SingleSRFDetHead.forward, mmdet3d_plugin/models/sparse_heads/
+// srfdet_head.py:1484-1525 (== :2281-2322): nn.MultiheadAttention self-attention over the proposals (+ residual +
+// LayerNorm), DynamicConv (:2633-2693), FFN, classification / regression towers, and the fused projection of the
+// LiDAR+camera RoI features (:2255-2264).  In the reference each of these is a chain of torch ops (~60 launches per
+// stage); here a stage is ~20 launches of three kernels:
+//
+//   srf_linear        Y = epilogue(X W^T + b): 32x128 output tile per workgroup, 32-deep K chunks staged through the
+//                     same swizzled LDS operand images as the sparse conv (ds_read_b128 fragments, register-prefetched
+//                     double buffer), v_mfma_f32_32x32x2_f32.  When a workgroup owns whole rows (N <= 128) the
+//                     epilogue LayerNorm -> ReLU -> (+residual) -> LayerNorm -> ReLU chain runs in the same launch;
+//                     long-K products (out_layer, K = 6272) are split over K into partial slabs reduced by
+//                     srf_rows_epilogue, which applies the same chain.
+//   srf_self_attention  softmax(Q K^T / sqrt(d)) V per head, one workgroup per (head, 32 queries), online softmax in
+//                     registers; np <= a few thousand keys stream through LDS.
+//   srf_dynconv_mid   per proposal: (49 x C)(C x d) -> LN -> ReLU -> (49 x d)(d x C) -> LN -> ReLU with the
+//                     proposal's own weights, all operands resident in LDS, v_mfma_f32_16x16x4_f32.
+//
+// All arithmetic is f32 (the reference is f32 and the contract is 1e-4 on box parameters; gfx950 has no xf32).
+#include "common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct RowEpilogue {
+    const float *bias;      // [N] or null
+    const float *ln1_g;     // [N] or null -> first LayerNorm
+    const float *ln1_b;
+    const float *residual;  // [M, ldr] or null, added after ln1/relu1
+    const float *ln2_g;     // second LayerNorm (after the residual) or null
+    const float *ln2_b;
+    int ldr;
+    int relu1, relu2;
+    float eps1, eps2;
+};
+
+// LayerNorm over one row spread across a wave: NV values per lane (columns lane, lane+64, ...); biased variance,
+// two-pass, like torch.nn.LayerNorm
+template <int NV>
+__device__ __forceinline__ void srf_wave_layernorm(float (&v)[NV], int N, int lane, const float *g, const float *b, float eps)
+{
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + i * 64 < N) s += v[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    const float mean = s / (float)N;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + i * 64 < N) {
+            const float t = v[i] - mean;
+            q += t * t;
+        }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) q += __shfl_xor(q, d, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)N + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < N) v[i] = (v[i] - mean) * rstd * g[c] + b[c];
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void srf_row_epilogue(float (&v)[NV], int N, int lane, int row, const RowEpilogue &ep)
+{
+    if (ep.bias)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + i * 64 < N) v[i] += ep.bias[lane + i * 64];
+    if (ep.ln1_g) srf_wave_layernorm<NV>(v, N, lane, ep.ln1_g, ep.ln1_b, ep.eps1);
+    if (ep.relu1)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+    if (ep.residual)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + i * 64 < N) v[i] += ep.residual[(size_t)row * ep.ldr + lane + i * 64];
+    if (ep.ln2_g) srf_wave_layernorm<NV>(v, N, lane, ep.ln2_g, ep.ln2_b, ep.eps2);
+    if (ep.relu2)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// srf_linear
+// ---------------------------------------------------------------------------------------------------------------------
+#define LIN_TM 32
+#define LIN_TN 128
+#define LIN_KC 32
+
+// 32 floats of one operand row (4 consecutive channels per call) into the swizzled parity image (see spconv.hip)
+__device__ __forceinline__ void srf_img_store(float *img, int r, int q, const f32x4 &v)
+{
+    const int swz = (r >> 1) & 7;
+    const int off = 2 * (q & 1);
+    const f32x2 ev = {v[0], v[2]}, od = {v[1], v[3]};
+    *reinterpret_cast<f32x2 *>(img + r * 32 + ((q >> 1) ^ swz) * 4 + off) = ev;
+    *reinterpret_cast<f32x2 *>(img + r * 32 + ((4 + (q >> 1)) ^ swz) * 4 + off) = od;
+}
+
+// register-staged loads of one K chunk (branch-free: clamped addresses, validity kept in a bit mask and applied at
+// store time so that the loads stay in flight across the MFMA block)
+__device__ __forceinline__ void srf_lin_load(const float *__restrict__ X, int M, int ldx, const float *__restrict__ W, int N,
+                                             int ldw, int row0, int col0, int kc, int kend, int xr, int xq, f32x4 &rx,
+                                             f32x4 (&rw)[4], unsigned &ok)
+{
+    const int tid = threadIdx.x;
+    unsigned m = 0;
+    {
+        const int row = row0 + xr, k = kc + xq * 4;
+        rx = *reinterpret_cast<const f32x4 *>(X + (size_t)(row < M ? row : 0) * ldx + (k < kend ? k : 0));
+        m |= ((row < M) & (k < kend)) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = tid + j * 256;
+        const int n = col0 + (e >> 3), k = kc + (e & 7) * 4;
+        rw[j] = *reinterpret_cast<const f32x4 *>(W + (size_t)(n < N ? n : 0) * ldw + (k < kend ? k : 0));
+        m |= (((n < N) & (k < kend)) ? 1u : 0u) << (1 + j);
+    }
+    ok = m;
+}
+
+__device__ __forceinline__ void srf_lin_store(float *sx, float *sw, int xr, int xq, const f32x4 &rx, const f32x4 (&rw)[4],
+                                              unsigned ok)
+{
+    const int tid = threadIdx.x;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    srf_img_store(sx, xr, xq, (ok & 1u) ? rx : zero);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = tid + j * 256;
+        srf_img_store(sw, e >> 3, e & 7, ((ok >> (1 + j)) & 1u) ? rw[j] : zero);
+    }
+}
+
+__global__ __launch_bounds__(256) void srf_linear_k(const float *__restrict__ X, int M, int K, int ldx,
+                                                  const float *__restrict__ W, int N, int ldw, float *__restrict__ Y,
+                                                  int ldy, int k_per_split, float *__restrict__ partial, RowEpilogue ep,
+                                                  int fuse_rows)
+{
+    __shared__ __attribute__((aligned(16))) float s_x[2][LIN_TM * 32];
+    __shared__ __attribute__((aligned(16))) float s_w[2][LIN_TN * 32];
+    __shared__ __attribute__((aligned(16))) float s_out[LIN_TM][LIN_TN + 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col0 = blockIdx.x * LIN_TN, row0 = blockIdx.y * LIN_TM, split = blockIdx.z;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    const int T = (kend - kbeg + LIN_KC - 1) / LIN_KC;
+
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+
+    // staging: X tile 32 rows x 8 float4 = 256 (one per thread); W tile 128 rows x 8 = 1024 (four per thread)
+    f32x4 rx, rw[4];
+    unsigned ok = 0;
+    const int xr = tid >> 3, xq = tid & 7;
+    const int kh = lane >> 5;
+    const int arow = lane & 31, a_swz = (arow >> 1) & 7;
+    const int bcol = wave * 32 + (lane & 31), b_swz = (bcol >> 1) & 7;
+    if (T > 0) {
+        srf_lin_load(X, M, ldx, W, N, ldw, row0, col0, kbeg, kend, xr, xq, rx, rw, ok);
+        srf_lin_store(s_x[0], s_w[0], xr, xq, rx, rw, ok);
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        const bool more = t + 1 < T;
+        if (more) srf_lin_load(X, M, ldx, W, N, ldw, row0, col0, kbeg + (t + 1) * LIN_KC, kend, xr, xq, rx, rw, ok);
+        f32x4 af[4], bf[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            af[g] = *reinterpret_cast<const f32x4 *>(s_x[buf] + arow * 32 + (((kh << 2) + g) ^ a_swz) * 4);
+            bf[g] = *reinterpret_cast<const f32x4 *>(s_w[buf] + bcol * 32 + (((kh << 2) + g) ^ b_swz) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j >> 2][j & 3], bf[j >> 2][j & 3], acc, 0, 0, 0);
+        if (more) srf_lin_store(s_x[buf ^ 1], s_w[buf ^ 1], xr, xq, rx, rw, ok);
+        __syncthreads();
+    }
+
+    // C/D layout: col = lane & 31, row = (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5)
+    if (partial) {  // split-K: raw partial sums, reduced by srf_rows_epilogue_k
+        float *dst = partial + (size_t)split * M * N;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = row0 + (j & 3) + 8 * (j >> 2) + 4 * kh, col = col0 + wave * 32 + (lane & 31);
+            if (row < M && col < N) dst[(size_t)row * N + col] = acc[j];
+        }
+        return;
+    }
+    if (!fuse_rows) {  // plain bias (+ReLU) epilogue straight from the accumulators
+        const int col = col0 + wave * 32 + (lane & 31);
+        const float b = (ep.bias && col < N) ? ep.bias[col] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = row0 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+            if (row < M && col < N) {
+                float v = acc[j] + b;
+                if (ep.relu1) v = v > 0.f ? v : 0.f;
+                Y[(size_t)row * ldy + col] = v;
+            }
+        }
+        return;
+    }
+    // whole rows live in this workgroup (N <= 128): tile -> LDS, then one wave per 8 rows runs the row epilogue
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s_out[(j & 3) + 8 * (j >> 2) + 4 * kh][wave * 32 + (lane & 31)] = acc[j];
+    __syncthreads();
+    for (int r = wave * 8; r < wave * 8 + 8; ++r) {
+        const int row = row0 + r;
+        if (row >= M) break;
+        float v[2] = {lane < N ? s_out[r][lane] : 0.f, lane + 64 < N ? s_out[r][lane + 64] : 0.f};
+        srf_row_epilogue<2>(v, N, lane, row, ep);
+        if (lane < N) Y[(size_t)row * ldy + lane] = v[0];
+        if (lane + 64 < N) Y[(size_t)row * ldy + lane + 64] = v[1];
+    }
+}
+
+// one wave per row: sum the split-K partial slabs (or read a finished product), then the epilogue chain.  N <= 1024.
+__global__ __launch_bounds__(256) void srf_rows_epilogue_k(const float *__restrict__ partial, int nsplit, int M, int N,
+                                                         float *__restrict__ Y, int ldy, RowEpilogue ep)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + i * 64;
+        float s = 0.f;
+        if (c < N)
+            for (int p = 0; p < nsplit; ++p) s += partial[((size_t)p * M + row) * N + c];
+        v[i] = s;
+    }
+    srf_row_epilogue<16>(v, N, lane, row, ep);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (lane + i * 64 < N) Y[(size_t)row * ldy + lane + i * 64] = v[i];
+}
+
+static RowEpilogue srf_make_epilogue(const float *bias, const float *ln1_g, const float *ln1_b, float eps1, int relu1,
+                                     const float *residual, int ldr, const float *ln2_g, const float *ln2_b, float eps2,
+                                     int relu2)
+{
+    RowEpilogue ep;
+    ep.bias = bias;
+    ep.ln1_g = ln1_g;
+    ep.ln1_b = ln1_b;
+    ep.residual = residual;
+    ep.ln2_g = ln2_g;
+    ep.ln2_b = ln2_b;
+    ep.ldr = ldr;
+    ep.relu1 = relu1;
+    ep.relu2 = relu2;
+    ep.eps1 = eps1;
+    ep.eps2 = eps2;
+    return ep;
+}
+
+extern "C" size_t srf_linear_workspace_bytes(int M, int N, int K)
+{
+    // split-K slabs for long K, or one slab when the row epilogue cannot be fused (N > 128)
+    int nsplit = 1;
+    if (K >= 2048) nsplit = (K + 255) / 256;
+    return (size_t)nsplit * (size_t)(M > 0 ? M : 1) * N * sizeof(float);
+}
+
+extern "C" int srf_linear(const float *X, int M, int K, int ldx, const float *W, int N, int ldw, const float *bias,
+                          const float *ln1_g, const float *ln1_b, float eps1, int relu1, const float *residual, int ldr,
+                          const float *ln2_g, const float *ln2_b, float eps2, int relu2, float *Y, int ldy,
+                          void *workspace, size_t workspace_bytes, srf_stream_t stream)
+{
+    if (M < 0 || N <= 0 || K <= 0 || (K & 3) || (ldx & 3) || (ldw & 3) || ldx < K || ldw < K || ldy < N) return SRF_EINVAL;
+    if ((ln1_g == nullptr) != (ln1_b == nullptr) || (ln2_g == nullptr) != (ln2_b == nullptr)) return SRF_EINVAL;
+    if (M == 0) return SRF_OK;
+    if (!X || !W || !Y) return SRF_EINVAL;
+    const bool rows = ln1_g || ln2_g || residual || relu2;
+    if (rows && N > 1024) return SRF_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    RowEpilogue ep = srf_make_epilogue(bias, ln1_g, ln1_b, eps1, relu1, residual, ldr, ln2_g, ln2_b, eps2, relu2);
+    int nsplit = 1, kps = K;
+    if (K >= 2048) {
+        kps = 256;
+        nsplit = (K + kps - 1) / kps;
+    }
+    const bool two_pass = nsplit > 1 || (rows && N > LIN_TN);
+    if (two_pass) {
+        if (!workspace || workspace_bytes < (size_t)nsplit * M * N * sizeof(float)) return SRF_EWORKSPACE;
+        RowEpilogue none = srf_make_epilogue(nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0, nullptr, nullptr, 0.f, 0);
+        hipLaunchKernelGGL(srf_linear_k, dim3(srf_ceil_div(N, LIN_TN), srf_ceil_div(M, LIN_TM), nsplit), dim3(256), 0, st, X, M, K,
+                           ldx, W, N, ldw, Y, ldy, kps, (float *)workspace, none, 0);
+        hipLaunchKernelGGL(srf_rows_epilogue_k, dim3(srf_ceil_div(M, 4)), dim3(256), 0, st, (const float *)workspace, nsplit, M,
+                           N, Y, ldy, ep);
+    } else {
+        hipLaunchKernelGGL(srf_linear_k, dim3(srf_ceil_div(N, LIN_TN), srf_ceil_div(M, LIN_TM), 1), dim3(256), 0, st, X, M, K, ldx,
+                           W, N, ldw, Y, ldy, K, (float *)nullptr, ep, rows ? 1 : 0);
+    }
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// srf_self_attention: qkv (P, 3E) rows [q | k | v] (after in_proj), heads H, head dim d = E / H (d <= 32, d % 4 == 0)
+// out (P, E) = concat_h softmax(q_h k_h^T / sqrt(d)) v_h          (nn.MultiheadAttention, batch 1; srfdet_head.py:1489)
+// One workgroup per (head, 32 queries); 8 lanes share a query and split the keys; online softmax, merged by shuffles.
+// ---------------------------------------------------------------------------------------------------------------------
+#define ATT_DMAX 32
+#define ATT_KTILE 128
+
+__global__ __launch_bounds__(256) void srf_self_attention_k(const float *__restrict__ qkv, int P, int E, int H,
+                                                          float *__restrict__ out)
+{
+    __shared__ float s_k[ATT_KTILE][ATT_DMAX + 1];
+    __shared__ float s_v[ATT_KTILE][ATT_DMAX + 1];
+    const int d = E / H;
+    const int h = blockIdx.x, q0 = blockIdx.y * 32;
+    const int tid = threadIdx.x;
+    const int qi = q0 + (tid >> 3), part = tid & 7;
+    const float scale = 1.0f / sqrtf((float)d);
+    float q[ATT_DMAX], o[ATT_DMAX];
+#pragma unroll
+    for (int i = 0; i < ATT_DMAX; ++i) {
+        q[i] = (i < d && qi < P) ? qkv[(size_t)qi * 3 * E + h * d + i] * scale : 0.f;
+        o[i] = 0.f;
+    }
+    float mx = -INFINITY, den = 0.f;
+    for (int k0 = 0; k0 < P; k0 += ATT_KTILE) {
+        const int nk = min(ATT_KTILE, P - k0);
+        __syncthreads();
+        for (int e = tid; e < nk * d; e += 256) {
+            const int kk = e / d, i = e % d;
+            s_k[kk][i] = qkv[(size_t)(k0 + kk) * 3 * E + E + h * d + i];
+            s_v[kk][i] = qkv[(size_t)(k0 + kk) * 3 * E + 2 * E + h * d + i];
+        }
+        __syncthreads();
+        for (int kk = part; kk < nk; kk += 8) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < ATT_DMAX; ++i)
+                if (i < d) s += q[i] * s_k[kk][i];
+            const float nm = fmaxf(mx, s);
+            const float corr = __expf(mx - nm), p = __expf(s - nm);
+            den = den * corr + p;
+#pragma unroll
+            for (int i = 0; i < ATT_DMAX; ++i)
+                if (i < d) o[i] = o[i] * corr + p * s_v[kk][i];
+            mx = nm;
+        }
+    }
+    // merge the 8 partial (max, sum, o) states of a query
+#pragma unroll
+    for (int sft = 1; sft < 8; sft <<= 1) {
+        const float omx = __shfl_xor(mx, sft, 64), oden = __shfl_xor(den, sft, 64);
+        const float nm = fmaxf(mx, omx);
+        const float c1 = (mx == -INFINITY) ? 0.f : __expf(mx - nm), c2 = (omx == -INFINITY) ? 0.f : __expf(omx - nm);
+        den = den * c1 + oden * c2;
+#pragma unroll
+        for (int i = 0; i < ATT_DMAX; ++i) {
+            const float oo = __shfl_xor(o[i], sft, 64);
+            o[i] = o[i] * c1 + oo * c2;
+        }
+        mx = nm;
+    }
+    if (qi < P)
+        for (int i = part; i < d; i += 8) out[(size_t)qi * E + h * d + i] = o[i] / den;
+}
+
+extern "C" int srf_self_attention(const float *qkv, int P, int E, int H, float *out, srf_stream_t stream)
+{
+    if (P < 0 || E <= 0 || H <= 0 || E % H || (E / H) > ATT_DMAX) return SRF_EINVAL;
+    if (P == 0) return SRF_OK;
+    if (!qkv || !out) return SRF_EINVAL;
+    hipLaunchKernelGGL(srf_self_attention_k, dim3(H, srf_ceil_div(P, 32)), dim3(256), 0, (hipStream_t)stream, qkv, P, E, H, out);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// srf_dynconv_mid (srfdet_head.py:2671-2686): per proposal r
+//   X1 = F_r (S x C) . W1_r (C x d);  X1 = relu(LN_d(X1));  X2 = X1 (S x d) . W2_r (d x C);  out_r = relu(LN_C(X2))
+// F: (R, S, C) bin-major RoI features; params: (R, 2*C*d) = [W1 | W2] as produced by dynamic_layer.
+// One workgroup per proposal; S = 49 rows padded to 64; C in {128, 256}, d in {32, 64}.  16x16x4 f32 MFMA tiles.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int C, int D>
+__global__ __launch_bounds__(256) void srf_dynconv_mid_k(const float *__restrict__ F, const float *__restrict__ params, int S,
+                                                       const float *__restrict__ g1, const float *__restrict__ b1, float eps1,
+                                                       const float *__restrict__ g2, const float *__restrict__ b2, float eps2,
+                                                       float *__restrict__ out)
+{
+    constexpr int SP = 64;  // padded rows
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *s_f = lds;                  // [SP][C+1]
+    float *s_w1 = s_f + SP * (C + 1);  // [C][D+1]   (k-major for the B operand of product 1)
+    float *s_x1 = s_w1 + C * (D + 1);  // [SP][D+1]
+    float *s_w2 = s_f;                 // [D][C+1]  reuses the F region once product 1 is done (D <= SP)
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *Fr = F + (size_t)r * S * C;
+    const float *W1 = params + (size_t)r * 2 * C * D, *W2 = W1 + C * D;
+    for (int e = tid; e < SP * C; e += 256) {
+        const int i = e / C, c = e % C;
+        s_f[i * (C + 1) + c] = i < S ? Fr[(size_t)i * C + c] : 0.f;
+    }
+    for (int e = tid; e < C * D; e += 256) s_w1[(e / D) * (D + 1) + e % D] = W1[e];
+    __syncthreads();
+    // product 1: (SP x C)(C x D): 4 x (D/16) tiles of 16x16, wave w takes row tile w
+    const int l15 = lane & 15, lq = lane >> 4;
+    {
+        f32x4 acc[D / 16];
+#pragma unroll
+        for (int t = 0; t < D / 16; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < C; k += 4) {
+            const float a = s_f[(wave * 16 + l15) * (C + 1) + k + lq];
+#pragma unroll
+            for (int t = 0; t < D / 16; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, s_w1[(k + lq) * (D + 1) + t * 16 + l15], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < D / 16; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_x1[(wave * 16 + lq * 4 + j) * (D + 1) + t * 16 + l15] = acc[t][j];
+    }
+    __syncthreads();  // every wave is done reading F: its region now takes W2
+    for (int e = tid; e < C * D; e += 256) s_w2[(e / C) * (C + 1) + e % C] = W2[e];
+    // LayerNorm(D) + ReLU on each of the S rows: 4 lanes per row
+    {
+        const int row = tid >> 2, part = tid & 3;
+        float v[D / 4], s = 0.f;
+#pragma unroll
+        for (int i = 0; i < D / 4; ++i) {
+            v[i] = s_x1[row * (D + 1) + part + i * 4];
+            s += v[i];
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        const float mean = s / (float)D;
+        float qv = 0.f;
+#pragma unroll
+        for (int i = 0; i < D / 4; ++i) qv += (v[i] - mean) * (v[i] - mean);
+        qv += __shfl_xor(qv, 1, 64);
+        qv += __shfl_xor(qv, 2, 64);
+        const float rstd = 1.0f / sqrtf(qv / (float)D + eps1);
+#pragma unroll
+        for (int i = 0; i < D / 4; ++i) {
+            const int c = part + i * 4;
+            const float y = (v[i] - mean) * rstd * g1[c] + b1[c];
+            s_x1[row * (D + 1) + c] = (row < S && y > 0.f) ? y : 0.f;
+        }
+    }
+    __syncthreads();
+    // product 2: (SP x D)(D x C): wave w takes row tile w, all C/16 column tiles; then LayerNorm(C) + ReLU per row
+    {
+        f32x4 acc[C / 16];
+#pragma unroll
+        for (int t = 0; t < C / 16; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < D; k += 4) {
+            const float a = s_x1[(wave * 16 + l15) * (D + 1) + k + lq];
+#pragma unroll
+            for (int t = 0; t < C / 16; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, s_w2[(k + lq) * (C + 1) + t * 16 + l15], acc[t], 0, 0, 0);
+        }
+        // row (wave*16 + lq*4 + j) is spread over the 16 lanes with the same lq: reduce across those lanes
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < C / 16; ++t) s += acc[t][j];
+#pragma unroll
+            for (int dd = 1; dd < 16; dd <<= 1) s += __shfl_xor(s, dd, 64);
+            const float mean = s / (float)C;
+            float qv = 0.f;
+#pragma unroll
+            for (int t = 0; t < C / 16; ++t) qv += (acc[t][j] - mean) * (acc[t][j] - mean);
+#pragma unroll
+            for (int dd = 1; dd < 16; dd <<= 1) qv += __shfl_xor(qv, dd, 64);
+            const float rstd = 1.0f / sqrtf(qv / (float)C + eps2);
+            const int row = wave * 16 + lq * 4 + j;
+            if (row < S) {
+#pragma unroll
+                for (int t = 0; t < C / 16; ++t) {
+                    const int c = t * 16 + l15;
+                    const float y = (acc[t][j] - mean) * rstd * g2[c] + b2[c];
+                    out[((size_t)r * S + row) * C + c] = y > 0.f ? y : 0.f;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int srf_dynconv_mid(const float *F, const float *params, int R, int S, int C, int D, const float *g1,
+                               const float *b1, float eps1, const float *g2, const float *b2, float eps2, float *out,
+                               srf_stream_t stream)
+{
+    if (R < 0 || S <= 0 || S > 64) return SRF_EINVAL;
+    if (R == 0) return SRF_OK;
+    if (!F || !params || !g1 || !b1 || !g2 || !b2 || !out) return SRF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 128 && D == 32) {
+        const size_t sh = sizeof(float) * (64 * 129 + 128 * 33 + 64 * 33);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_dynconv_mid_k<128, 32>), dim3(R), dim3(256), sh, st, F, params, S, g1, b1, eps1, g2,
+                           b2, eps2, out);
+    } else if (C == 256 && D == 64) {
+        const size_t sh = sizeof(float) * (64 * 257 + 256 * 65 + 64 * 65);
+        static bool attr_set = false;
+        if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in (idempotent; a race only repeats the call)
+            SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_dynconv_mid_k<256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)sh));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_dynconv_mid_k<256, 64>), dim3(R), dim3(256), sh, st, F, params, S, g1, b1, eps1, g2,
+                           b2, eps2, out);
+    } else {
+        return SRF_EUNSUPPORTED;
+    }
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// srf_apply_deltas (srfdet_head.py:1534-1625): deltas (R, Dd) on boxes (R, Dd) with centres in metres -> refined boxes
+// with centres normalised to [0,1]; sin/cos/velocity copied from the deltas.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DeltaGeom {
+    float w[6], lo[3], ext[3], clamp;
+};
+
+__global__ __launch_bounds__(128) void srf_apply_deltas_k(const float *__restrict__ deltas, const float *__restrict__ boxes,
+                                                        int R, int Dd, DeltaGeom g, float *__restrict__ out)
+{
+    const int r = blockIdx.x * 128 + threadIdx.x;
+    if (r >= R) return;
+    const float *d = deltas + (size_t)r * Dd, *b = boxes + (size_t)r * Dd;
+    float *o = out + (size_t)r * Dd;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float size = expf(b[3 + i]);
+        const float ctr = (d[i] / g.w[i]) * size + b[i];
+        float n = (ctr - g.lo[i]) / g.ext[i];
+        n = n < 0.f ? 0.f : (n > 1.f ? 1.f : n);
+        o[i] = n;
+        float ds = d[3 + i] / g.w[3 + i];
+        ds = ds > g.clamp ? g.clamp : ds;
+        o[3 + i] = logf(expf(ds) * size);
+    }
+    for (int i = 6; i < Dd; ++i) o[i] = d[i];
+}
+
+extern "C" int srf_apply_deltas(const float *deltas, const float *boxes, int R, int Dd, const float *weights6,
+                                const float *pc_range, float scale_clamp, float *out, srf_stream_t stream)
+{
+    if (R < 0 || Dd < 8 || !weights6 || !pc_range) return SRF_EINVAL;
+    if (R == 0) return SRF_OK;
+    if (!deltas || !boxes || !out) return SRF_EINVAL;
+    DeltaGeom g;
+    for (int i = 0; i < 6; ++i) g.w[i] = weights6[i];
+    for (int i = 0; i < 3; ++i) {
+        g.lo[i] = pc_range[i];
+        g.ext[i] = pc_range[3 + i] - pc_range[i];
+    }
+    g.clamp = scale_clamp;
+    hipLaunchKernelGGL(srf_apply_deltas_k, dim3(srf_ceil_div(R, 128)), dim3(128), 0, (hipStream_t)stream, deltas, boxes, R, Dd, g,
+                       out);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}

@@ -313,3 +313,70 @@ def nms_rotated(boxes_xywhr, scores, iou_threshold):
     check(L.srf_nms_rotated(_ptr(sorted_boxes), n, float(iou_threshold), _ptr(keep), _ptr(ws), ws_bytes, _stream()),
           "nms_rotated")
     return order[keep.bool()]
+
+
+# ---------------------------------------------------------------------------------------------- decoder stage
+def _ln(ln):
+    """nn.LayerNorm or (gamma, beta, eps) or None -> (ptr_g, ptr_b, eps)."""
+    if ln is None:
+        return None, None, 0.0
+    if isinstance(ln, tuple):
+        return _ptr(ln[0]), _ptr(ln[1]), float(ln[2])
+    return _ptr(ln.weight), _ptr(ln.bias), float(ln.eps)
+
+
+def linear(x, weight, bias=None, ln1=None, relu1=False, residual=None, ln2=None, relu2=False):
+    """Y = [LN2]([residual +] relu1?([LN1](x @ weight.T + bias))), then relu2? -- one launch (two when K >= 2048 or N > 128
+    with a row epilogue).  x (M,K), weight (N,K), both with unit inner stride."""
+    x = _dev(x, "x", torch.float32)
+    if not weight.is_cuda or weight.stride(1) != 1:
+        raise RuntimeError("srfdet3d_amd: `weight` must be a GPU tensor with unit inner stride")
+    M, K = x.shape
+    N = weight.shape[0]
+    L = _lib.lib()
+    y = _empty((M, N), torch.float32, x.device)
+    if residual is not None:
+        residual = _dev(residual, "residual", torch.float32)
+    need_ws = K >= 2048 or ((ln1 is not None or ln2 is not None or residual is not None or relu2) and N > 128)
+    ws_bytes = L.srf_linear_workspace_bytes(M, N, K) if need_ws else 0
+    ws = _empty((ws_bytes,), torch.uint8, x.device) if ws_bytes else None
+    g1, b1, e1 = _ln(ln1)
+    g2, b2, e2 = _ln(ln2)
+    check(L.srf_linear(_ptr(x), M, K, x.stride(0), _ptr(weight), N, weight.stride(0), _ptr(bias), g1, b1, e1, int(bool(relu1)),
+                       _ptr(residual), residual.stride(0) if residual is not None else 0, g2, b2, e2, int(bool(relu2)),
+                       _ptr(y), N, _ptr(ws), ws_bytes, _stream()), "linear")
+    return y
+
+
+def self_attention(qkv, num_heads):
+    """qkv (P, 3E) rows [q|k|v] -> (P, E): softmax(q k^T / sqrt(d)) v per head."""
+    qkv = _dev(qkv, "qkv", torch.float32)
+    P, E3 = qkv.shape
+    E = E3 // 3
+    out = _empty((P, E), torch.float32, qkv.device)
+    check(_lib.lib().srf_self_attention(_ptr(qkv), P, E, num_heads, _ptr(out), _stream()), "self_attention")
+    return out
+
+
+def dynconv_mid(feats, params, ln1, ln2):
+    """feats (R,S,C), params (R, 2*C*D) -> relu(LN_C(relu(LN_D(feats @ W1)) @ W2)), (R,S,C)."""
+    feats = _dev(feats, "feats", torch.float32)
+    params = _dev(params, "params", torch.float32)
+    R, S, C = feats.shape
+    D = params.shape[1] // (2 * C)
+    out = _empty((R, S, C), torch.float32, feats.device)
+    g1, b1, e1 = _ln(ln1)
+    g2, b2, e2 = _ln(ln2)
+    check(_lib.lib().srf_dynconv_mid(_ptr(feats), _ptr(params), R, S, C, D, g1, b1, e1, g2, b2, e2, _ptr(out), _stream()),
+          "dynconv_mid")
+    return out
+
+
+def apply_deltas(deltas, boxes, weights6, pc_range, scale_clamp):
+    deltas = _dev(deltas, "deltas", torch.float32)
+    boxes = _dev(boxes, "boxes", torch.float32)
+    R, Dd = deltas.shape
+    out = _empty((R, Dd), torch.float32, deltas.device)
+    check(_lib.lib().srf_apply_deltas(_ptr(deltas), _ptr(boxes), R, Dd, hf(weights6), hf(pc_range), float(scale_clamp),
+                                      _ptr(out), _stream()), "apply_deltas")
+    return out

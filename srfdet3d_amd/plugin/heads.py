@@ -177,8 +177,47 @@ class _StageBase(BaseModule):
         return r.permute(0, 2, 1).reshape(r.shape[0], r.shape[2], 7, 7)
 
     # ---- stage arithmetic -----------------------------------------------------------------------------------
+    def _hip_eligible(self, roi_feats):
+        dc = self.inst_interact_lidar
+        return (roi_feats.is_cuda and not torch.is_grad_enabled() and not self.training
+                and (dc.feat_channels, dc.dynamic_dim) in ((128, 32), (256, 64)) and roi_feats.shape[1] <= 64
+                and isinstance(self.activation_lidar, nn.ReLU) and dc.dynamic_num == 2)
+
+    def _refine_hip(self, roi_feats, boxes_m, prop_feats, bs, n_p):
+        """The stage on the hand-written kernels of csrc/decoder.hip (inference): ~20 launches instead of ~60."""
+        C = self.feat_channels_lidar
+        R = bs * n_p
+        S = roi_feats.shape[1]
+        q0 = (roi_feats.mean(dim=1) if prop_feats is None else prop_feats).reshape(R, C).contiguous()
+        mha = self.self_attn_lidar
+        qkv = ops.linear(q0, mha.in_proj_weight, mha.in_proj_bias)
+        att = qkv.new_empty((R, C))
+        for b in range(bs):  # attention is among the proposals of one sample
+            att[b * n_p:(b + 1) * n_p] = ops.self_attention(qkv[b * n_p:(b + 1) * n_p], mha.num_heads)
+        q1 = ops.linear(att, mha.out_proj.weight, mha.out_proj.bias, residual=q0, ln2=self.norm1_lidar)
+        dc = self.inst_interact_lidar
+        params = ops.linear(q1, dc.dynamic_layer.weight, dc.dynamic_layer.bias)
+        mid = ops.dynconv_mid(roi_feats, params, dc.norm1, dc.norm2)
+        obj = ops.linear(mid.view(R, S * C), dc.out_layer.weight, dc.out_layer.bias, ln1=dc.norm3, relu1=True, residual=q1,
+                         ln2=self.norm2_lidar)
+        hid = ops.linear(obj, self.linear1_lidar.weight, self.linear1_lidar.bias, relu1=True)
+        obj = ops.linear(hid, self.linear2_lidar.weight, self.linear2_lidar.bias, residual=obj, ln2=self.norm3_lidar)
+        cls_f, reg_f = obj, obj
+        for i in range(0, len(self.cls_module_lidar), 3):
+            cls_f = ops.linear(cls_f, self.cls_module_lidar[i].weight, None, ln1=self.cls_module_lidar[i + 1], relu1=True)
+        for i in range(0, len(self.reg_module_lidar), 3):
+            reg_f = ops.linear(reg_f, self.reg_module_lidar[i].weight, None, ln1=self.reg_module_lidar[i + 1], relu1=True)
+        logits = ops.linear(cls_f, self.class_logits_lidar.weight, self.class_logits_lidar.bias)
+        deltas = ops.linear(reg_f, self.bboxes_delta_lidar.weight, self.bboxes_delta_lidar.bias)
+        pred = ops.apply_deltas(deltas, boxes_m.reshape(R, -1), self.bbox_weights[:6], self.pc_range_lidar, self.scale_clamp)
+        return logits.view(bs, n_p, -1), pred.view(bs, n_p, -1), obj.view(1, R, C)
+
     def _refine(self, roi_feats, boxes_m, prop_feats, bs, n_p):
-        """roi_feats (R,S,C); boxes_m (bs,n_p,D) with centres in metres; prop_feats (bs,n_p,C)-viewable or None."""
+        """roi_feats (R,S,C); boxes_m (bs,n_p,D) with centres in metres; prop_feats (bs,n_p,C)-viewable or None.
+        Inference on the GPU runs `_refine_hip`; the torch formulation below is the autograd (training) form and what
+        the host-side fixture tests exercise."""
+        if self._hip_eligible(roi_feats):
+            return self._refine_hip(roi_feats, boxes_m, prop_feats, bs, n_p)
         C = self.feat_channels_lidar
         R = bs * n_p
         if prop_feats is None:
@@ -242,7 +281,12 @@ class SingleSRFDetHead(_StageBase):
             if img_feats is not None else None
         pts_roi = self._gather(point_feats, rois_bev, pooler) if point_feats is not None else None
         if img_roi is not None and pts_roi is not None and self.use_fusion:
-            roi_feats = self.output_fused_proj(torch.cat((img_roi, pts_roi), dim=-1))
+            fused_in = torch.cat((img_roi, pts_roi), dim=-1)
+            if self._hip_eligible(pts_roi):
+                roi_feats = ops.linear(fused_in.view(-1, fused_in.shape[-1]), self.output_fused_proj.weight,
+                                       self.output_fused_proj.bias).view(pts_roi.shape)
+            else:
+                roi_feats = self.output_fused_proj(fused_in)
         elif not self.use_fusion and img_roi is not None and pts_roi is None:
             roi_feats = img_roi
         elif not self.use_fusion and pts_roi is not None and img_roi is None:
