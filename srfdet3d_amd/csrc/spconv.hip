@@ -492,10 +492,18 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
         hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_packed_k<64, 64, 2, 2>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0,
                            st, SRF_ARGS);
         break;
-    case 128:
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_packed_k<128, 64, 2, 2>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0,
-                           st, SRF_ARGS);
+    case 128: {
+        // 64-row tiles halve the W-slab traffic, 32-row tiles balance better when there are only a few tiles per CU:
+        // pick the one whose busiest CU (tiles dealt evenly over 256 CUs) carries fewer 32-row units
+        const int units64 = 2 * srf_ceil_div(srf_ceil_div(A_out, 64), 256), units32 = srf_ceil_div(srf_ceil_div(A_out, 32), 256);
+        if (units32 < units64)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_packed_k<128, 32, 1, 4>), dim3(srf_ceil_div(A_out, 32)), dim3(256), 0,
+                               st, SRF_ARGS);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_packed_k<128, 64, 2, 2>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0,
+                               st, SRF_ARGS);
         break;
+    }
     default:
         return SRF_EUNSUPPORTED;
     }
