@@ -183,7 +183,7 @@ int srf_box_rois(float *boxes, int B, int P, int box_dim, const float *pc_range 
  *   null pointers skip a step.  Replaces nn.Linear + nn.LayerNorm + ReLU (+ the residual adds) call chains, e.g.
  *   out_layer -> norm3 -> ReLU -> (+prop) -> norm2 (srfdet_head.py:2689-2691, :1502-1503).  K % 4 == 0; K >= 2048 is
  *   split over K and needs the workspace (srf_linear_workspace_bytes); LayerNorm steps need N <= 1024.
- * srf_self_attention: qkv (P x 3E) = [q | k | v] rows after in_proj -> out (P x E), heads H, head dim E/H <= 32;
+ * srf_self_attention: qkv (P x 3E) = [q | k | v] rows after in_proj -> out (P x E), heads H, head dim E/H in {16, 32};
  *   replaces the attention core of nn.MultiheadAttention(batch 1) at srfdet_head.py:1489.
  * srf_dynconv_mid: feats (R x S x C) bin-major RoI features, params (R x 2*C*D) from dynamic_layer ->
  *   relu(LN_C(relu(LN_D(feats W1)) W2)) (R x S x C); srfdet_head.py:2671-2686.  (C, D) in {(128,32), (256,64)}, S <= 64.

@@ -314,71 +314,98 @@ extern "C" int srf_linear(const float *X, int M, int K, int ldx, const float *W,
 // ---------------------------------------------------------------------------------------------------------------------
 #define ATT_DMAX 32
 #define ATT_KTILE 128
+#define ATT_QPB 16   // queries per workgroup
+#define ATT_PARTS 16 // lanes sharing one query (each takes every 16th key)
 
+template <int DH>  // head dim, multiple of 4
 __global__ __launch_bounds__(256) void srf_self_attention_k(const float *__restrict__ qkv, int P, int E, int H,
                                                           float *__restrict__ out)
 {
-    __shared__ float s_k[ATT_KTILE][ATT_DMAX + 1];
-    __shared__ float s_v[ATT_KTILE][ATT_DMAX + 1];
-    const int d = E / H;
-    const int h = blockIdx.x, q0 = blockIdx.y * 32;
+    constexpr int LD = DH + 4;  // 16-byte aligned rows, bank-shifted by 4 floats per key
+    __shared__ __attribute__((aligned(16))) float s_k[ATT_KTILE * LD];
+    __shared__ __attribute__((aligned(16))) float s_v[ATT_KTILE * LD];
+    const int h = blockIdx.x, q0 = blockIdx.y * ATT_QPB;
     const int tid = threadIdx.x;
-    const int qi = q0 + (tid >> 3), part = tid & 7;
-    const float scale = 1.0f / sqrtf((float)d);
-    float q[ATT_DMAX], o[ATT_DMAX];
+    const int qi = q0 + tid / ATT_PARTS, part = tid % ATT_PARTS;
+    const float scale = 1.0f / sqrtf((float)DH);
+    f32x4 q[DH / 4], o[DH / 4];
 #pragma unroll
-    for (int i = 0; i < ATT_DMAX; ++i) {
-        q[i] = (i < d && qi < P) ? qkv[(size_t)qi * 3 * E + h * d + i] * scale : 0.f;
-        o[i] = 0.f;
+    for (int i = 0; i < DH / 4; ++i) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        q[i] = qi < P ? *reinterpret_cast<const f32x4 *>(qkv + (size_t)qi * 3 * E + h * DH + i * 4) * scale : z;
+        o[i] = z;
     }
     float mx = -INFINITY, den = 0.f;
     for (int k0 = 0; k0 < P; k0 += ATT_KTILE) {
         const int nk = min(ATT_KTILE, P - k0);
         __syncthreads();
-        for (int e = tid; e < nk * d; e += 256) {
-            const int kk = e / d, i = e % d;
-            s_k[kk][i] = qkv[(size_t)(k0 + kk) * 3 * E + E + h * d + i];
-            s_v[kk][i] = qkv[(size_t)(k0 + kk) * 3 * E + 2 * E + h * d + i];
+        for (int e = tid; e < nk * (DH / 4); e += 256) {
+            const int kk = e / (DH / 4), i = e % (DH / 4);
+            const float *src = qkv + (size_t)(k0 + kk) * 3 * E + h * DH + i * 4;
+            *reinterpret_cast<f32x4 *>(s_k + kk * LD + i * 4) = *reinterpret_cast<const f32x4 *>(src + E);
+            *reinterpret_cast<f32x4 *>(s_v + kk * LD + i * 4) = *reinterpret_cast<const f32x4 *>(src + 2 * E);
         }
         __syncthreads();
-        for (int kk = part; kk < nk; kk += 8) {
+        for (int kk = part; kk < nk; kk += ATT_PARTS) {
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < ATT_DMAX; ++i)
-                if (i < d) s += q[i] * s_k[kk][i];
+            for (int i = 0; i < DH / 4; ++i) {
+                const f32x4 kv = *reinterpret_cast<const f32x4 *>(s_k + kk * LD + i * 4);
+                s += q[i][0] * kv[0] + q[i][1] * kv[1] + q[i][2] * kv[2] + q[i][3] * kv[3];
+            }
             const float nm = fmaxf(mx, s);
             const float corr = __expf(mx - nm), p = __expf(s - nm);
             den = den * corr + p;
 #pragma unroll
-            for (int i = 0; i < ATT_DMAX; ++i)
-                if (i < d) o[i] = o[i] * corr + p * s_v[kk][i];
+            for (int i = 0; i < DH / 4; ++i) {
+                const f32x4 vv = *reinterpret_cast<const f32x4 *>(s_v + kk * LD + i * 4);
+                o[i] = o[i] * corr + vv * p;
+            }
             mx = nm;
         }
     }
-    // merge the 8 partial (max, sum, o) states of a query
+    // merge the partial (max, sum, o) states of the lanes that share a query
 #pragma unroll
-    for (int sft = 1; sft < 8; sft <<= 1) {
+    for (int sft = 1; sft < ATT_PARTS; sft <<= 1) {
         const float omx = __shfl_xor(mx, sft, 64), oden = __shfl_xor(den, sft, 64);
         const float nm = fmaxf(mx, omx);
         const float c1 = (mx == -INFINITY) ? 0.f : __expf(mx - nm), c2 = (omx == -INFINITY) ? 0.f : __expf(omx - nm);
         den = den * c1 + oden * c2;
 #pragma unroll
-        for (int i = 0; i < ATT_DMAX; ++i) {
-            const float oo = __shfl_xor(o[i], sft, 64);
-            o[i] = o[i] * c1 + oo * c2;
-        }
+        for (int i = 0; i < DH / 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float oo = __shfl_xor(o[i][c], sft, 64);
+                o[i][c] = o[i][c] * c1 + oo * c2;
+            }
         mx = nm;
     }
-    if (qi < P)
-        for (int i = part; i < d; i += 8) out[(size_t)qi * E + h * d + i] = o[i] / den;
+    if (qi < P && part < DH / 4) {
+        const f32x4 r = o[0] / den;  // every lane of the group holds the merged state; lane `part` writes slice `part`
+        f32x4 w = r;
+#pragma unroll
+        for (int i = 0; i < DH / 4; ++i)
+            if (i == part) w = o[i] / den;
+        *reinterpret_cast<f32x4 *>(out + (size_t)qi * E + h * DH + part * 4) = w;
+    }
 }
 
 extern "C" int srf_self_attention(const float *qkv, int P, int E, int H, float *out, srf_stream_t stream)
 {
-    if (P < 0 || E <= 0 || H <= 0 || E % H || (E / H) > ATT_DMAX) return SRF_EINVAL;
+    if (P < 0 || E <= 0 || H <= 0 || E % H || (E / H) > ATT_DMAX || (E & 3)) return SRF_EINVAL;
     if (P == 0) return SRF_OK;
     if (!qkv || !out) return SRF_EINVAL;
-    hipLaunchKernelGGL(srf_self_attention_k, dim3(H, srf_ceil_div(P, 32)), dim3(256), 0, (hipStream_t)stream, qkv, P, E, H, out);
+    const dim3 grid(H, srf_ceil_div(P, ATT_QPB));
+    switch (E / H) {
+    case 16:
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_self_attention_k<16>), grid, dim3(256), 0, (hipStream_t)stream, qkv, P, E, H, out);
+        break;
+    case 32:
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_self_attention_k<32>), grid, dim3(256), 0, (hipStream_t)stream, qkv, P, E, H, out);
+        break;
+    default:
+        return SRF_EUNSUPPORTED;
+    }
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }
