@@ -7,7 +7,7 @@ driver launches this file under torch.distributed.run and every rank runs K fram
 are independent: no data-path collective); the job's time is the max over ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline     -- the dominant hand-written kernel (the 128->128 SubM sparse conv on the f32 MFMA pipe), its
+  roofline     -- the dominant hand-written kernel (the 128->128 SubM sparse conv, srf_spconv_packed_k, f32 MFMA), its
                   algorithmic FLOPs per launch (2 * pairs * Cin * Cout) over its mean duration measured with HIP
                   events on the launch stream inside the timed region, against the 157.3 TFLOP/s f32 MFMA peak;
   cpu_baseline -- oracle/pipeline.py (the CPU port of the same path: C/OpenMP operators + torch-CPU dense layers)
@@ -135,7 +135,7 @@ def main():
             if os.path.exists(tpath):
                 with open(tpath) as fh:
                     traffic = json.load(fh).get("traffic_bytes_per_launch")
-            roofline = dict(kernel="srf_spconv_mfma32_k<128,64,2,2> (SubM 3x3x3, 128->128)", bound="mfma",
+            roofline = dict(kernel="srf_spconv_packed_k<128,...> (SubM 3x3x3, 128->128, 5x184x184 level)", bound="mfma",
                             achieved=round(achieved, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                             launches=len(dom), avg_us=round(ms * 1e3, 2), algorithmic_flops_per_launch=int(flops),
