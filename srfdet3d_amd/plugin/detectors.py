@@ -131,7 +131,11 @@ class SRFDet(BaseModule):
                 coors.append(F.pad(c, (1, 0), mode="constant", value=i))
             if len(points) == 1:
                 return voxels[0], nums[0], coors[0]
-            return torch.cat(voxels, 0), torch.cat(nums, 0), torch.cat(coors, 0)
+            allv = torch.cat(voxels, 0)
+            means = [getattr(v, "srf_vfe_mean", None) for v in voxels]
+            if all(m is not None for m in means):  # keep the per-voxel means the voxelization kernel produced
+                allv.srf_vfe_mean = torch.cat(means, 0)
+            return allv, torch.cat(nums, 0), torch.cat(coors, 0)
         coors = [F.pad(self.pts_voxel_layer(res), (1, 0), mode="constant", value=i) for i, res in enumerate(points)]
         if len(points) == 1:
             return points[0], coors[0]

@@ -95,6 +95,9 @@ class _StageBase(BaseModule):
         self.voxel_size_lidar = voxel_size
         self.is_kitti = bool(is_kitti)
         self.use_fusion = use_fusion
+        # False reproduces the reference's image-RoI batch ids (b + cam*bs) against maps flattened b*n_cam + cam, which
+        # only coincide for bs = 1 (SURVEY.md finding 7); True makes the ids consistent for bs > 1
+        self.corrected_cam_indexing = False
         self.self_attn_lidar = nn.MultiheadAttention(C, num_heads, dropout=dropout)
         self.inst_interact_lidar = DynamicConv(C, dynamic_conv["dynamic_dim"], dynamic_conv["dynamic_num"],
                                                pooler_resolution)
@@ -164,6 +167,10 @@ class _StageBase(BaseModule):
     def _img_rois_feats(self, img_feats, rois_img, pooler_img, bs, n_p, n_cam):
         """gather over all cameras and sum them per proposal -> (bs*n_p, S, C) (srfdet_head.py:2543-2562)."""
         flat = [f.reshape(f.shape[0] * f.shape[1], *f.shape[2:]) for f in img_feats]
+        if self.corrected_cam_indexing and bs > 1:
+            ids = rois_img[:, 0]
+            rois_img = rois_img.clone()
+            rois_img[:, 0] = torch.remainder(ids, bs) * n_cam + torch.div(ids, bs, rounding_mode="floor")
         r = self._gather(flat, rois_img, pooler_img)  # (n_cam*bs*n_p, S, C), cam-major rows
         return r.view(n_cam, bs * n_p, r.shape[1], r.shape[2]).sum(dim=0)
 

@@ -75,3 +75,35 @@ def test_gpu_fusion_head_stage_by_stage_matches_reference(dev):
     with torch.no_grad():
         lg, bx = hd2([f.to(dev) for f in imf2], [f.to(dev) for f in pf2], metas2)
     np.testing.assert_allclose(bx.cpu().numpy()[0], GOLD["headlc.boxes"][0], rtol=0, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_gpu_fusion_stage_bs2_reference_and_corrected_cam_indexing(dev):
+    """bs = 2 exposes the reference's image-RoI indexing quirk (SURVEY.md finding 7): by default the HIP path
+    reproduces it (checked against the CPU oracle, which follows srfdet_head.py:2520-2547 literally); with
+    `corrected_cam_indexing` every sample reads its own cameras, i.e. equals the bs = 1 result of that sample."""
+    hd, pf, imf, metas = lc_head()
+    hd = hd.to(dev)
+    g = torch.Generator().manual_seed(5)
+    pf2 = [torch.cat([f, torch.randn(f.shape, generator=g) * 0.5], 0) for f in pf]
+    imf2 = [torch.cat([f, torch.randn(f.shape, generator=g) * 0.5], 0) for f in imf]
+    metas2 = [metas[0], dict(lidar2img=[m for m in S.camera_rig(f=177.0, cx=100.0, cy=70.0)])]
+    bx = torch.from_numpy(np.concatenate([GOLD["headlc.stage_in_boxes"][0], GOLD["headlc.stage_in_boxes"][1]], 0).copy())
+    prop = torch.from_numpy(np.concatenate([GOLD["headlc.stage_in_prop"][0], GOLD["headlc.stage_in_prop"][1]], 0).copy())
+    stage = hd.head_series_lidar[0]
+    with torch.no_grad():
+        conv = lambda fs: [hd.img_convs[i](f.to(dev).flatten(0, 1)).unflatten(0, (f.shape[0], N_CAM)) for i, f in enumerate(fs)]
+        im_dev = conv(imf2)
+        pf_dev = [f.to(dev) for f in pf2]
+        lg, pred, _ = stage(im_dev, pf_dev, bx.clone().to(dev), prop.to(dev), hd.roi_extractor_lidar, metas2,
+                            pooler_img=hd.roi_extractor_img)
+    # sample 1 under the reference indexing reads
+    # cameras of BOTH samples, so it differs from its stand-alone result; the corrected indexing restores equality
+    with torch.no_grad():
+        alone = stage([f[1:2] for f in im_dev], [f[1:2] for f in pf_dev], bx[1:2].clone().to(dev), prop[1:2].to(dev),
+                      hd.roi_extractor_lidar, metas2[1:], pooler_img=hd.roi_extractor_img)[1]
+        stage.corrected_cam_indexing = True
+        fixed = stage(im_dev, pf_dev, bx.clone().to(dev), prop.to(dev), hd.roi_extractor_lidar, metas2,
+                      pooler_img=hd.roi_extractor_img)[1]
+    assert (pred[1] - alone[0]).abs().max().item() > 1e-3
+    torch.testing.assert_close(fixed[1], alone[0], rtol=0, atol=1e-4)

@@ -122,3 +122,49 @@ def test_dynamic_voxel_configs_against_oracle(name, sweep, npts, np_, dev):
     out = res[0]["pts_bbox"] if "pts_bbox" in res[0] else res[0]
     assert set(out.keys()) == {"boxes_3d", "scores_3d", "labels_3d"}
     assert out["boxes_3d"].tensor.shape[1] == (7 if "kitti" in name or "waymo" in name else 9)
+
+
+def test_batch_of_two_frames(setup, dev):
+    """bs = 2: per-sample voxelization with batch ids, one sparse encoder pass over both samples, per-sample attention."""
+    cpu, gpu, pts = setup
+    frames = [pts, S.nuscenes_sweep(2001, 20000)]
+    vf, coors = pipeline.voxel_features(cpu, frames)
+    bev_ref = pipeline.sparse_encoder(cpu.pts_middle_encoder, vf, coors, 2)
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes), dict(box_type_3d=LiDARInstance3DBoxes)]
+    rec = []
+    hooks = [st.register_forward_pre_hook(lambda m, a: rec.append((a[1].detach().clone().cpu().numpy(),
+                                                                  a[2].detach().clone().cpu().numpy().reshape(2, 200, -1))))
+             for st in gpu.bbox_head.head_series_lidar]
+    with torch.no_grad():
+        bev = gpu.extract_bev([torch.from_numpy(f).to(dev) for f in frames])
+        assert np.array_equal(bev.cpu().numpy(), bev_ref)
+        feats = gpu.pts_neck(gpu.pts_backbone(bev))
+        logits, boxes = gpu.bbox_head(None, feats, metas)
+        res = gpu.forward(return_loss=False, points=[[torch.from_numpy(f).to(dev) for f in frames]], img_metas=[metas])
+    for h in hooks:
+        h.remove()
+    assert boxes.shape == (5, 2, 200, 10) and len(res) == 2
+    ref_logits, ref_boxes = pipeline.head_forward(cpu.bbox_head, None, [f.cpu() for f in feats], metas, stage_inputs=rec)
+    np.testing.assert_allclose(boxes.cpu().numpy(), ref_boxes.numpy(), rtol=0, atol=1e-4)
+    # each sample of the batch equals the same frame run alone (the first stages are tight; see test_oracle_pinned)
+    with torch.no_grad():
+        l1, b1 = gpu.bbox_head(None, [f[1:2].contiguous() for f in feats], metas[1:])
+    np.testing.assert_allclose(boxes[0, 1].cpu().numpy(), b1[0, 0].cpu().numpy(), rtol=0, atol=1e-4)
+
+
+def test_checkpoint_round_trip(setup, dev):
+    cpu, gpu, pts = setup
+    import io
+    buf = io.BytesIO()
+    torch.save({"state_dict": gpu.state_dict()}, buf)
+    buf.seek(0)
+    sd = torch.load(buf, weights_only=True)["state_dict"]
+    fresh = workloads.build("srfdet_voxel_nusc_L", 200).eval().to(dev)
+    missing, unexpected = fresh.load_state_dict(sd, strict=True)
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes)]
+    p = torch.from_numpy(pts).to(dev)
+    with torch.no_grad():
+        a = gpu.simple_test(None, [p], metas)[0]["pts_bbox"]
+        b = fresh.simple_test(None, [p], metas)[0]["pts_bbox"]
+    assert torch.equal(a["labels_3d"], b["labels_3d"])
+    torch.testing.assert_close(a["boxes_3d"].tensor, b["boxes_3d"].tensor, rtol=0, atol=1e-4)
