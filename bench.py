@@ -32,6 +32,11 @@ WORKLOADS = {
                    "grid 1472x1472x41, end-to-end incl. NMS"),
     "nusc_LC": dict(cfg="srfdet_voxel_nusc_LC", desc="srfdet_voxel_nusc_LC inference (LiDAR + 6 cameras), synthetic 30k-pt "
                     "sweep + 6x928x1600 images, end-to-end incl. NMS"),
+    "waymo_L": dict(cfg="srfdet_dvoxel_waymo_L", desc="srfdet_dvoxel_waymo_L inference, synthetic 180k-pt sweep, dynamic "
+                    "voxelization, grid 1536x1536x41, end-to-end incl. NMS", sweep="waymo_sweep", seed=5000, points=180000),
+    "kitti_L": dict(cfg="srfdet_voxel_kitti_L", desc="srfdet_voxel_kitti_L inference, synthetic 17k-pt front-view sweep, "
+                    "dynamic voxelization, grid 1408x1600x41, end-to-end incl. NMS", sweep="kitti_sweep", seed=1000,
+                    points=17000),
 }
 
 
@@ -85,7 +90,9 @@ def main():
 
     # a small pool of distinct frames, resident in HBM before the timed region; rank r starts at frame r
     n_pool = 8
-    frames = [torch.from_numpy(synthetic.nuscenes_sweep(2000 + i)).to(dev) for i in range(n_pool)]
+    sweep = getattr(synthetic, wl.get("sweep", "nuscenes_sweep"))
+    n_points = wl.get("points", 30000)
+    frames = [torch.from_numpy(sweep(wl.get("seed", 2000) + i, n_points)).to(dev) for i in range(n_pool)]
     metas = [dict(box_type_3d=LiDARInstance3DBoxes)]
     img = None
     if model.use_img:
@@ -160,12 +167,12 @@ def main():
                                 sample=f"{nfr} frame(s) of the same workload through oracle/pipeline.py "
                                        f"(C/OpenMP operators + torch-CPU dense layers), {dt:.1f} s")
         total_frames = args.steps * world
-        out = dict(metric=f"frames/sec, {wl['cfg']} synthetic 30k-pt sweeps", value=round(total_frames / elapsed, 3),
+        out = dict(metric=f"frames/sec, {wl['cfg']} synthetic {n_points // 1000}k-pt sweeps", value=round(total_frames / elapsed, 3),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="f32" if args.img_dtype == "fp32" else f"f32 (image branch {args.img_dtype})",
                    data="synthetic",
-                   config=dict(workload=wl["desc"], num_proposals=args.np, points_per_frame=30000,
+                   config=dict(workload=wl["desc"], num_proposals=args.np, points_per_frame=n_points,
                                frames_per_rank=args.steps, hip_graph_tail=not args.eager, weights="seeded random init, randomised BN statistics",
                                parallelism=f"replica per GPU x{world}, frames sharded, no data-path collective"),
                    roofline=roofline, cpu_baseline=cpu_baseline)

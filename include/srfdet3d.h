@@ -161,6 +161,14 @@ int srf_roi_extract(const srf_featmap *levels /*host[num_levels]*/, int num_leve
                     int64_t out_stride_c, int64_t out_stride_bin, int accumulate, int *levels_out /* R or NULL */,
                     srf_stream_t stream);
 
+/* Backward of srf_roi_extract with respect to the feature maps (training of the image branch; RoIs carry no
+ * gradient, as in mmcv's roi_align_backward).  grad_levels[i] has the layout of levels[i] and must be zeroed by
+ * the caller; grad_out has the strides given. */
+int srf_roi_extract_bwd(const srf_featmap *levels /*host*/, float *const *grad_levels /*host array of device ptrs*/,
+                        int num_levels, int C, const float *rois, int R, int pooled, int sampling_ratio,
+                        float finest_scale, const float *grad_out, int64_t out_stride_r, int64_t out_stride_c,
+                        int64_t out_stride_bin, srf_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * a11-a13  proposal box -> RoI geometry, fused.
  * Replaces the torch op chains of points_feats_sampling_bboxes_roi (srfdet_head.py:1638-1683 / :2579-2624)
@@ -207,6 +215,9 @@ int srf_apply_deltas(const float *deltas, const float *boxes, int R, int Dd, con
  * boxes: (n,5) [cx, cy, w, h, angle(rad)] already sorted by descending score; keep[i] = 1 if box i survives
  * greedy suppression at IoU > iou_threshold.  n <= 4096.
  * ------------------------------------------------------------------------------------------------------- */
+/* K9 pairwise rotated BEV IoU (n x m), boxes (cx, cy, w, h, angle): mmcv box_iou_rotated under mmdet3d
+ * BboxOverlaps3D, used by OTAssignerSRFDet (mmdet3d_plugin/core/bbox/assigners/ota_srfdet.py:148-150). */
+int srf_box_iou_rotated(const float *boxes_a, int n, const float *boxes_b, int m, float *iou, srf_stream_t stream);
 size_t srf_nms_rotated_workspace_bytes(int n);
 int srf_nms_rotated(const float *boxes, int n, float iou_threshold, int *keep, void *workspace, size_t workspace_bytes,
                     srf_stream_t stream);

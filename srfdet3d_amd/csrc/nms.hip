@@ -128,6 +128,27 @@ __global__ __launch_bounds__(64) void srf_nms_reduce_k(const unsigned long long 
     }
 }
 
+// pairwise rotated BEV IoU, (n x m): K9 of SURVEY.md (mmcv box_iou_rotated under mmdet3d BboxOverlaps3D), used by the
+// OTA label assignment at mmdet3d_plugin/core/bbox/assigners/ota_srfdet.py:148-150 (training only)
+__global__ __launch_bounds__(256) void srf_iou_rotated_k(const float *__restrict__ a, int n, const float *__restrict__ b, int m,
+                                                       float *__restrict__ out)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)n * m) return;
+    out[t] = srf_rotated_iou(a + (t / m) * 5, b + (t % m) * 5);
+}
+
+extern "C" int srf_box_iou_rotated(const float *boxes_a, int n, const float *boxes_b, int m, float *iou, srf_stream_t stream)
+{
+    if (n < 0 || m < 0) return SRF_EINVAL;
+    if (n == 0 || m == 0) return SRF_OK;
+    if (!boxes_a || !boxes_b || !iou) return SRF_EINVAL;
+    hipLaunchKernelGGL(srf_iou_rotated_k, dim3(srf_ceil_div((long long)n * m, 256)), dim3(256), 0, (hipStream_t)stream, boxes_a, n,
+                       boxes_b, m, iou);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
 extern "C" size_t srf_nms_rotated_workspace_bytes(int n)
 {
     if (n <= 0) return 0;

@@ -147,6 +147,123 @@ extern "C" int srf_roi_extract(const srf_featmap *levels, int num_levels, int C,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// backward of the gather w.r.t. the feature maps (training of the image branch: tools/train.py freezes the LiDAR
+// branch but VoVNet stages 3-5, the image FPN and img_convs receive gradients through RoIAlign).  Same geometry as
+// the forward kernel; every tap adds weight * grad / count into its map with a float atomic (the order of the adds,
+// and therefore the last bits of the gradient, is not deterministic -- the same holds for the reference's mmcv op).
+// RoIs carry no gradient, as in mmcv.
+// ---------------------------------------------------------------------------------------------------------------------
+struct RoiGradLevels {
+    float *grad[SRF_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(128) void srf_roi_extract_bwd_k(RoiLevels L, RoiGradLevels G, int C, const float *__restrict__ rois,
+                                                           int R, int pooled, int sr, float finest_scale,
+                                                           const float *__restrict__ gout, long long so_r, long long so_c,
+                                                           long long so_b)
+{
+    __shared__ long long s_off[SRF_MAX_POOLED * SRF_MAX_SR * SRF_MAX_SR][4];
+    __shared__ float s_w[SRF_MAX_POOLED * SRF_MAX_SR * SRF_MAX_SR][4];
+    __shared__ int s_lvl;
+    const int r = blockIdx.x, ph = blockIdx.y;
+    const float *b = rois + (size_t)r * 5;
+    if (threadIdx.x == 0) s_lvl = srf_roi_level(b, L.num, finest_scale);
+    __syncthreads();
+    const srf_featmap f = L.lv[s_lvl];
+    float *gmap = G.grad[s_lvl];
+    const int n = (int)b[0];
+    const int nsamp = pooled * sr * sr;
+    const bool valid_n = n >= 0 && n < f.N;
+    if (threadIdx.x < nsamp) {
+        const int pw = threadIdx.x / (sr * sr), iy = (threadIdx.x / sr) % sr, ix = threadIdx.x % sr;
+        const float x1 = __fsub_rn(__fmul_rn(b[1], f.spatial_scale), 0.5f), y1 = __fsub_rn(__fmul_rn(b[2], f.spatial_scale), 0.5f);
+        const float x2 = __fsub_rn(__fmul_rn(b[3], f.spatial_scale), 0.5f), y2 = __fsub_rn(__fmul_rn(b[4], f.spatial_scale), 0.5f);
+        const float bin_h = __fdiv_rn(__fsub_rn(y2, y1), (float)pooled), bin_w = __fdiv_rn(__fsub_rn(x2, x1), (float)pooled);
+        float y = __fadd_rn(__fadd_rn(y1, __fmul_rn((float)ph, bin_h)),
+                            __fdiv_rn(__fmul_rn(__fadd_rn((float)iy, 0.5f), bin_h), (float)sr));
+        float x = __fadd_rn(__fadd_rn(x1, __fmul_rn((float)pw, bin_w)),
+                            __fdiv_rn(__fmul_rn(__fadd_rn((float)ix, 0.5f), bin_w), (float)sr));
+        float w1 = 0.f, w2 = 0.f, w3 = 0.f, w4 = 0.f;
+        long long o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+        const int H = f.H, W = f.W;
+        if (valid_n && !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) && (y == y) && (x == x)) {
+            if (y <= 0.0f) y = 0.0f;
+            if (x <= 0.0f) x = 0.0f;
+            int y_low = (int)y, x_low = (int)x, y_high, x_high;
+            if (y_low >= H - 1) {
+                y_high = y_low = H - 1;
+                y = (float)y_low;
+            } else
+                y_high = y_low + 1;
+            if (x_low >= W - 1) {
+                x_high = x_low = W - 1;
+                x = (float)x_low;
+            } else
+                x_high = x_low + 1;
+            const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.0f - ly, hx = 1.0f - lx;
+            w1 = hy * hx;
+            w2 = hy * lx;
+            w3 = ly * hx;
+            w4 = ly * lx;
+            const long long base = (long long)n * f.stride_n;
+            o1 = base + y_low * f.stride_h + x_low * f.stride_w;
+            o2 = base + y_low * f.stride_h + x_high * f.stride_w;
+            o3 = base + y_high * f.stride_h + x_low * f.stride_w;
+            o4 = base + y_high * f.stride_h + x_high * f.stride_w;
+        }
+        s_off[threadIdx.x][0] = o1;
+        s_off[threadIdx.x][1] = o2;
+        s_off[threadIdx.x][2] = o3;
+        s_off[threadIdx.x][3] = o4;
+        s_w[threadIdx.x][0] = w1;
+        s_w[threadIdx.x][1] = w2;
+        s_w[threadIdx.x][2] = w3;
+        s_w[threadIdx.x][3] = w4;
+    }
+    __syncthreads();
+    const float inv = 1.0f / (float)(sr * sr);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float *plane = gmap + (long long)c * f.stride_c;
+        for (int pw = 0; pw < pooled; ++pw) {
+            const float g = gout[(long long)r * so_r + (long long)c * so_c + (long long)(ph * pooled + pw) * so_b] * inv;
+            for (int s = 0; s < sr * sr; ++s) {
+                const int q = pw * sr * sr + s;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (s_w[q][t] != 0.f) atomicAdd(plane + s_off[q][t], s_w[q][t] * g);
+            }
+        }
+    }
+}
+
+extern "C" int srf_roi_extract_bwd(const srf_featmap *levels, float *const *grad_levels, int num_levels, int C,
+                                   const float *rois, int R, int pooled, int sampling_ratio, float finest_scale,
+                                   const float *grad_out, int64_t out_stride_r, int64_t out_stride_c, int64_t out_stride_bin,
+                                   srf_stream_t stream)
+{
+    if (!levels || !grad_levels || num_levels <= 0 || num_levels > SRF_MAX_LEVELS || C <= 0 || R < 0 || pooled <= 0 ||
+        pooled > SRF_MAX_POOLED || sampling_ratio <= 0 || sampling_ratio > SRF_MAX_SR || !(finest_scale > 0.0f))
+        return SRF_EINVAL;
+    if (pooled * sampling_ratio * sampling_ratio > 128) return SRF_EINVAL;
+    if (R == 0) return SRF_OK;
+    if (!rois || !grad_out) return SRF_EINVAL;
+    RoiLevels L;
+    RoiGradLevels G;
+    L.num = num_levels;
+    for (int i = 0; i < SRF_MAX_LEVELS; ++i) {
+        const int j = i < num_levels ? i : 0;
+        if (!grad_levels[j] || levels[j].N <= 0) return SRF_EINVAL;
+        L.lv[i] = levels[j];
+        G.grad[i] = grad_levels[j];
+    }
+    hipLaunchKernelGGL(srf_roi_extract_bwd_k, dim3(R, pooled), dim3(128), 0, (hipStream_t)stream, L, G, C, rois, R, pooled,
+                       sampling_ratio, finest_scale, grad_out, (long long)out_stride_r, (long long)out_stride_c,
+                       (long long)out_stride_bin);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // proposal box -> BEV RoI and per-camera image RoIs, one thread per (sample, proposal)
 // ---------------------------------------------------------------------------------------------------------------------
 struct BoxGeom {

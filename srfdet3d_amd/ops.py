@@ -380,3 +380,44 @@ def apply_deltas(deltas, boxes, weights6, pc_range, scale_clamp):
     check(_lib.lib().srf_apply_deltas(_ptr(deltas), _ptr(boxes), R, Dd, hf(weights6), hf(pc_range), float(scale_clamp),
                                       _ptr(out), _stream()), "apply_deltas")
     return out
+
+
+# ---------------------------------------------------------------------------------------------- training support
+class _RoIExtractFn(torch.autograd.Function):
+    """roi_extract with a gradient for the feature maps (RoIs carry none, as in mmcv)."""
+
+    @staticmethod
+    def forward(ctx, rois, strides, out_size, sampling_ratio, finest_scale, bin_major, *feats):
+        out = roi_extract(list(feats), rois, strides, out_size, sampling_ratio, finest_scale, bin_major=bin_major)
+        ctx.save_for_backward(rois, *feats)
+        ctx.cfg = (strides, out_size, sampling_ratio, finest_scale, bin_major)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        rois, *feats = ctx.saved_tensors
+        strides, out_size, sampling_ratio, finest_scale, bin_major = ctx.cfg
+        grad_out = grad_out.contiguous()
+        R, C, nl = rois.shape[0], feats[0].shape[1], len(strides)
+        grads = [torch.zeros_like(f) for f in feats]
+        fm = (FeatMap * nl)(*[_featmap(f, 1.0 / s) for f, s in zip(feats, strides)])
+        gp = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in grads])
+        bins = out_size * out_size
+        so_c, so_b = (1, C) if bin_major else (bins, 1)
+        check(_lib.lib().srf_roi_extract_bwd(fm, gp, nl, C, _ptr(rois), R, out_size, sampling_ratio, float(finest_scale),
+                                             _ptr(grad_out), C * bins, so_c, so_b, _stream()), "roi_extract_bwd")
+        return (None, None, None, None, None, None, *grads)
+
+
+def roi_extract_autograd(feats, rois, strides, out_size=7, sampling_ratio=2, finest_scale=56.0, bin_major=False):
+    feats = [f if f.is_contiguous() or f.is_contiguous(memory_format=torch.channels_last) else f.contiguous() for f in feats]
+    return _RoIExtractFn.apply(rois.detach(), list(strides), out_size, sampling_ratio, finest_scale, bin_major, *feats)
+
+
+def box_iou_rotated(a, b):
+    """pairwise rotated BEV IoU: a (n,5), b (m,5) as (cx, cy, w, h, angle) -> (n, m)."""
+    a = _dev(a, "a", torch.float32)
+    b = _dev(b, "b", torch.float32)
+    out = _empty((a.shape[0], b.shape[0]), torch.float32, a.device)
+    check(_lib.lib().srf_box_iou_rotated(_ptr(a), a.shape[0], _ptr(b), b.shape[0], _ptr(out), _stream()), "box_iou_rotated")
+    return out

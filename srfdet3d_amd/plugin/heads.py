@@ -138,11 +138,32 @@ class _StageBase(BaseModule):
     def _gather(self, feats, rois, pooler):
         """RoI features as (R, S, C).  The fused path asks the extractor for that layout directly."""
         if isinstance(pooler, SingleRoIExtractor):
-            out = pooler(_channels_last(feats[:pooler.num_inputs]), rois, bin_major=True)
+            lv = feats[:pooler.num_inputs]
+            if torch.is_grad_enabled() and any(f.requires_grad for f in lv):
+                layer = pooler.roi_layers[0]
+                return ops.roi_extract_autograd(lv, rois, pooler.featmap_strides, layer.output_size, layer.sampling_ratio,
+                                                float(pooler.finest_scale), bin_major=True)
+            out = pooler(_channels_last(lv), rois, bin_major=True)
         else:  # any object with the mmdet call surface (feats, rois) -> (R, C, 7, 7)
             out = pooler(feats[:pooler.num_inputs], rois)
             out = out.flatten(2).permute(0, 2, 1).contiguous()
         return out
+
+    def _geometry(self, bboxes, want_bev, l2i):
+        """RoIs of the proposals and the boxes with centres in metres.  Inference overwrites the caller's tensor in place
+        like the reference (srfdet_head.py:1646); when autograd is recording, the kernel runs on a detached copy (RoIs
+        carry no gradient) and the metres are formed by differentiable torch ops instead."""
+        if torch.is_grad_enabled() and bboxes.requires_grad:
+            rois_bev, rois_img = ops.box_rois(bboxes.detach().clone().contiguous(), self.pc_range_lidar, self.voxel_size_lidar,
+                                              mutate_centres=False, want_bev=want_bev, lidar2img=l2i)
+            r = self.pc_range_lidar
+            ctr = bboxes[..., :3] * _const([r[3] - r[0], r[4] - r[1], r[5] - r[2]], bboxes) + _const(r[:3], bboxes)
+            return torch.cat([ctr, bboxes[..., 3:]], dim=-1), rois_bev, rois_img
+        if not bboxes.is_contiguous():
+            raise RuntimeError("srfdet3d_amd: proposal boxes must be contiguous (their centres are rewritten in place)")
+        rois_bev, rois_img = ops.box_rois(bboxes, self.pc_range_lidar, self.voxel_size_lidar, mutate_centres=True,
+                                          want_bev=want_bev, lidar2img=l2i)
+        return bboxes, rois_bev, rois_img
 
     def points_feats_sampling_bboxes_roi(self, points_feats, bboxes, pooler, img_metas=None):
         """BEV RoI features of each proposal, (bs*n_p, C, 7, 7); overwrites bboxes[..., :3] with metres in place
@@ -269,7 +290,7 @@ class SingleSRFDetHeadLiDAR(_StageBase):
         """(bs,n_p,D) boxes with normalised centres -> (logits (bs,n_p,#cls), boxes (bs,n_p,D), obj (1,bs*n_p,C)).
         `bboxes[..., :3]` is overwritten with metres, as in the reference."""
         bs, n_p = bboxes.shape[:2]
-        rois, _ = ops.box_rois(bboxes, self.pc_range_lidar, self.voxel_size_lidar, mutate_centres=True)
+        bboxes, rois, _ = self._geometry(bboxes, True, None)
         roi_feats = self._gather(point_feats, rois, pooler)
         return self._refine(roi_feats, bboxes, prop_feats, bs, n_p)
 
@@ -282,8 +303,7 @@ class SingleSRFDetHead(_StageBase):
     def forward(self, img_feats, point_feats, bboxes, prop_feats, pooler, img_metas, pooler_img=None):
         bs, n_p = bboxes.shape[:2]
         l2i = self._lidar2img(img_metas, bboxes) if img_feats is not None else None
-        rois_bev, rois_img = ops.box_rois(bboxes, self.pc_range_lidar, self.voxel_size_lidar, mutate_centres=True,
-                                          want_bev=point_feats is not None, lidar2img=l2i)
+        bboxes, rois_bev, rois_img = self._geometry(bboxes, point_feats is not None, l2i)
         img_roi = self._img_rois_feats(img_feats, rois_img, pooler_img, bs, n_p, l2i.shape[1]) \
             if img_feats is not None else None
         pts_roi = self._gather(point_feats, rois_bev, pooler) if point_feats is not None else None
@@ -488,6 +508,56 @@ class SRFDetHead(BaseModule):
             logits_all, boxes_all = logits[None], pred[None].clone()
         boxes_all[..., :3] = boxes_all[..., :3] * ext + lo
         return logits_all, boxes_all
+
+    # ---- training (srfdet_head.py:322-377, :1041-1201) ----------------------------------------------------------
+    def forward_train(self, img_feats, point_feats, gt_bboxes, gt_labels, gt_bboxes_ignore=None, img_metas=None,
+                      proposal_cfg=None, **kwargs):
+        assert proposal_cfg is None and self.assigner is not None and self.loss_cls is not None
+        logits, boxes = self(img_feats, point_feats, img_metas)
+        out = dict(pred_logits=logits[-1], pred_boxes=boxes[-1])
+        if self.deep_supervision:
+            out["aux_outputs"] = [dict(pred_logits=a, pred_boxes=b) for a, b in zip(logits[:-1], boxes[:-1])]
+        return self.loss_ota(out, gt_bboxes, gt_labels)
+
+    def loss_ota(self, outputs, gt_bboxes_list, gt_labels_list):
+        dev = gt_labels_list[0].device
+        gts = [torch.cat((g.gravity_center, g.tensor[:, 3:]), dim=1).to(dev) for g in gt_bboxes_list]
+        losses = {}
+        layers = [(outputs, self.num_heads, "")] + [(aux, i + 1, f"s.{i}.") for i, aux in enumerate(outputs.get("aux_outputs", []))]
+        for out, head_idx, prefix in layers:
+            idx = self.assigner(out, gts, gt_labels_list, head_idx)
+            losses[prefix + "loss_cls"] = self.loss_classification(out, gt_labels_list, idx)
+            losses[prefix + "loss_bbox"] = self.loss_boxes(out, gts, idx)
+        return losses
+
+    def loss_classification(self, outputs, gt_labels_list, indices):
+        from .training import reduce_mean
+        logits = outputs["pred_logits"]
+        target = torch.full(logits.shape[:2], self.num_classes, dtype=torch.int64, device=logits.device)
+        n = 0
+        for b, (labels, (fg, j)) in enumerate(zip(gt_labels_list, indices)):
+            target[b, fg] = labels[j]
+            n += int(j.numel())
+        num = logits.new_tensor([float(n)])
+        if self.sync_cls_avg_factor:
+            num = reduce_mean(num)
+        loss = self.loss_cls(logits.flatten(0, 1), target.flatten(0, 1)) / num.clamp(min=1).item()
+        return torch.nan_to_num(loss)
+
+    def loss_boxes(self, outputs, gt_bboxes_list, indices):
+        from .bbox_util import normalize_bbox
+        from .training import reduce_mean
+        pred = outputs["pred_boxes"]
+        p = torch.cat([pred[b, fg] for b, (fg, _) in enumerate(indices)])
+        t = torch.cat([g[j] for g, (_, j) in zip(gt_bboxes_list, indices)])
+        if len(p) == 0:
+            return torch.nan_to_num(pred.sum() * 0)
+        num = torch.clamp(reduce_mean(p.new_tensor([float(p.shape[0])])), min=1).item()
+        tn = normalize_bbox(t, self.pc_range)
+        ok = torch.isfinite(tn).all(dim=-1)
+        D = self.code_weights.numel()
+        w = torch.ones_like(p) * self.code_weights
+        return torch.nan_to_num(self.loss_bbox(p[ok, :D], tn[ok, :D], w[ok, :D]) / num)
 
     def simple_test_bboxes(self, img_feats, point_feats, img_metas):
         logits, boxes = self(img_feats, point_feats, img_metas)

@@ -1,0 +1,186 @@
+"""Training-side checks: gradient of the RoI gather, 3-D IoU, OTA assignment invariants, one
+LiDAR+camera training step with the LiDAR branch frozen as tools/train.py:221-276 does, and a 2-rank DDP step."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from srfdet3d_amd import ops, synthetic as S, workloads
+from srfdet3d_amd.compat.boxes import LiDARInstance3DBoxes
+from srfdet3d_amd.plugin import training
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_roi_align(feat, rois, scale, P=7, sr=2):
+    """differentiable restatement of RoIAlign(avg, aligned) in torch ops (double precision) for gradient checking."""
+    N, C, H, W = feat.shape
+    out = []
+    for r in rois:
+        n = int(r[0])
+        x1, y1, x2, y2 = [r[i] * scale - 0.5 for i in range(1, 5)]
+        bw, bh = (x2 - x1) / P, (y2 - y1) / P
+        idx = torch.arange(P * sr, dtype=feat.dtype, device=feat.device)
+        ys = y1 + (idx // sr) * bh + ((idx % sr) + 0.5) * bh / sr
+        xs = x1 + (idx // sr) * bw + ((idx % sr) + 0.5) * bw / sr
+        yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+        valid = ~((yy < -1) | (yy > H) | (xx < -1) | (xx > W))
+        yy, xx = yy.clamp(min=0), xx.clamp(min=0)
+        y0, x0 = yy.floor().long().clamp(max=H - 1), xx.floor().long().clamp(max=W - 1)
+        y1i, x1i = (y0 + 1).clamp(max=H - 1), (x0 + 1).clamp(max=W - 1)
+        yy = torch.where(y0 >= H - 1, y0.to(feat.dtype), yy)
+        xx = torch.where(x0 >= W - 1, x0.to(feat.dtype), xx)
+        ly, lx = yy - y0, xx - x0
+        f = feat[n]
+        v = ((1 - ly) * (1 - lx) * f[:, y0, x0] + (1 - ly) * lx * f[:, y0, x1i] + ly * (1 - lx) * f[:, y1i, x0] + ly * lx * f[:, y1i, x1i])
+        v = v * valid
+        out.append(v.view(C, P, sr, P, sr).mean(dim=(2, 4)))
+    return torch.stack(out)
+
+
+def test_roi_extract_backward_matches_autograd(dev):
+    g = torch.Generator().manual_seed(0)
+    feats = [torch.randn(2, 6, s, s + 2, generator=g) for s in (24, 12, 6, 3)]
+    rois = torch.tensor([[0, 10.3, 20.1, 80.7, 90.2], [1, -5, -8, 30, 25], [0, 40, 30, 170, 150], [1, 2, 3, 190, 185],
+                         [0, 150, 150, 151, 152]], dtype=torch.float32)
+    strides = [8, 16, 32, 64]
+    lv = ops.roi_extract([f.to(dev) for f in feats], rois.to(dev), strides, return_levels=True)[1].cpu().tolist()
+    assert len(set(lv)) >= 2
+    w = torch.randn(5, 6, 7, 7, generator=g)
+    fd = [f.double().requires_grad_(True) for f in feats]
+    ref = torch.stack([_torch_roi_align(fd[l], rois[i:i + 1].double(), 1.0 / strides[l])[0] for i, l in enumerate(lv)])
+    (ref * w.double()).sum().backward()
+    for layout in ("nchw", "cl"):
+        fg = [f.to(dev).requires_grad_(True) for f in feats]
+        fin = [f.contiguous(memory_format=torch.channels_last) for f in fg] if layout == "cl" else fg
+        out = ops.roi_extract_autograd(fin, rois.to(dev), strides)
+        torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-5)
+        (out * w.to(dev)).sum().backward()
+        for a, b in zip(fg, fd):
+            want = b.grad if b.grad is not None else torch.zeros_like(b)  # a level no RoI maps to gets a zero gradient
+            torch.testing.assert_close(a.grad.cpu().double(), want, rtol=1e-4, atol=1e-5)
+
+
+def test_iou3d_against_axis_aligned_cases(dev):
+    a = torch.tensor([[0, 0, 0, 2, 4, 1, 0.0], [0, 0, 0, 2, 4, 1, np.pi / 2], [10, 10, 0, 1, 1, 1, 0.3]], device=dev)
+    b = torch.tensor([[0, 0, 0, 2, 4, 1, 0.0], [1, 0, 0.5, 2, 4, 1, 0.0], [0, 0, 0, 4, 2, 1, 0.0]], device=dev)
+    iou = training.bbox_overlaps_3d(a, b).cpu()
+    assert abs(iou[0, 0] - 1.0) < 1e-5
+    # shifted by 1 in x and 0.5 in z: bev overlap 1x4, z overlap 0.5 -> 2 / (8 + 8 - 2)
+    assert abs(iou[0, 1] - 2.0 / 14.0) < 1e-5
+    # 2x4 rotated by 90 deg == 4x2 unrotated
+    assert abs(iou[1, 2] - 1.0) < 1e-4
+    assert iou[2].abs().max() == 0
+
+
+def _gt(dev, n=12, seed=0):
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(-40, 40, (n, 2))
+    z = rng.uniform(-2.5, -0.5, (n, 1))
+    size = rng.uniform([1.5, 3.5, 1.4], [2.2, 5.0, 2.0], (n, 3))
+    yaw = rng.uniform(-np.pi, np.pi, (n, 1))
+    vel = rng.normal(0, 1, (n, 2))
+    t = torch.tensor(np.concatenate([xy, z, size, yaw, vel], 1), dtype=torch.float32, device=dev)
+    return LiDARInstance3DBoxes(t, box_dim=9), torch.from_numpy(rng.integers(0, 10, n)).to(dev)
+
+
+def test_ota_assignment_invariants(dev):
+    m = workloads.model_cfg("srfdet_voxel_nusc_L")
+    asg = training.OTAssignerSRFDet(**{k: v for k, v in m.train_cfg.assigner.items() if k != "type"})
+    gtb, gtl = _gt(dev)
+    gts = torch.cat((gtb.gravity_center, gtb.tensor[:, 3:]), dim=1)
+    g = torch.Generator().manual_seed(1)
+    P = 300
+    pred = torch.zeros(1, P, 10)
+    pred[0, :, :3] = torch.rand(P, 3, generator=g) * torch.tensor([110.4, 110.4, 8.0]) + torch.tensor([-55.2, -55.2, -5.0])
+    pred[0, :, 3:6] = torch.log(torch.tensor([1.9, 4.2, 1.7]))
+    pred[0, :, 7] = 1.0
+    logits = torch.randn(1, P, 10, generator=g)
+    # twelve predictions sit on the ground truth (centre + 5 cm, same size and heading, confident right class)
+    pred[0, :12, :3] = gts[:, :3].cpu() + 0.05
+    pred[0, :12, 3:6] = gts[:, 3:6].cpu().log()
+    pred[0, :12, 6], pred[0, :12, 7] = gts[:, 6].cpu().sin(), gts[:, 6].cpu().cos()
+    logits[0, :12] = -4.0
+    logits[0, torch.arange(12), gtl.cpu()] = 4.0
+    out = dict(pred_boxes=pred.to(dev), pred_logits=logits.to(dev))
+    for head_idx in (1, 5):
+        fg, j = asg(out, [gts], [gtl], head_idx)[0]
+        assert fg.dtype == torch.bool and fg.sum() == j.numel() >= 12
+        assert set(j.cpu().tolist()) == set(range(12)), "every ground-truth box gets at least one prediction"
+        assert fg[:12].all(), "the predictions placed on the ground truth are selected"
+    fg, j = asg(out, [gts[:0]], [gtl[:0]], 5)[0]
+    assert fg.sum() == 0 and j.numel() == 0
+
+
+def _lc_inputs(dev, seed=0):
+    pts = torch.from_numpy(S.nuscenes_sweep(2000 + seed, 8000)).to(dev)
+    img = torch.from_numpy(S.camera_images(3000 + seed, h=128, w=224)).to(dev)
+    gtb, gtl = _gt(dev, seed=seed)
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes, lidar2img=[m for m in S.camera_rig(f=177.0, cx=112.0, cy=64.0)])]
+    return dict(img=img, points=[pts], img_metas=metas, gt_bboxes_3d=[gtb], gt_labels_3d=[gtl])
+
+
+def _lc_model(dev, P=64):
+    torch.manual_seed(0)
+    m = workloads.build("srfdet_voxel_nusc_LC", P, train=True)
+    training.freeze_lidar_components(m)
+    return m.to(dev).train()
+
+
+def test_lc_training_step(dev):
+    model = _lc_model(dev)
+    assert not model.pts_middle_encoder.training and model.bbox_head.training
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=2e-4, weight_decay=0.01)
+    losses = model(return_loss=True, **_lc_inputs(dev))
+    assert set(losses) == {"loss_cls", "loss_bbox"} | {f"s.{i}.{n}" for i in range(4) for n in ("loss_cls", "loss_bbox")}
+    total = sum(losses.values())
+    assert torch.isfinite(total)
+    total.backward()
+    named = dict(model.named_parameters())
+    for k in ("bbox_head.head_series_lidar.0.output_fused_proj.weight", "bbox_head.head_series_lidar.4.bboxes_delta_lidar.weight",
+              "bbox_head.img_convs.0.weight", "img_neck.fpn_convs.0.conv.weight", "img_backbone.stage5.OSA5_3.concat.OSA5_3_concat/conv.weight",
+              "bbox_head.dpg_fc1_img.weight", "bbox_head.init_proposal_boxes.weight"):
+        g = named[k].grad
+        assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0, k
+    assert all(p.grad is None for n, p in named.items() if n.startswith("pts_"))
+    before = named["bbox_head.head_series_lidar.0.output_fused_proj.weight"].detach().clone()
+    torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.requires_grad], 35.0)
+    opt.step()
+    assert not torch.equal(before, named["bbox_head.head_series_lidar.0.output_fused_proj.weight"])
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # two ranks share the one GPU of the box -> gloo
+    dev = torch.device("cuda:0")
+    model = _lc_model(dev, P=32)
+    ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)
+    losses = ddp(return_loss=True, **_lc_inputs(dev, seed=rank))  # each rank trains on its own frame
+    sum(losses.values()).backward()
+    g = dict(model.named_parameters())["bbox_head.head_series_lidar.0.output_fused_proj.weight"].grad
+    q.put((rank, float(sum(losses.values())), g.detach().cpu()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_average_gradients(dev):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.isfinite(res[0][1]) and np.isfinite(res[1][1]) and res[0][1] != res[1][1]  # different frames
+    torch.testing.assert_close(res[0][2], res[1][2])  # gradients all-reduced: identical on both ranks
