@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Config 4 of BASELINE.json: srfdet_voxel_nusc_LC training, bs frames per GPU, DDP over RCCL (one process per GPU).
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/train_bench.py --iters 20
+
+Synthetic frames + random ground truth; the LiDAR branch is frozen as tools/train.py:221-276
+does, so gradients (and the all-reduce) cover VoVNet stages 3-5, the image FPN and the head.  Prints iterations/s and
+the share of a step spent in backward+all-reduce on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from srfdet3d_amd import synthetic, workloads  # noqa: E402
+from srfdet3d_amd.compat.boxes import LiDARInstance3DBoxes  # noqa: E402
+from srfdet3d_amd.plugin import training  # noqa: E402
+
+
+def random_gt(dev, n, rng):
+    xy = rng.uniform(-45, 45, (n, 2))
+    z = rng.uniform(-2.5, -0.5, (n, 1))
+    size = rng.uniform([1.5, 3.5, 1.4], [2.2, 5.0, 2.0], (n, 3))
+    yaw = rng.uniform(-np.pi, np.pi, (n, 1))
+    vel = rng.normal(0, 1, (n, 2))
+    t = torch.tensor(np.concatenate([xy, z, size, yaw, vel], 1), dtype=torch.float32, device=dev)
+    return LiDARInstance3DBoxes(t, box_dim=9), torch.from_numpy(rng.integers(0, 10, n)).to(dev)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bs", type=int, default=2)
+    ap.add_argument("--np", type=int, default=900)
+    ap.add_argument("--img-hw", default="928x1600")
+    a = ap.parse_args()
+    rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    h, w = (int(v) for v in a.img_hw.split("x"))
+    torch.manual_seed(0)
+    model = workloads.build("srfdet_voxel_nusc_LC", a.np, train=True)
+    training.freeze_lidar_components(model)
+    model = model.to(dev).train()
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=True) if world > 1 else model
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.01)
+    rng = np.random.default_rng(rank)
+    scale = w / 1600.0
+    rig = synthetic.camera_rig(f=1266.0 * scale, cx=816.0 * scale, cy=491.0 * h / 928.0)
+    pts = [torch.from_numpy(synthetic.nuscenes_sweep(2000 + rank * a.bs + i)).to(dev) for i in range(a.bs)]
+    img = torch.cat([torch.from_numpy(synthetic.camera_images(3000 + rank * a.bs + i, h=h, w=w)) for i in range(a.bs)], 0).to(dev)
+    gts = [random_gt(dev, 20, rng) for _ in range(a.bs)]
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes, lidar2img=[m for m in rig]) for _ in range(a.bs)]
+
+    def step():
+        losses = net(return_loss=True, img=img, points=pts, img_metas=metas, gt_bboxes_3d=[g[0] for g in gts],
+                     gt_labels_3d=[g[1] for g in gts])
+        total = sum(losses.values())
+        opt.zero_grad(set_to_none=True)
+        total.backward()
+        torch.nn.utils.clip_grad_norm_(params, 35.0)
+        opt.step()
+        return total.item()
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        ntrain = sum(p.numel() for p in params)
+        print(json.dumps(dict(metric="training iterations/s, srfdet_voxel_nusc_LC", value=round(a.iters / dt, 3), n_gpus=world,
+                              frames_per_s=round(a.iters * a.bs * world / dt, 3), bs_per_gpu=a.bs, num_proposals=a.np,
+                              image=f"{h}x{w}", trainable_params=ntrain, grad_bytes_per_step=4 * ntrain, last_loss=round(loss, 4))))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
