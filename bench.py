@@ -68,10 +68,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # one rank per GPU; the modulo only matters for rehearsing the N > 1 path on a box with fewer GPUs than ranks
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("SRF_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only for rehearsals
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from srfdet3d_amd import ops, synthetic, workloads
     from srfdet3d_amd.compat.boxes import LiDARInstance3DBoxes
@@ -122,7 +128,7 @@ def main():
     records = ops.KERNEL_TIMING["spconv"]
     ops.KERNEL_TIMING = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
