@@ -100,11 +100,16 @@ def install_stand_ins():
     mod("mmcv")
     mod("mmcv.runner", force_fp32=_identity_decorator_factory, auto_fp16=_identity_decorator_factory,
         BaseModule=_BaseModule, ModuleList=nn.ModuleList)
-    mod("mmcv.cnn", build_activation_layer=lambda cfg: nn.ReLU(inplace=cfg.get("inplace", False)),
+    def _build_norm_layer(cfg, n):
+        assert cfg["type"] == "BN1d"
+        return "bn", nn.BatchNorm1d(n, eps=cfg.get("eps", 1e-5), momentum=cfg.get("momentum", 0.1))
+
+    mod("mmcv.cnn", build_norm_layer=_build_norm_layer, build_activation_layer=lambda cfg: nn.ReLU(inplace=cfg.get("inplace", False)),
         ConvModule=_conv_module, build_conv_layer=_raiser("build_conv_layer"))
     mod("mmcv.cnn.bricks")
     mod("mmcv.cnn.bricks.transformer", build_transformer_layer_sequence=_raiser("build_transformer_layer_sequence"))
-    mod("mmcv.ops", MultiScaleDeformableAttention=type("MultiScaleDeformableAttention", (nn.Module,), {}))
+    mod("mmcv.ops", MultiScaleDeformableAttention=type("MultiScaleDeformableAttention", (nn.Module,), {}),
+        DynamicScatter=_raiser("DynamicScatter"))
     mod("mmdet")
     mod("mmdet.core", build_assigner=_raiser("build_assigner"), bbox2roi=_bbox2roi,
         multi_apply=_raiser("multi_apply"), build_sampler=_raiser("build_sampler"))
@@ -115,10 +120,12 @@ def install_stand_ins():
     mod("mmdet.models.dense_heads.base_dense_head", BaseDenseHead=_BaseModule)
     mod("mmdet3d")
     mod("mmdet3d.core", box3d_multiclass_nms=_raiser("box3d_multiclass_nms"), xywhr2xyxyr=_raiser("xywhr2xyxyr"))
+    mod("mmdet3d.models.builder", VOXEL_ENCODERS=_Registry())
     mod("mmdet3d.models", HEADS=_Registry(), build_loss=_raiser("build_loss"), build_head=_raiser("build_head"),
         build_roi_extractor=_raiser("build_roi_extractor"))
     for pkg in ("mmdet3d_plugin", "mmdet3d_plugin.core", "mmdet3d_plugin.core.bbox", "mmdet3d_plugin.models",
-                "mmdet3d_plugin.models.sparse_heads", "mmdet3d_plugin.models.backbones"):
+                "mmdet3d_plugin.models.sparse_heads", "mmdet3d_plugin.models.backbones",
+                "mmdet3d_plugin.models.voxel_encoders"):
         m = types.ModuleType(pkg)
         m.__path__ = []
         sys.modules[pkg] = m
@@ -135,6 +142,9 @@ def load_reference(ref):
     util = load("mmdet3d_plugin.core.bbox.util", "mmdet3d_plugin/core/bbox/util.py")
     head = load("mmdet3d_plugin.models.sparse_heads.srfdet_head", "mmdet3d_plugin/models/sparse_heads/srfdet_head.py")
     head.vovnet = load("mmdet3d_plugin.models.backbones.vovnet", "mmdet3d_plugin/models/backbones/vovnet.py")
+    load("mmdet3d_plugin.models.voxel_encoders.utils", "mmdet3d_plugin/models/voxel_encoders/utils.py")
+    head.pillar = load("mmdet3d_plugin.models.voxel_encoders.pillar_encoder_custom",
+                       "mmdet3d_plugin/models/voxel_encoders/pillar_encoder_custom.py")
     return util, head
 
 
@@ -357,6 +367,18 @@ def main():
     lc["headlc.rois_img"] = np.stack(hl.roi_extractor_img.rois, 0)
     lc["headlc.stage_in_boxes"] = np.stack([b for b, _ in stage_in], 0)
     lc["headlc.stage_in_prop"] = np.stack([f for _, f in stage_in], 0)
+    # ---- pillar encoder: pillar_encoder_custom.py:95-160 + utils.py:63-146 (legacy=False as the configs set it) ----
+    pfn = head.pillar.PillarFeatureNetCustom(in_channels=5, feat_channels=[64], with_distance=False, voxel_size=[0.2, 0.2, 8],
+                                             norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01),
+                                             point_cloud_range=[-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], legacy=False).eval()
+    detgen.load_det_params(pfn, "pfn.")
+    Np, Mp = 60, 20
+    num = (np.arange(Np) % Mp + 1).astype(np.int32)
+    vox = detgen.det("pfn.voxels", (Np, Mp, 5)) * (np.arange(Mp)[None, :, None] < num[:, None, None])
+    pc = np.stack([np.zeros(Np), np.zeros(Np), np.arange(Np) % 512, (np.arange(Np) * 7) % 512], 1).astype(np.int32)
+    with torch.no_grad():
+        lc["pfn.out"] = pfn(t(vox.astype(np.float32)), t(num), t(pc)).numpy()
+
     path = os.path.join(HERE, "fusion_nusc.npz")
     np.savez_compressed(path, **lc)
     print("wrote", path, {k: v.shape for k, v in lc.items()})

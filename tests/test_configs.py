@@ -12,7 +12,8 @@ from srfdet3d_amd.compat.config import Config
 
 REF = "/root/reference"
 NAMES = {"srfdet_voxel_nusc_L": "configs/nus/srfdet_voxel_nusc_L.py", "srfdet_voxel_nusc_LC": "configs/nus/srfdet_voxel_nusc_LC.py",
-         "srfdet_voxel_kitti_L": "configs/kitti/srfdet_voxel_kitti_L.py", "srfdet_dvoxel_waymo_L": "configs/waymo/srfdet_dvoxel_waymo_L.py"}
+         "srfdet_voxel_kitti_L": "configs/kitti/srfdet_voxel_kitti_L.py", "srfdet_dvoxel_waymo_L": "configs/waymo/srfdet_dvoxel_waymo_L.py",
+         "srfdet_pillar_nusc_L": "configs/nus/srfdet_pillar_nusc_L.py"}
 
 
 def _plain(o):

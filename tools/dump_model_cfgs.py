@@ -20,6 +20,7 @@ CONFIGS = {
     "srfdet_voxel_nusc_LC": "configs/nus/srfdet_voxel_nusc_LC.py",
     "srfdet_voxel_kitti_L": "configs/kitti/srfdet_voxel_kitti_L.py",
     "srfdet_dvoxel_waymo_L": "configs/waymo/srfdet_dvoxel_waymo_L.py",
+    "srfdet_pillar_nusc_L": "configs/nus/srfdet_pillar_nusc_L.py",
 }
 
 
