@@ -308,6 +308,235 @@ extern "C" int srf_linear(const float *X, int M, int K, int ldx, const float *W,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// srf_stage_tail: everything of a stage that is row-local after the DynamicConv projection, in ONE launch per 32
+// proposals (srfdet_head.py:1506-1520): FFN (C -> F -> C) + residual + LayerNorm, the classification tower (n_cls x
+// [Linear, LayerNorm, ReLU]) + class_logits, the regression tower (n_reg x [...]) + bboxes_delta + apply_deltas.
+// Activations never leave LDS (kept in the swizzled operand image); weights stream through a double-buffered slab.
+// Replaces 11 launches of srf_linear (each ~12 us of mostly latency at 200 rows) per stage.  C = 128 only.
+// ---------------------------------------------------------------------------------------------------------------------
+#define TAIL_C 128
+#define TAIL_MAX_TOWER 4
+
+struct DeltaGeomFwd {
+    float w[6], lo[3], ext[3], clamp;
+};
+
+struct TailWeights {
+    const float *w1, *b1;              // linear1: (F, C), (F)
+    const float *w2, *b2;              // linear2: (C, F), (C)
+    const float *n3_g, *n3_b;          // norm3
+    const float *cls_w[TAIL_MAX_TOWER], *cls_g[TAIL_MAX_TOWER], *cls_b[TAIL_MAX_TOWER];
+    const float *reg_w[TAIL_MAX_TOWER], *reg_g[TAIL_MAX_TOWER], *reg_b[TAIL_MAX_TOWER];
+    const float *wl, *bl;              // class_logits: (ncls, C)
+    const float *wd, *bd;              // bboxes_delta: (Dd, C)
+    float eps_n3, eps_cls[TAIL_MAX_TOWER], eps_reg[TAIL_MAX_TOWER];
+    int F, n_cls, n_reg, ncls, Dd;
+};
+
+// One weight block = 128 output rows x 128 k of a row-major (N x ldw) matrix: 16 float4 per thread, all in flight at once
+// (the chain is latency-bound: 7 workgroups, ~2 us of MFMA per block, so a block's loads are issued one block ahead).
+struct TailBlock {
+    f32x4 v[16];
+    unsigned ok;
+};
+
+__device__ __forceinline__ void srf_tail_load(TailBlock &blk, const float *__restrict__ W, int ldw, int n0, int N, int k0)
+{
+    const int tid = threadIdx.x;
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int e = tid + j * 256, n = n0 + (e >> 5);
+        blk.v[j] = *reinterpret_cast<const f32x4 *>(W + (size_t)(n < N ? n : 0) * ldw + k0 + (e & 31) * 4);
+        m |= (n < N ? 1u : 0u) << j;
+    }
+    blk.ok = m;
+}
+
+__device__ __forceinline__ void srf_tail_commit(const TailBlock &blk, float *s_w)
+{
+    const int tid = threadIdx.x;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int e = tid + j * 256, q = e & 31;
+        srf_img_store(s_w + (q >> 3) * (LIN_TN * 32), e >> 5, q & 7, ((blk.ok >> j) & 1u) ? blk.v[j] : zero);
+    }
+}
+
+// acc += src image (4 chunks of [32 rows x 32]) . s_w block (4 chunks of [128 cols x 32])^T, this wave's 32 columns
+__device__ __forceinline__ void srf_tail_mma(const float *src_img, const float *s_w, f32x16 &acc)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kh = lane >> 5, arow = lane & 31, a_swz = (arow >> 1) & 7;
+    const int bcol = wave * 32 + (lane & 31), b_swz = (bcol >> 1) & 7;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x4 af[4], bf[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            af[g] = *reinterpret_cast<const f32x4 *>(src_img + t * 1024 + arow * 32 + (((kh << 2) + g) ^ a_swz) * 4);
+            bf[g] = *reinterpret_cast<const f32x4 *>(s_w + t * (LIN_TN * 32) + bcol * 32 + (((kh << 2) + g) ^ b_swz) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j >> 2][j & 3], bf[j >> 2][j & 3], acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void srf_tail_zero(f32x16 &acc)
+{
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+}
+
+// accumulators -> s_out[32][128] (row-major tile)
+__device__ __forceinline__ void srf_tail_spill(const f32x16 &acc, float (*s_out)[LIN_TN + 4])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s_out[(j & 3) + 8 * (j >> 2) + 4 * kh][wave * 32 + (lane & 31)] = acc[j];
+}
+
+// s_out[32][0 .. 128) (row-major) -> operand image (4 chunks)
+__device__ __forceinline__ void srf_tail_to_image(float (*s_out)[LIN_TN + 4], float *img)
+{
+    const int r = threadIdx.x >> 3, q = threadIdx.x & 7;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_out[r][ch * 32 + q * 4]);
+        srf_img_store(img + ch * 1024, r, q, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict__ obj_in, int R, TailWeights tw,
+                                                      const float *__restrict__ boxes_m, DeltaGeomFwd g,
+                                                      float *__restrict__ obj_out, float *__restrict__ logits,
+                                                      float *__restrict__ pred)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *img_obj = lds;                 // 4 chunks: obj, then obj2
+    float *img_h = img_obj + 4 * 1024;    // 4 chunks: one 128-wide slice of the FFN hidden layer / tower activations
+    float *s_w = img_h + 4 * 1024;        // one weight block (4 chunks x 128 cols)
+    float(*s_out)[LIN_TN + 4] = reinterpret_cast<float(*)[LIN_TN + 4]>(s_w + 4 * LIN_TN * 32);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * 32;
+    const int C = TAIL_C, F = tw.F;
+    TailBlock blk;
+    srf_tail_load(blk, tw.w1, C, 0, F, 0);
+    {  // obj tile -> image
+        const int r = tid >> 3, q = tid & 7, row = row0 + r;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < R) v = *reinterpret_cast<const f32x4 *>(obj_in + (size_t)row * C + ch * 32 + q * 4);
+            srf_img_store(img_obj + ch * 1024, r, q, v);
+        }
+    }
+    f32x16 acc, acc2;
+    srf_tail_zero(acc2);
+    // ---- FFN, one 128-wide slice of the hidden layer at a time: h = relu(obj W1[n0:n0+128]^T + b1); acc2 += h W2[:, n0:]^T
+    for (int n0 = 0; n0 < F; n0 += LIN_TN) {
+        srf_tail_commit(blk, s_w);                 // W1 slice
+        __syncthreads();
+        srf_tail_load(blk, tw.w2, F, 0, C, n0);    // W2 k-block, in flight during the MFMAs below
+        srf_tail_zero(acc);
+        srf_tail_mma(img_obj, s_w, acc);
+        srf_tail_spill(acc, s_out);
+        __syncthreads();
+        for (int e = tid; e < 32 * LIN_TN; e += 256) {
+            const int r = e >> 7, c = e & (LIN_TN - 1);
+            const float v = s_out[r][c] + tw.b1[n0 + c];
+            s_out[r][c] = v > 0.f ? v : 0.f;
+        }
+        __syncthreads();
+        srf_tail_to_image(s_out, img_h);
+        srf_tail_commit(blk, s_w);                 // W2 k-block (all waves are past the MFMAs that read s_w)
+        __syncthreads();
+        if (n0 + LIN_TN < F) srf_tail_load(blk, tw.w1, C, n0 + LIN_TN, F, 0);
+        else if (tw.n_cls > 0) srf_tail_load(blk, tw.cls_w[0], C, 0, C, 0);
+        else srf_tail_load(blk, tw.wl, C, 0, tw.ncls, 0);
+        srf_tail_mma(img_h, s_w, acc2);
+        __syncthreads();
+    }
+    // ---- obj2 = LN3(obj + ffn + b2) ----------------------------------------------------------------------------------
+    srf_tail_spill(acc2, s_out);
+    __syncthreads();
+    {
+        RowEpilogue ep = {tw.b2, nullptr, nullptr, obj_in, tw.n3_g, tw.n3_b, C, 0, 0, 0.f, tw.eps_n3};
+        for (int r = wave * 8; r < wave * 8 + 8; ++r) {
+            const int row = row0 + r;
+            float v[2] = {s_out[r][lane], s_out[r][lane + 64]};
+            if (row < R) {
+                srf_row_epilogue<2>(v, C, lane, row, ep);
+                obj_out[(size_t)row * C + lane] = v[0];
+                obj_out[(size_t)row * C + lane + 64] = v[1];
+            } else {
+                v[0] = v[1] = 0.f;
+            }
+            s_out[r][lane] = v[0];
+            s_out[r][lane + 64] = v[1];
+        }
+    }
+    __syncthreads();
+    srf_tail_to_image(s_out, img_obj);  // img_obj now holds obj2, the input of both towers
+    // ---- towers ---------------------------------------------------------------------------------------------------------
+    for (int tower = 0; tower < 2; ++tower) {
+        const int nl = tower == 0 ? tw.n_cls : tw.n_reg;
+        const int N = tower == 0 ? tw.ncls : tw.Dd;
+        const float *src = img_obj;
+        for (int l = 0; l <= nl; ++l) {  // l == nl: the tower's output layer (class_logits / bboxes_delta)
+            srf_tail_commit(blk, s_w);
+            __syncthreads();
+            // next block: the next layer of this tower, its head, or the first block of the other tower
+            if (l + 1 < nl) srf_tail_load(blk, tower == 0 ? tw.cls_w[l + 1] : tw.reg_w[l + 1], C, 0, C, 0);
+            else if (l + 1 == nl) srf_tail_load(blk, tower == 0 ? tw.wl : tw.wd, C, 0, N, 0);
+            else if (tower == 0) {
+                if (tw.n_reg > 0) srf_tail_load(blk, tw.reg_w[0], C, 0, C, 0);
+                else srf_tail_load(blk, tw.wd, C, 0, tw.Dd, 0);
+            }
+            srf_tail_zero(acc);
+            srf_tail_mma(src, s_w, acc);
+            srf_tail_spill(acc, s_out);
+            __syncthreads();
+            if (l < nl) {
+                RowEpilogue ep = {nullptr, tower == 0 ? tw.cls_g[l] : tw.reg_g[l], tower == 0 ? tw.cls_b[l] : tw.reg_b[l], nullptr,
+                                  nullptr, nullptr, 0, 1, 0, tower == 0 ? tw.eps_cls[l] : tw.eps_reg[l], 0.f};
+                for (int r = wave * 8; r < wave * 8 + 8; ++r) {
+                    float v[2] = {s_out[r][lane], s_out[r][lane + 64]};
+                    srf_row_epilogue<2>(v, C, lane, row0 + r, ep);
+                    s_out[r][lane] = v[0];
+                    s_out[r][lane + 64] = v[1];
+                }
+                __syncthreads();
+                srf_tail_to_image(s_out, img_h);
+                src = img_h;
+            } else if (tower == 0) {
+                for (int e = tid; e < 32 * N; e += 256) {
+                    const int r = e / N, c = e % N, row = row0 + r;
+                    if (row < R) logits[(size_t)row * N + c] = s_out[r][c] + tw.bl[c];
+                }
+            } else if (tid < 32 && row0 + tid < R) {
+                const int row = row0 + tid;
+                const float *b = boxes_m + (size_t)row * N;
+                float *o = pred + (size_t)row * N;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float size = expf(b[3 + i]);
+                    const float ctr = ((s_out[tid][i] + tw.bd[i]) / g.w[i]) * size + b[i];
+                    float n = (ctr - g.lo[i]) / g.ext[i];
+                    o[i] = n < 0.f ? 0.f : (n > 1.f ? 1.f : n);
+                    float ds = (s_out[tid][3 + i] + tw.bd[3 + i]) / g.w[3 + i];
+                    ds = ds > g.clamp ? g.clamp : ds;
+                    o[3 + i] = logf(expf(ds) * size);
+                }
+                for (int i = 6; i < N; ++i) o[i] = s_out[tid][i] + tw.bd[i];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // srf_self_attention: qkv (P, 3E) rows [q | k | v] (after in_proj), heads H, head dim d = E / H (d <= 32, d % 4 == 0)
 // out (P, E) = concat_h softmax(q_h k_h^T / sqrt(d)) v_h          (nn.MultiheadAttention, batch 1; srfdet_head.py:1489)
 // One workgroup per (head, 32 queries); 8 lanes share a query and split the keys; online softmax, merged by shuffles.
@@ -577,6 +806,51 @@ __global__ __launch_bounds__(128) void srf_apply_deltas_k(const float *__restric
         o[3 + i] = logf(expf(ds) * size);
     }
     for (int i = 6; i < Dd; ++i) o[i] = d[i];
+}
+
+extern "C" int srf_stage_tail(const float *obj_in, int R, int C, int F, const float *w1, const float *b1, const float *w2,
+                              const float *b2, const float *n3_g, const float *n3_b, float n3_eps, int n_cls,
+                              const float *const *cls_w, const float *const *cls_g, const float *const *cls_b,
+                              const float *cls_eps, int n_reg, const float *const *reg_w, const float *const *reg_g,
+                              const float *const *reg_b, const float *reg_eps, const float *wl, const float *bl, int ncls,
+                              const float *wd, const float *bd, int Dd, const float *boxes_m, const float *weights6,
+                              const float *pc_range, float scale_clamp, float *obj_out, float *logits, float *pred,
+                              srf_stream_t stream)
+{
+    if (R < 0 || C != TAIL_C || F <= 0 || F % LIN_TN || F > 4 * LIN_TN || n_cls < 0 || n_cls > TAIL_MAX_TOWER || n_reg < 0 ||
+        n_reg > TAIL_MAX_TOWER || ncls <= 0 || ncls > 32 || Dd < 8 || Dd > 32)
+        return SRF_EUNSUPPORTED;
+    if (R == 0) return SRF_OK;
+    if (!obj_in || !w1 || !b1 || !w2 || !b2 || !n3_g || !n3_b || !wl || !bl || !wd || !bd || !boxes_m || !weights6 || !pc_range ||
+        !obj_out || !logits || !pred)
+        return SRF_EINVAL;
+    TailWeights tw;
+    tw.w1 = w1, tw.b1 = b1, tw.w2 = w2, tw.b2 = b2, tw.n3_g = n3_g, tw.n3_b = n3_b, tw.eps_n3 = n3_eps;
+    for (int l = 0; l < TAIL_MAX_TOWER; ++l) {
+        tw.cls_w[l] = l < n_cls ? cls_w[l] : nullptr, tw.cls_g[l] = l < n_cls ? cls_g[l] : nullptr;
+        tw.cls_b[l] = l < n_cls ? cls_b[l] : nullptr, tw.eps_cls[l] = l < n_cls ? cls_eps[l] : 0.f;
+        tw.reg_w[l] = l < n_reg ? reg_w[l] : nullptr, tw.reg_g[l] = l < n_reg ? reg_g[l] : nullptr;
+        tw.reg_b[l] = l < n_reg ? reg_b[l] : nullptr, tw.eps_reg[l] = l < n_reg ? reg_eps[l] : 0.f;
+    }
+    tw.wl = wl, tw.bl = bl, tw.wd = wd, tw.bd = bd;
+    tw.F = F, tw.n_cls = n_cls, tw.n_reg = n_reg, tw.ncls = ncls, tw.Dd = Dd;
+    DeltaGeomFwd g;
+    for (int i = 0; i < 6; ++i) g.w[i] = weights6[i];
+    for (int i = 0; i < 3; ++i) {
+        g.lo[i] = pc_range[i];
+        g.ext[i] = pc_range[3 + i] - pc_range[i];
+    }
+    g.clamp = scale_clamp;
+    const size_t sh = sizeof(float) * (4 * 1024 + 4 * 1024 + 4 * LIN_TN * 32 + 32 * (LIN_TN + 4));  // 113 KB
+    static bool attr_set = false;
+    if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
+        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_stage_tail_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(srf_stage_tail_k, dim3(srf_ceil_div(R, 32)), dim3(256), sh, (hipStream_t)stream, obj_in, R, tw, boxes_m, g,
+                       obj_out, logits, pred);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
 }
 
 extern "C" int srf_apply_deltas(const float *deltas, const float *boxes, int R, int Dd, const float *weights6,

@@ -382,6 +382,45 @@ def apply_deltas(deltas, boxes, weights6, pc_range, scale_clamp):
     return out
 
 
+def _ptr_array(tensors):
+    import ctypes
+    arr = (ctypes.c_void_p * max(len(tensors), 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def stage_tail(obj, ffn, norm3, cls_layers, reg_layers, logits_fc, deltas_fc, boxes, weights6, pc_range, scale_clamp):
+    """FFN + residual + norm3, both towers, class_logits, bboxes_delta and apply_deltas in one launch per 32 rows.
+    ffn = (linear1, linear2); cls_layers / reg_layers = [(Linear(bias=False), LayerNorm), ...].
+    Returns obj_out (R,C), logits (R,ncls), pred (R,Dd)."""
+    obj = _dev(obj, "obj", torch.float32)
+    boxes = _dev(boxes, "boxes", torch.float32)
+    R, C = obj.shape
+    lin1, lin2 = ffn
+    F = lin1.weight.shape[0]
+    ncls, Dd = logits_fc.weight.shape[0], deltas_fc.weight.shape[0]
+    if boxes.shape != (R, Dd):
+        raise ValueError("boxes must be (R, Dd)")
+    obj_out = _empty((R, C), torch.float32, obj.device)
+    logits = _empty((R, ncls), torch.float32, obj.device)
+    pred = _empty((R, Dd), torch.float32, obj.device)
+    cw, cg, cb = ([m.weight for m, _ in cls_layers], [n.weight for _, n in cls_layers], [n.bias for _, n in cls_layers])
+    rw, rg, rb = ([m.weight for m, _ in reg_layers], [n.weight for _, n in reg_layers], [n.bias for _, n in reg_layers])
+    for t in [lin1.weight, lin1.bias, lin2.weight, lin2.bias, norm3.weight, norm3.bias, logits_fc.weight, logits_fc.bias,
+              deltas_fc.weight, deltas_fc.bias] + cw + cg + cb + rw + rg + rb:
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != obj.device:
+            raise ValueError("stage_tail: parameters must be contiguous float32 on the input's device")
+    check(_lib.lib().srf_stage_tail(
+        _ptr(obj), R, C, F, _ptr(lin1.weight), _ptr(lin1.bias), _ptr(lin2.weight), _ptr(lin2.bias), _ptr(norm3.weight),
+        _ptr(norm3.bias), float(norm3.eps), len(cls_layers), _ptr_array(cw), _ptr_array(cg), _ptr_array(cb),
+        hf([n.eps for _, n in cls_layers] or [0.0]), len(reg_layers), _ptr_array(rw), _ptr_array(rg), _ptr_array(rb),
+        hf([n.eps for _, n in reg_layers] or [0.0]), _ptr(logits_fc.weight), _ptr(logits_fc.bias), ncls, _ptr(deltas_fc.weight),
+        _ptr(deltas_fc.bias), Dd, _ptr(boxes), hf(weights6), hf(pc_range), float(scale_clamp), _ptr(obj_out), _ptr(logits),
+        _ptr(pred), _stream()), "stage_tail")
+    return obj_out, logits, pred
+
+
 # ---------------------------------------------------------------------------------------------- training support
 class _RoIExtractFn(torch.autograd.Function):
     """roi_extract with a gradient for the feature maps (RoIs carry none, as in mmcv)."""

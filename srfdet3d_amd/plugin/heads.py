@@ -121,6 +121,7 @@ class _StageBase(BaseModule):
         self.bboxes_delta_lidar = nn.Linear(C, len(bbox_weights))
         self.scale_clamp = scale_clamp
         self.bbox_weights = list(bbox_weights)
+        self.fuse_stage_tail = True  # FFN + towers + deltas in one launch (ops.stage_tail) when the shapes allow
         if use_fusion:
             self.output_fused_proj = nn.Linear(2 * C, C)
         if init_cfg is None:
@@ -211,6 +212,13 @@ class _StageBase(BaseModule):
                 and (dc.feat_channels, dc.dynamic_dim) in ((128, 32), (256, 64)) and roi_feats.shape[1] <= 64
                 and isinstance(self.activation_lidar, nn.ReLU) and dc.dynamic_num == 2)
 
+    def _tail_fusable(self):
+        """srf_stage_tail covers C == 128, FFN width a multiple of 128 up to 512 and towers of at most 4 layers."""
+        F = self.linear1_lidar.weight.shape[0]
+        return (self.fuse_stage_tail and self.feat_channels_lidar == 128 and F % 128 == 0 and F <= 512
+                and len(self.cls_module_lidar) <= 12 and len(self.reg_module_lidar) <= 12
+                and self.class_logits_lidar.weight.shape[0] <= 32 and 8 <= self.bboxes_delta_lidar.weight.shape[0] <= 32)
+
     def _refine_hip(self, roi_feats, boxes_m, prop_feats, bs, n_p):
         """The stage on the hand-written kernels of csrc/decoder.hip (inference): ~20 launches instead of ~60."""
         C = self.feat_channels_lidar
@@ -228,6 +236,14 @@ class _StageBase(BaseModule):
         mid = ops.dynconv_mid(roi_feats, params, dc.norm1, dc.norm2)
         obj = ops.linear(mid.view(R, S * C), dc.out_layer.weight, dc.out_layer.bias, ln1=dc.norm3, relu1=True, residual=q1,
                          ln2=self.norm2_lidar)
+        if self._tail_fusable():
+            cls_layers = [(self.cls_module_lidar[i], self.cls_module_lidar[i + 1]) for i in range(0, len(self.cls_module_lidar), 3)]
+            reg_layers = [(self.reg_module_lidar[i], self.reg_module_lidar[i + 1]) for i in range(0, len(self.reg_module_lidar), 3)]
+            obj, logits, pred = ops.stage_tail(obj, (self.linear1_lidar, self.linear2_lidar), self.norm3_lidar, cls_layers,
+                                               reg_layers, self.class_logits_lidar, self.bboxes_delta_lidar,
+                                               boxes_m.reshape(R, -1), self.bbox_weights[:6], self.pc_range_lidar,
+                                               self.scale_clamp)
+            return logits.view(bs, n_p, -1), pred.view(bs, n_p, -1), obj.view(1, R, C)
         hid = ops.linear(obj, self.linear1_lidar.weight, self.linear1_lidar.bias, relu1=True)
         obj = ops.linear(hid, self.linear2_lidar.weight, self.linear2_lidar.bias, residual=obj, ln2=self.norm3_lidar)
         cls_f, reg_f = obj, obj

@@ -68,3 +68,56 @@ def test_dynconv_mid_matches_torch(dev, C, D):
         want = F.relu(F.layer_norm(torch.bmm(x, w2), (C,), n2.weight.double(), n2.bias.double(), n2.eps))
         got = ops.dynconv_mid(feats, params, n1, n2)
     torch.testing.assert_close(got.double(), want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("R,F_,n_cls,n_reg,ncls,Dd", [(200, 512, 2, 3, 10, 10), (900, 512, 2, 3, 10, 10), (37, 256, 1, 1, 3, 8),
+                                                      (64, 128, 4, 4, 32, 10), (1, 512, 0, 0, 10, 10)])
+def test_stage_tail_matches_per_op_chain(dev, R, F_, n_cls, n_reg, ncls, Dd):
+    """srf_stage_tail (FFN + norm3 + towers + logits + deltas + apply_deltas in one launch) against the same chain on
+    srf_linear / srf_apply_deltas, and against torch float64 (srfdet_head.py:1506-1520, :1534-1625)."""
+    C = 128
+    g = torch.Generator().manual_seed(R + F_ + n_cls)
+    nn = torch.nn
+
+    def lin(i, o, bias=True):
+        m = nn.Linear(i, o, bias=bias)
+        with torch.no_grad():
+            m.weight.copy_(torch.randn(o, i, generator=g) / i ** 0.5)
+            if bias:
+                m.bias.copy_(torch.randn(o, generator=g) * 0.1)
+        return m.to(dev)
+
+    lin1, lin2, norm3 = lin(C, F_), lin(F_, C), _ln(C, dev, g)
+    cls_layers = [(lin(C, C, False), _ln(C, dev, g)) for _ in range(n_cls)]
+    reg_layers = [(lin(C, C, False), _ln(C, dev, g)) for _ in range(n_reg)]
+    logits_fc, deltas_fc = lin(C, ncls), lin(C, Dd)
+    obj = torch.randn(R, C, generator=g).to(dev)
+    boxes = torch.cat([torch.rand(R, 3, generator=g) * 100 - 50, torch.randn(R, 3, generator=g) * 0.3 + 0.5,
+                       torch.randn(R, Dd - 6, generator=g)], 1).to(dev)
+    w6, rng, clamp = [2.0, 2.0, 2.0, 1.0, 1.0, 1.0], [-55.2, -55.2, -5.0, 55.2, 55.2, 3.0], 5.0
+    with torch.no_grad():
+        got_obj, got_logits, got_pred = ops.stage_tail(obj, (lin1, lin2), norm3, cls_layers, reg_layers, logits_fc, deltas_fc,
+                                                        boxes, w6, rng, clamp)
+        hid = ops.linear(obj, lin1.weight, lin1.bias, relu1=True)
+        o2 = ops.linear(hid, lin2.weight, lin2.bias, residual=obj, ln2=norm3)
+        cf, rf = o2, o2
+        for m, n in cls_layers:
+            cf = ops.linear(cf, m.weight, None, ln1=n, relu1=True)
+        for m, n in reg_layers:
+            rf = ops.linear(rf, m.weight, None, ln1=n, relu1=True)
+        lg = ops.linear(cf, logits_fc.weight, logits_fc.bias)
+        pr = ops.apply_deltas(ops.linear(rf, deltas_fc.weight, deltas_fc.bias), boxes, w6, rng, clamp)
+        # same k-ordered fma chains -> the fused kernel reproduces the per-op chain to the last bits
+        torch.testing.assert_close(got_obj, o2, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(got_logits, lg, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(got_pred, pr, rtol=1e-5, atol=1e-5)
+        # and torch float64
+        d = lambda m: (m.weight.double(), None if m.bias is None else m.bias.double())
+        x = obj.double()
+        h = F.relu(F.linear(x, *d(lin1)))
+        x = F.layer_norm(x + F.linear(h, *d(lin2)), (C,), norm3.weight.double(), norm3.bias.double(), norm3.eps)
+        torch.testing.assert_close(got_obj.double(), x, rtol=5e-5, atol=5e-5)
+        c = x
+        for m, n in cls_layers:
+            c = F.relu(F.layer_norm(F.linear(c, m.weight.double()), (C,), n.weight.double(), n.bias.double(), n.eps))
+        torch.testing.assert_close(got_logits.double(), F.linear(c, *d(logits_fc)), rtol=1e-4, atol=1e-4)
