@@ -206,6 +206,13 @@ int srf_self_attention(const float *qkv, int P, int E, int H, float *out, srf_st
 int srf_dynconv_mid(const float *feats, const float *params, int R, int S, int C, int D, const float *g1,
                     const float *b1, float eps1, const float *g2, const float *b2, float eps2, float *out,
                     srf_stream_t stream);
+/* srf_channel_affine: y[n][c][:] = x[n][c][:] * scale[c] + shift[c], optionally clamped at 0 -- eval-mode
+ * BatchNorm2d (+ ReLU) after the dense convolutions of SECONDCustom / FPN / VoVNet (second_custom.py:41-63,
+ * vovnet.py:39-56) in one pass.  x, y: NCHW f32 with plane size HW and their own batch strides (in floats), so y may be
+ * a channel slice of a wider tensor; y == x is allowed. */
+int srf_channel_affine(const float *x, int N, int C, int HW, long long x_batch_stride, const float *scale,
+                       const float *shift, int relu, float *y, long long y_batch_stride, srf_stream_t stream);
+
 /* srf_stage_tail: the row-local remainder of a stage in one launch (srfdet_head.py:1506-1520): FFN + residual + norm3,
  * classification tower + class_logits, regression tower + bboxes_delta + apply_deltas.  obj_in (R x C) is norm2's
  * output; outputs obj_out (R x C), logits (R x ncls), pred (R x Dd).  cls_/reg_ arrays are HOST arrays of n_cls / n_reg

@@ -4,7 +4,7 @@ There is no CPU fallback: if the library is missing or an op is handed a non-GPU
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrfdet3d_hip.so")
@@ -56,6 +56,7 @@ SIGNATURES = {
                            c_int, _P, c_int, _P, c_size_t, _P]),
     "srf_self_attention": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "srf_dynconv_mid": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, c_float, _P, _P]),
+    "srf_channel_affine": (c_int, [_P, c_int, c_int, c_int, c_longlong, _P, _P, c_int, _P, c_longlong, _P]),
     "srf_stage_tail": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, c_int, POINTER(c_void_p), POINTER(c_void_p),
                                POINTER(c_void_p), _HF, c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), _HF, _P, _P,
                                c_int, _P, _P, c_int, _P, _HF, _HF, c_float, _P, _P, _P, _P]),

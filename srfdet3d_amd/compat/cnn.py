@@ -88,6 +88,12 @@ class ConvModule(nn.Module):
             self.activate = build_activation_layer(act)
 
     def forward(self, x):
+        if self.with_norm and isinstance(self.conv, nn.Conv2d):
+            from ..dense import _foldable, conv_bn_act, fusable
+            norm = getattr(self, self.norm_name)
+            relu = self.with_activation and isinstance(self.activate, nn.ReLU)
+            if _foldable(norm) and fusable(x) and (relu or not self.with_activation):
+                return conv_bn_act(self.conv, norm, relu, x)
         x = self.conv(x)
         if self.with_norm:
             x = getattr(self, self.norm_name)(x)

@@ -274,6 +274,23 @@ __global__ __launch_bounds__(256) void srf_spconv_mfma32_k(const float *__restri
 // linear.  The accumulation order per output element is unchanged (k ascending, channel ascending): results stay
 // bit-identical to srf_spconv_fwd and to the oracle.
 // =====================================================================================================================
+// direct (LDS-free B operand) layout of the COUT = 128 kernel, see srf_spconv_direct_k below
+static bool srf_direct_layout(int Cin, int Cout) { return Cout == 128 && (Cin == 64 || Cin == 128); }
+
+__global__ __launch_bounds__(256) void srf_pack_weights_direct_k(const float *__restrict__ W, int K, int Cin, int Cout,
+                                                               int nchunk, float *__restrict__ P)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)K * nchunk * Cout * 32;
+    if (t >= total) return;
+    const int i = (int)(t & 3), lane = (int)((t >> 2) & 63), g = (int)((t >> 8) & 3), wc = (int)((t >> 10) & 3);
+    const long long rest = t >> 12;
+    const int chunk = (int)(rest % nchunk), k = (int)(rest / nchunk);
+    const int col = wc * 32 + (lane & 31);
+    const int c = chunk * 32 + 2 * (4 * g + i) + (lane >> 5);
+    P[t] = c < Cin ? W[((size_t)k * Cin + c) * Cout + col] : 0.0f;
+}
+
 __global__ __launch_bounds__(256) void srf_pack_weights_k(const float *__restrict__ W, int K, int Cin, int Cout, int nchunk,
                                                         float *__restrict__ P)
 {
@@ -302,8 +319,12 @@ extern "C" int srf_spconv_pack_weights(const float *W, int K, int Cin, int Cout,
     if (!W || !packed || K <= 0 || K > SRF_KMAX || Cin <= 0 || Cout <= 0) return SRF_EINVAL;
     const int nchunk = (Cin + 31) / 32;
     const long long total = (long long)K * nchunk * Cout * 32;
-    hipLaunchKernelGGL(srf_pack_weights_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, W, K, Cin, Cout,
-                       nchunk, packed);
+    if (srf_direct_layout(Cin, Cout))
+        hipLaunchKernelGGL(srf_pack_weights_direct_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, W, K,
+                           Cin, Cout, nchunk, packed);
+    else
+        hipLaunchKernelGGL(srf_pack_weights_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, W, K, Cin, Cout,
+                           nchunk, packed);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }
@@ -472,6 +493,154 @@ __global__ __launch_bounds__(256) void srf_spconv_packed_k(const float *__restri
     }
 }
 
+// =====================================================================================================================
+// COUT = 128, Cin in {64, 128}: the B operand never touches LDS.  Weights are packed so that every lane finds the 16
+// values it feeds to the 16 MFMAs of a 32-channel chunk as four consecutive float4 (one coalesced 1 KB load per wave
+// and group), and are fetched global(L2) -> registers one chunk ahead by the wave that uses them: no slab copy, no LDS
+// traffic for B and one barrier per kernel offset (64 MFMAs per wave and row tile) instead of one per chunk.  LDS holds
+// only the gathered input rows of one offset (double buffered) and the neighbour tile.  Same accumulation order as every
+// other kernel here (offset ascending, channel ascending): bit-identical results.
+//   direct layout: Wd[k][chunk][wc = col/32][g][lane][i] = W[k][chunk*32 + 2*(4g+i) + (lane>>5)][wc*32 + (lane&31)]
+// =====================================================================================================================
+template <int NCH>
+__device__ __forceinline__ void srf_dir_load_b(f32x4 (&b)[4], const float *__restrict__ Wd, int k, int chunk, int wc, int lane)
+{
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        b[g] = *reinterpret_cast<const f32x4 *>(Wd + (((((size_t)k * NCH + chunk) * 4 + wc) * 4 + g) * 64 + lane) * 4);
+}
+
+template <int TM, int NCH, int NA>
+__device__ __forceinline__ void srf_dir_gather(const float *__restrict__ in, const int *s_nbr_k, f32x4 (&ra)[NA], unsigned &okmask)
+{
+    const int tid = threadIdx.x;
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int e = tid + j * 256;
+        const int r = e / (8 * NCH), q = e % (8 * NCH);
+        const int i = s_nbr_k[r];
+        ra[j] = *reinterpret_cast<const f32x4 *>(in + (size_t)(i >= 0 ? i : 0) * (32 * NCH) + q * 4);
+        m |= (i >= 0 ? 1u : 0u) << j;
+    }
+    okmask = m;
+}
+
+template <int TM, int NCH, int NA>
+__device__ __forceinline__ void srf_dir_store(float *s_a, const f32x4 (&ra)[NA], unsigned okmask)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int e = tid + j * 256;
+        const int r = e / (8 * NCH), qq = e % (8 * NCH);
+        const int ch = qq >> 3, q = qq & 7;
+        const f32x4 v = ((okmask >> j) & 1u) ? ra[j] : zero;
+        const int swz = (r >> 1) & 7;
+        const int off = 2 * (q & 1);
+        const f32x2 ev = {v[0], v[2]}, od = {v[1], v[3]};
+        float *img = s_a + ch * (TM * 32) + r * 32;
+        *reinterpret_cast<f32x2 *>(img + ((q >> 1) ^ swz) * 4 + off) = ev;
+        *reinterpret_cast<f32x2 *>(img + ((4 + (q >> 1)) ^ swz) * 4 + off) = od;
+    }
+}
+
+template <int TM, int NCH, int NBUF>
+__global__ __launch_bounds__(256) void srf_spconv_direct_k(const float *__restrict__ in, const float *__restrict__ Wd, int K,
+                                                         const int *__restrict__ nbr, int nbr_stride, int A_out,
+                                                         const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                         const float *__restrict__ residual, int relu,
+                                                         float *__restrict__ out)
+{
+    constexpr int COUT = 128, RT = TM / 32, NA = TM * 8 * NCH / 256;
+    __shared__ int s_nbr[SRF_KMAX * TM];
+    __shared__ int s_any[SRF_KMAX];
+    __shared__ int s_klist[SRF_KMAX + 1];
+    __shared__ __attribute__((aligned(16))) float s_a[NBUF][NCH * TM * 32];
+
+    const int row0 = srf_xcd_tile(blockIdx.x, gridDim.x) * TM;
+    const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
+    srf_load_nbr_tile<TM>(nbr, nbr_stride, K, row0, A_out, s_nbr, s_any);
+    if (tid == 0) {
+        int n = 0;
+        for (int k = 0; k < K; ++k)
+            if (s_any[k]) s_klist[n++] = k;
+        s_klist[SRF_KMAX] = n;
+    }
+    __syncthreads();
+    const int ntap = s_klist[SRF_KMAX];
+
+    f32x16 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[rt][j] = 0.0f;
+
+    const int kh = lane >> 5;
+    f32x4 ra[NA], bq[2][4];
+    unsigned okmask = 0;
+    if (ntap > 0) {
+        const int k0 = s_klist[0];
+        srf_dir_load_b<NCH>(bq[0], Wd, k0, 0, wc, lane);
+        srf_dir_gather<TM, NCH, NA>(in, s_nbr + k0 * TM, ra, okmask);
+        srf_dir_store<TM, NCH, NA>(s_a[0], ra, okmask);
+    }
+    __syncthreads();
+    for (int tk = 0; tk < ntap; ++tk) {
+        const int buf = NBUF == 2 ? (tk & 1) : 0;
+        const int kc = s_klist[tk];
+        const bool more = tk + 1 < ntap;
+        const int kn = more ? s_klist[tk + 1] : kc;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            // B fragments of the next chunk (of this offset or the first of the next one); NCH is even, so the
+            // register pair alternates consistently across offsets
+            if (c + 1 < NCH) srf_dir_load_b<NCH>(bq[(c + 1) & 1], Wd, kc, c + 1, wc, lane);
+            else srf_dir_load_b<NCH>(bq[(c + 1) & 1], Wd, kn, 0, wc, lane);  // harmless re-read on the last offset
+            // the gather of the next offset goes out AFTER the last B load this offset still has to wait for: vmcnt
+            // retires in order, so an earlier gather (an L2 miss more often than not) would be waited for at every
+            // chunk; here it has two chunks of MFMAs to land and only the LDS store below waits for it
+            if (c == NCH - 2 && more) srf_dir_gather<TM, NCH, NA>(in, s_nbr + kn * TM, ra, okmask);
+            f32x4 af[RT][4];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int arow = rt * 32 + (lane & 31);
+                const float *pa = s_a[buf] + c * (TM * 32) + arow * 32;
+                const int a_swz = (arow >> 1) & 7;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) af[rt][g] = *reinterpret_cast<const f32x4 *>(pa + (((kh << 2) + g) ^ a_swz) * 4);
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rt][j >> 2][j & 3], bq[c & 1][j >> 2][j & 3], acc[rt], 0, 0, 0);
+        }
+        if (NBUF == 1) __syncthreads();  // single buffer: every wave is done reading before the rows are replaced
+        if (more) srf_dir_store<TM, NCH, NA>(s_a[NBUF == 2 ? (buf ^ 1) : 0], ra, okmask);
+        __syncthreads();
+    }
+
+    const int col = wc * 32 + (lane & 31);
+    const float al = alpha ? alpha[col] : 1.0f;
+    const float be = alpha ? beta[col] : 0.0f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = row0 + rt * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+            if (row < A_out) {
+                float v = acc[rt][j];
+                if (alpha) v = __fmaf_rn(v, al, be);
+                if (residual) v = __fadd_rn(v, residual[(size_t)row * COUT + col]);
+                if (relu) v = v > 0.0f ? v : 0.0f;
+                out[(size_t)row * COUT + col] = v;
+            }
+        }
+}
+
 extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const float *W_packed, int K, const int *nbr,
                                      int nbr_stride, int A_out, int Cout, const float *alpha, const float *beta,
                                      const float *residual, int relu, float *out, srf_stream_t stream)
@@ -493,6 +662,17 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
                            st, SRF_ARGS);
         break;
     case 128: {
+        if (srf_direct_layout(Cin, Cout)) {
+#define SRF_DARGS in, W_packed, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out
+            if (Cin == 128)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_direct_k<32, 4, 2>), dim3(srf_ceil_div(A_out, 32)), dim3(256), 0, st,
+                                   SRF_DARGS);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_direct_k<32, 2, 2>), dim3(srf_ceil_div(A_out, 32)), dim3(256), 0, st,
+                                   SRF_DARGS);
+#undef SRF_DARGS
+            break;
+        }
         // 64-row tiles halve the W-slab traffic, 32-row tiles balance better when there are only a few tiles per CU:
         // pick the one whose busiest CU (tiles dealt evenly over 256 CUs) carries fewer 32-row units
         const int units64 = 2 * srf_ceil_div(srf_ceil_div(A_out, 64), 256), units32 = srf_ceil_div(srf_ceil_div(A_out, 32), 256);

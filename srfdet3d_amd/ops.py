@@ -382,6 +382,24 @@ def apply_deltas(deltas, boxes, weights6, pc_range, scale_clamp):
     return out
 
 
+def channel_affine(x, scale, shift, relu, out=None):
+    """y = x * scale[c] + shift[c] (+ ReLU) on a contiguous NCHW tensor; `out` may be x itself or a channel slice of a
+    wider contiguous NCHW tensor (same N, H, W)."""
+    x = _dev(x, "x", torch.float32)
+    N, C = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    if out is None:
+        out = torch.empty_like(x)
+    if out.shape != x.shape or out.dtype != torch.float32 or out.device != x.device:
+        raise ValueError("channel_affine: out must match x")
+    if HW and (out.stride(1) != HW or not out[0, 0].is_contiguous()):
+        raise ValueError("channel_affine: out must be NCHW with contiguous channel planes")
+    y_sn = out.stride(0) if N > 1 else C * HW
+    check(_lib.lib().srf_channel_affine(_ptr(x), N, C, HW, C * HW, _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(out),
+                                        max(y_sn, C * HW), _stream()), "channel_affine")
+    return out
+
+
 def _ptr_array(tensors):
     import ctypes
     arr = (ctypes.c_void_p * max(len(tensors), 1))()

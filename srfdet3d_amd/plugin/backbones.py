@@ -4,6 +4,7 @@ from torch import nn
 
 from ..compat.cnn import BaseModule, build_conv_layer, build_norm_layer
 from ..compat.registry import BACKBONES
+from ..dense import run_sequential
 
 
 @BACKBONES.register_module()
@@ -27,6 +28,6 @@ class SECONDCustom(BaseModule):
     def forward(self, x):
         outs = []
         for stage in self.blocks:
-            x = stage(x)
+            x = run_sequential(stage, x)
             outs.append(x)
         return tuple(outs)

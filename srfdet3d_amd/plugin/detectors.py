@@ -47,6 +47,7 @@ class SRFDet(BaseModule):
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
         self._graphed_tail = None
+        self._graphed_img = None
         # None = fp32 (the configs' default).  torch.float16 / torch.bfloat16 run the image backbone + neck under
         # autocast with fp32 outputs, i.e. the reference's `auto_fp16(apply_to=('img'), out_fp32=True)` mode
         # (srfdet.py:141); opt-in, never the default.
@@ -56,8 +57,9 @@ class SRFDet(BaseModule):
         """Replay the static-shape tail (SECOND -> FPN -> decoder -> decode) as a captured hipGraph in `simple_test`
         (see srfdet3d_amd/graphs.py).  Results are identical to the eager path; opt-in because a graph pins its
         buffers for the lifetime of the model."""
-        from ..graphs import GraphedTail
+        from ..graphs import GraphedImageBranch, GraphedTail
         self._graphed_tail = GraphedTail(self) if enabled else None
+        self._graphed_img = GraphedImageBranch(self) if (enabled and self.use_img) else None
         return self
 
     def init_weights(self):
@@ -86,9 +88,17 @@ class SRFDet(BaseModule):
 
     def _test_bboxes(self, img, points, img_metas):
         if self._graphed_tail is not None and not self.training and points is not None:
-            img_feats = self.extract_img_feat(img, img_metas) if img is not None else None
+            img_static = False
+            if img is not None and self._graphed_img is not None:
+                # image branch: hipGraph on a side stream, overlapping the eager LiDAR half below
+                img_feats, img_done = self._graphed_img(img, img_metas)
+                img_static = True
+            else:
+                img_feats = self.extract_img_feat(img, img_metas) if img is not None else None
             bev = self.extract_bev(points)
-            scores, boxes = self._graphed_tail(bev, img_feats, img_metas)
+            if img_static:
+                torch.cuda.current_stream().wait_event(img_done)
+            scores, boxes = self._graphed_tail(bev, img_feats, img_metas, img_static=img_static)
             return self.bbox_head.get_bboxes(None, None, img_metas, decoded=(scores, boxes))
         img_feats, point_feats = self.extract_feat(img, points, img_metas)
         return self.bbox_head.simple_test_bboxes(img_feats, point_feats, img_metas)

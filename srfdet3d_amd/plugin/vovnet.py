@@ -15,6 +15,7 @@ from torch.nn.modules.batchnorm import _BatchNorm
 
 from ..compat.cnn import BaseModule
 from ..compat.registry import BACKBONES
+from ..dense import run_sequential
 
 # name: (stem widths, per-stage conv width, per-stage output width, layers per block, blocks per stage, depthwise)
 SPECS = {
@@ -69,11 +70,11 @@ class OSAModule(nn.Module):
 
     def forward(self, x):
         feats = [x]
-        y = self.reduce(x) if self.reduce is not None else x
+        y = run_sequential(self.reduce, x) if self.reduce is not None else x
         for layer in self.layers:
-            y = layer(y)
+            y = run_sequential(layer, y)
             feats.append(y)
-        out = self.ese(self.concat(torch.cat(feats, dim=1)))
+        out = self.ese(run_sequential(self.concat, torch.cat(feats, dim=1)))
         return out + x if self.identity else out
 
 
@@ -109,7 +110,7 @@ class VoVNet(BaseModule):
 
     def forward(self, x):
         out = OrderedDict()
-        x = self.stem(x)
+        x = run_sequential(self.stem, x)
         if "stem" in self._out_features:
             out["stem"] = x
         for name in self.stage_names:

@@ -1,0 +1,59 @@
+"""Dense-side companions (csrc/dense.hip): the fused eval BatchNorm2d + ReLU pass against torch, and the fused
+conv -> BN -> ReLU routing of srfdet3d_amd/dense.py against the plain module chain."""
+import pytest
+import torch
+from torch import nn
+
+from srfdet3d_amd import dense, ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _bn(c, dev, g, eps=1e-3):
+    bn = nn.BatchNorm2d(c, eps=eps)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(c, generator=g) * 0.2)
+        bn.running_mean.copy_(torch.randn(c, generator=g) * 0.3)
+        bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+    return bn.to(dev).eval()
+
+
+@pytest.mark.parametrize("shape", [(6, 128, 58, 100), (1, 256, 184, 184), (2, 7, 29, 50), (3, 5, 1, 1), (1, 64, 33, 7)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_channel_affine_matches_bn_eval(dev, shape, relu):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).to(dev)
+    bn = _bn(shape[1], dev, g)
+    with torch.no_grad():
+        want = bn.double()(x.double())
+        bn.float()
+        if relu:
+            want = want.relu()
+        scale, shift = dense._fold_bn2d(bn)
+        got = ops.channel_affine(x, scale, shift, relu)
+        torch.testing.assert_close(got.double(), want, rtol=1e-5, atol=1e-5)
+        # in place, and into a channel slice of a wider tensor (the concat-buffer case)
+        wide = torch.full((shape[0], shape[1] + 9, *shape[2:]), 7.0, device=dev)
+        ops.channel_affine(x, scale, shift, relu, out=wide[:, 4:4 + shape[1]])
+        assert torch.equal(wide[:, 4:4 + shape[1]], got)
+        assert bool((wide[:, :4] == 7.0).all()) and bool((wide[:, 4 + shape[1]:] == 7.0).all())
+        y = x.clone()
+        assert ops.channel_affine(y, scale, shift, relu, out=y).data_ptr() == y.data_ptr()
+        assert torch.equal(y, got)
+
+
+def test_run_sequential_equals_module_chain(dev):
+    g = torch.Generator().manual_seed(5)
+    seq = nn.Sequential(nn.Conv2d(8, 16, 3, 1, 1, bias=False), _bn(16, dev, g), nn.ReLU(inplace=True),
+                        nn.Conv2d(16, 16, 3, 2, 1, bias=False), _bn(16, dev, g), nn.ReLU(inplace=True),
+                        nn.Conv2d(16, 4, 1, bias=False), _bn(4, dev, g)).to(dev).eval()
+    x = torch.randn(2, 8, 40, 36, generator=g).to(dev)
+    with torch.no_grad():
+        want = seq(x.clone())
+        got = dense.run_sequential(seq, x.clone())
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    # with grad enabled (training / fine-tuning) the modules run as written
+    seq.train()
+    y = dense.run_sequential(seq, x.clone().requires_grad_(True))
+    assert y.requires_grad
