@@ -206,12 +206,15 @@ int srf_self_attention(const float *qkv, int P, int E, int H, float *out, srf_st
 int srf_dynconv_mid(const float *feats, const float *params, int R, int S, int C, int D, const float *g1,
                     const float *b1, float eps1, const float *g2, const float *b2, float eps2, float *out,
                     srf_stream_t stream);
-/* srf_channel_affine: y[n][c][:] = x[n][c][:] * scale[c] + shift[c], optionally clamped at 0 -- eval-mode
- * BatchNorm2d (+ ReLU) after the dense convolutions of SECONDCustom / FPN / VoVNet (second_custom.py:41-63,
- * vovnet.py:39-56) in one pass.  x, y: NCHW f32 with plane size HW and their own batch strides (in floats), so y may be
- * a channel slice of a wider tensor; y == x is allowed. */
+/* srf_channel_affine: y[n][c][:] = x[n][c][:] * scale + shift (+ residual[n][c][:]), optionally clamped at 0, in one
+ * pass.  per_sample == 0: scale/shift are [C] -- eval-mode BatchNorm2d (+ ReLU) after the dense convolutions of
+ * SECONDCustom / FPN / VoVNet (second_custom.py:41-63, vovnet.py:39-56).  per_sample == 1: scale/shift are [N*C] -- the
+ * eSE channel gate, with the OSA block's identity input as `residual` (vovnet.py:136-150, :213-216).  shift and
+ * residual may be NULL.  x, y: NCHW f32 with plane size HW and their own batch strides (in floats), so y may be a
+ * channel slice of a wider tensor; y == x is allowed; residual is contiguous (N, C, HW). */
 int srf_channel_affine(const float *x, int N, int C, int HW, long long x_batch_stride, const float *scale,
-                       const float *shift, int relu, float *y, long long y_batch_stride, srf_stream_t stream);
+                       const float *shift, int per_sample, const float *residual, int relu, float *y,
+                       long long y_batch_stride, srf_stream_t stream);
 
 /* srf_stage_tail: the row-local remainder of a stage in one launch (srfdet_head.py:1506-1520): FFN + residual + norm3,
  * classification tower + class_logits, regression tower + bboxes_delta + apply_deltas.  obj_in (R x C) is norm2's

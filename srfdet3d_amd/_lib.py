@@ -56,7 +56,7 @@ SIGNATURES = {
                            c_int, _P, c_int, _P, c_size_t, _P]),
     "srf_self_attention": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "srf_dynconv_mid": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, c_float, _P, _P]),
-    "srf_channel_affine": (c_int, [_P, c_int, c_int, c_int, c_longlong, _P, _P, c_int, _P, c_longlong, _P]),
+    "srf_channel_affine": (c_int, [_P, c_int, c_int, c_int, c_longlong, _P, _P, c_int, _P, c_int, _P, c_longlong, _P]),
     "srf_stage_tail": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, c_int, POINTER(c_void_p), POINTER(c_void_p),
                                POINTER(c_void_p), _HF, c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), _HF, _P, _P,
                                c_int, _P, _P, c_int, _P, _HF, _HF, c_float, _P, _P, _P, _P]),

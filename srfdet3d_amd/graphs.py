@@ -67,10 +67,11 @@ class GraphedImageBranch:
     (voxelization, rulebooks, sparse convs), whose many short launches and host read-backs leave most of the chip
     idle.  `__call__` returns the persistent feature buffers and an event the consumer stream must wait for."""
 
-    def __init__(self, model, warmup=2):
+    def __init__(self, model, warmup=2, overlap=True):
         self.model = model
         self.warmup = warmup
         self.entries = {}
+        self.overlap = overlap
         self.stream = torch.cuda.Stream()
 
     def __call__(self, img, img_metas):
@@ -81,11 +82,12 @@ class GraphedImageBranch:
             e = self._capture(key, img, img_metas)
         for meta in img_metas:
             meta.update(input_shape=img.shape[-2:])
-        self.stream.wait_stream(main)  # img is ready, and the previous frame's consumers of the buffers are done
-        with torch.cuda.stream(self.stream):
+        run_on = self.stream if self.overlap else main
+        run_on.wait_stream(main)  # img is ready, and the previous frame's consumers of the buffers are done
+        with torch.cuda.stream(run_on):
             e["img"].copy_(img)
             e["graph"].replay()
-            e["done"].record(self.stream)
+            e["done"].record(run_on)
         return e["feats"], e["done"]
 
     def _capture(self, key, img, img_metas):

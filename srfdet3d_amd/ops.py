@@ -382,8 +382,9 @@ def apply_deltas(deltas, boxes, weights6, pc_range, scale_clamp):
     return out
 
 
-def channel_affine(x, scale, shift, relu, out=None):
-    """y = x * scale[c] + shift[c] (+ ReLU) on a contiguous NCHW tensor; `out` may be x itself or a channel slice of a
+def channel_affine(x, scale, shift, relu, out=None, residual=None):
+    """y = x * scale + shift (+ residual) (+ ReLU) on a contiguous NCHW tensor; scale / shift hold C values (per
+    channel) or N*C values (per sample and channel); shift may be None.  `out` may be x itself or a channel slice of a
     wider contiguous NCHW tensor (same N, H, W)."""
     x = _dev(x, "x", torch.float32)
     N, C = x.shape[0], x.shape[1]
@@ -395,7 +396,16 @@ def channel_affine(x, scale, shift, relu, out=None):
     if HW and (out.stride(1) != HW or not out[0, 0].is_contiguous()):
         raise ValueError("channel_affine: out must be NCHW with contiguous channel planes")
     y_sn = out.stride(0) if N > 1 else C * HW
-    check(_lib.lib().srf_channel_affine(_ptr(x), N, C, HW, C * HW, _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(out),
+    if scale.numel() not in (C, N * C) or (shift is not None and shift.numel() != scale.numel()):
+        raise ValueError("channel_affine: scale/shift must hold C or N*C values")
+    per_sample = int(scale.numel() != C)
+    if residual is not None:
+        residual = _dev(residual, "residual", torch.float32)
+        if residual.shape != x.shape:
+            raise ValueError("channel_affine: residual must match x")
+    check(_lib.lib().srf_channel_affine(_ptr(x), N, C, HW, C * HW, _ptr(_dev(scale, "scale", torch.float32)),
+                                        None if shift is None else _ptr(_dev(shift, "shift", torch.float32)), per_sample,
+                                        None if residual is None else _ptr(residual), int(bool(relu)), _ptr(out),
                                         max(y_sn, C * HW), _stream()), "channel_affine")
     return out
 

@@ -53,13 +53,14 @@ class SRFDet(BaseModule):
         # (srfdet.py:141); opt-in, never the default.
         self.img_autocast_dtype = None
 
-    def enable_hip_graphs(self, enabled=True):
+    def enable_hip_graphs(self, enabled=True, img_overlap=False):
         """Replay the static-shape tail (SECOND -> FPN -> decoder -> decode) as a captured hipGraph in `simple_test`
-        (see srfdet3d_amd/graphs.py).  Results are identical to the eager path; opt-in because a graph pins its
-        buffers for the lifetime of the model."""
+        (see srfdet3d_amd/graphs.py), and with images the VoVNet -> FPN branch as a second graph.  Results are identical
+        to the eager path; opt-in because a graph pins its buffers for the lifetime of the model.  img_overlap=True
+        replays the image graph on a side stream beside the eager LiDAR half."""
         from ..graphs import GraphedImageBranch, GraphedTail
         self._graphed_tail = GraphedTail(self) if enabled else None
-        self._graphed_img = GraphedImageBranch(self) if (enabled and self.use_img) else None
+        self._graphed_img = GraphedImageBranch(self, overlap=img_overlap) if (enabled and self.use_img) else None
         return self
 
     def init_weights(self):

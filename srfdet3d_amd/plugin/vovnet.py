@@ -15,7 +15,8 @@ from torch.nn.modules.batchnorm import _BatchNorm
 
 from ..compat.cnn import BaseModule
 from ..compat.registry import BACKBONES
-from ..dense import run_sequential
+from .. import ops
+from ..dense import fusable, run_sequential
 
 # name: (stem widths, per-stage conv width, per-stage output width, layers per block, blocks per stage, depthwise)
 SPECS = {
@@ -46,9 +47,13 @@ class eSEModule(nn.Module):
         super().__init__()
         self.fc = nn.Conv2d(channel, channel, kernel_size=1)
 
-    def forward(self, x):
+    def forward(self, x, identity=None):
         gate = F.relu6(self.fc(x.mean(dim=(2, 3), keepdim=True)) + 3.0) / 6.0
-        return x * gate
+        if fusable(x) and x.is_contiguous() and (identity is None or identity.is_contiguous()):
+            # gate multiply (+ the OSA identity add) in one in-place pass
+            return ops.channel_affine(x, gate.reshape(-1), None, False, out=x, residual=identity)
+        out = x * gate
+        return out if identity is None else out + identity
 
 
 class OSAModule(nn.Module):
@@ -74,8 +79,7 @@ class OSAModule(nn.Module):
         for layer in self.layers:
             y = run_sequential(layer, y)
             feats.append(y)
-        out = self.ese(run_sequential(self.concat, torch.cat(feats, dim=1)))
-        return out + x if self.identity else out
+        return self.ese(run_sequential(self.concat, torch.cat(feats, dim=1)), x if self.identity else None)
 
 
 def _stage(cin, width, cout, n_blocks, n_layers, idx, depthwise):

@@ -57,3 +57,15 @@ def test_run_sequential_equals_module_chain(dev):
     seq.train()
     y = dense.run_sequential(seq, x.clone().requires_grad_(True))
     assert y.requires_grad
+
+
+def test_channel_affine_gate_and_identity(dev):
+    """per-(sample, channel) scale without shift + residual: the eSE gate and the OSA identity add in one pass."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 10, 17, 12, generator=g).to(dev)
+    res = torch.randn(3, 10, 17, 12, generator=g).to(dev)
+    gate = torch.rand(3, 10, 1, 1, generator=g).to(dev)
+    want = x * gate + res
+    got = ops.channel_affine(x.clone(), gate.reshape(-1), None, False, residual=res)
+    assert torch.equal(got, want)
+    assert torch.equal(ops.channel_affine(x.clone(), gate.reshape(-1), None, False), x * gate)
