@@ -216,6 +216,17 @@ int srf_channel_affine(const float *x, int N, int C, int HW, long long x_batch_s
                        const float *shift, int per_sample, const float *residual, int relu, float *y,
                        long long y_batch_stride, srf_stream_t stream);
 
+/* srf_conv1x1: 1x1 convolution over the channel concatenation of n_src (<= 8) NCHW f32 tensors of the same N and
+ * H*W, followed by y = y * scale[co] + shift[co] (scale may be NULL: bias only; both NULL: none) and an optional ReLU --
+ * the `concat` layer of VoVNet's OSA blocks (vovnet.py:182-216: torch.cat + conv1x1 + BN + ReLU) without the
+ * concatenated tensor, and the FPN lateral convolutions.  srcs / src_channels are HOST arrays (device pointers,
+ * channel counts, each a multiple of 32); W_packed comes from srf_conv1x1_pack_weights(W (Cout x K row-major, K = sum
+ * of the channel counts in concat order)); Cout % 128 == 0 and HW % 4 == 0, else SRF_EUNSUPPORTED.  out: (N, Cout, HW). */
+size_t srf_conv1x1_packed_weight_bytes(int Cout, int K);
+int srf_conv1x1_pack_weights(const float *W, int Cout, int K, float *packed, srf_stream_t stream);
+int srf_conv1x1(const float *const *srcs, const int *src_channels, int n_src, int N, int HW, const float *W_packed, int Cout,
+                const float *scale, const float *shift, int relu, float *out, srf_stream_t stream);
+
 /* srf_stage_tail: the row-local remainder of a stage in one launch (srfdet_head.py:1506-1520): FFN + residual + norm3,
  * classification tower + class_logits, regression tower + bboxes_delta + apply_deltas.  obj_in (R x C) is norm2's
  * output; outputs obj_out (R x C), logits (R x ncls), pred (R x Dd).  cls_/reg_ arrays are HOST arrays of n_cls / n_reg

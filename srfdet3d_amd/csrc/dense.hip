@@ -69,3 +69,219 @@ extern "C" int srf_channel_affine(const float *x, int N, int C, int HW, long lon
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }
+
+// =====================================================================================================================
+// srf_conv1x1: 1x1 convolution over the CONCATENATION of up to 8 NCHW tensors, with the eval BatchNorm (or bias) and
+// ReLU as its epilogue -- the `concat` layer of every OSA block of VoVNet (vovnet.py:182-216: torch.cat of the block
+// input and its five 3x3 branches, then conv1x1 -> BN -> ReLU) without materialising the concatenation, and the
+// lateral convolutions of the FPN.  Per image it is the GEMM  Y[co][p] = sum_k W[co][k] X[k][p]  (p = pixel):
+//   * MFMA rows = output channels, columns = pixels: an accumulator register then holds 32 consecutive pixels of one
+//     channel, so the NCHW store is coalesced;
+//   * W is packed once per layer in per-lane MFMA order and goes L2 -> registers (as in srf_spconv_direct_k): each wave
+//     owns 32 output channels x 128 pixels (4 accumulators) and is the only reader of its weight rows;
+//   * X chunks (32 channels x 128 pixels, rows contiguous in NCHW) are copied linearly into a padded LDS tile,
+//     register-prefetched one chunk ahead, double buffered, one barrier per 64 MFMAs of every wave.
+// f32 MFMA (v_mfma_f32_32x32x2_f32), k ascending in concat order.
+// =====================================================================================================================
+#define C11_MAXSEG 8
+#define C11_TP 128            // pixels per tile
+#define C11_LD (C11_TP + 32)  // LDS row stride (floats): lanes 32-63 read the next k row -> the other 32 banks
+
+struct C11Segs {
+    const float *ptr[C11_MAXSEG];
+    int chunks[C11_MAXSEG];  // channels / 32
+    int nseg;
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void srf_conv1x1_pack_k(const float *__restrict__ W, int Cout, int K, float *__restrict__ P)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)Cout * K) return;
+    const int i = (int)(t & 3), lane = (int)((t >> 2) & 63), g = (int)((t >> 8) & 3);
+    const long long rest = t >> 10;
+    const int nchunk = K / 32;
+    const int chunk = (int)(rest % nchunk), ct = (int)(rest / nchunk);
+    const int co = ct * 32 + (lane & 31);
+    const int k = chunk * 32 + 2 * (4 * g + i) + (lane >> 5);
+    P[t] = W[(size_t)co * K + k];
+}
+
+__device__ __forceinline__ int c11_xcd_tile(int b, int n)
+{
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+template <int NQ>  // 32-pixel MFMA column tiles per wave: the workgroup tile is 128 channels x (32 * NQ) pixels
+__global__ __launch_bounds__(256) void srf_conv1x1_k(C11Segs segs, int HW, int nchunk, const float *__restrict__ Wp, int Cout,
+                                                    const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                                                    float *__restrict__ out, int n_ptiles, int n_ctiles)
+{
+    constexpr int TP = 32 * NQ, LD = TP + 32, RV = TP / 4;  // RV float4 per X row
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // [2][32 * LD] (+ padding that caps the occupancy)
+    float *s_x0 = s_dyn, *s_x1 = s_dyn + 32 * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-contiguous order with the channel tile fastest: the workgroups that share an X tile sit on one XCD's L2
+    const int t = c11_xcd_tile(blockIdx.x, gridDim.x);
+    const int ct = t % n_ctiles;
+    const int rest = t / n_ctiles;
+    const int pt = rest % n_ptiles, n = rest / n_ptiles;
+    const int p0 = pt * TP;
+    const int kh = lane >> 5;
+    // this thread's part of an X chunk: NQ float4, row = e / RV (k within the chunk), 4 pixels at (e % RV) * 4
+    int xoff[NQ], soff[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int e = tid + j * 256;
+        int p = p0 + (e % RV) * 4;
+        p = p < HW - 4 ? p : HW - 4;  // tail tile: clamped reads land in columns that are never stored
+        xoff[j] = (e / RV) * HW + p;
+        soff[j] = (e / RV) * LD + (e % RV) * 4;
+    }
+    const float *wbase = Wp + ((size_t)(ct * 4 + wave) * nchunk) * 1024 + lane * 4;
+
+    f32x16 acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[q][j] = 0.f;
+
+    f32x4 rx[NQ], wq[2][4];
+    int seg = 0, cis = 0;  // segment / chunk-in-segment of the chunk being PREFETCHED
+    const float *xs = segs.ptr[0] + (size_t)n * segs.chunks[0] * 32 * HW;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) rx[j] = *reinterpret_cast<const f32x4 *>(xs + xoff[j]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) wq[0][g] = *reinterpret_cast<const f32x4 *>(wbase + g * 256);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) *reinterpret_cast<f32x4 *>(s_x0 + soff[j]) = rx[j];
+    __syncthreads();
+    for (int c = 0; c < nchunk; c += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // two chunks per trip so that the register / LDS buffer parity is static
+            const int cc = c + h;
+            if (cc >= nchunk) break;
+            const bool more = cc + 1 < nchunk;
+            if (more) {
+                if (++cis == segs.chunks[seg]) {
+                    cis = 0;
+                    ++seg;
+                }
+                xs = segs.ptr[seg] + ((size_t)n * segs.chunks[seg] + cis) * 32 * HW;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) wq[h ^ 1][g] = *reinterpret_cast<const f32x4 *>(wbase + (size_t)(cc + 1) * 1024 + g * 256);
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) rx[j] = *reinterpret_cast<const f32x4 *>(xs + xoff[j]);
+            }
+            const float *sx = (h ? s_x1 : s_x0) + kh * LD + (lane & 31);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                float bf[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) bf[j] = sx[(2 * j) * LD + q * 32];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[h][j >> 2][j & 3], bf[j], acc[q], 0, 0, 0);
+            }
+            if (more) {
+                float *dst = h ? s_x0 : s_x1;
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) *reinterpret_cast<f32x4 *>(dst + soff[j]) = rx[j];
+            }
+            __syncthreads();
+        }
+    }
+    // epilogue: acc[q][j] = channel co0 + (j&3) + 8*(j>>2) + 4*kh, pixel p0 + q*32 + (lane&31)
+    const int co0 = ct * 128 + wave * 32;
+    float *po = out + ((size_t)n * Cout + co0) * HW;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = (j & 3) + 8 * (j >> 2) + 4 * kh;
+        const float a = scale ? scale[co0 + r] : 1.f, b = shift ? shift[co0 + r] : 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int p = p0 + q * 32 + (lane & 31);
+            if (p < HW) {
+                float v = acc[q][j];
+                if (scale) v = __fmaf_rn(v, a, b);
+                else if (shift) v = __fadd_rn(v, b);
+                if (relu) v = v > 0.f ? v : 0.f;
+                po[(size_t)r * HW + p] = v;
+            }
+        }
+    }
+}
+
+extern "C" size_t srf_conv1x1_packed_weight_bytes(int Cout, int K)
+{
+    if (Cout <= 0 || K <= 0 || Cout % 32 || K % 32) return 0;
+    return (size_t)Cout * K * sizeof(float);
+}
+
+extern "C" int srf_conv1x1_pack_weights(const float *W, int Cout, int K, float *packed, srf_stream_t stream)
+{
+    if (!W || !packed || Cout <= 0 || K <= 0) return SRF_EINVAL;
+    if (Cout % 32 || K % 32) return SRF_EUNSUPPORTED;
+    hipLaunchKernelGGL(srf_conv1x1_pack_k, dim3(srf_ceil_div((long long)Cout * K, 256)), dim3(256), 0, (hipStream_t)stream, W, Cout,
+                       K, packed);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+extern "C" int srf_conv1x1(const float *const *srcs, const int *src_channels, int n_src, int N, int HW, const float *W_packed,
+                           int Cout, const float *scale, const float *shift, int relu, float *out, srf_stream_t stream)
+{
+    if (n_src <= 0 || n_src > C11_MAXSEG || N < 0 || HW <= 0 || Cout <= 0 || !srcs || !src_channels) return SRF_EINVAL;
+    if (N == 0) return SRF_OK;
+    if (!W_packed || !out || (scale && !shift)) return SRF_EINVAL;
+    if (Cout % 128 || HW % 4 || HW < 4) return SRF_EUNSUPPORTED;
+    C11Segs segs;
+    int nchunk = 0;
+    for (int s = 0; s < C11_MAXSEG; ++s) {
+        segs.ptr[s] = s < n_src ? srcs[s] : nullptr;
+        segs.chunks[s] = s < n_src ? src_channels[s] / 32 : 0;
+        if (s < n_src) {
+            if (!srcs[s] || src_channels[s] <= 0) return SRF_EINVAL;
+            if (src_channels[s] % 32 || ((uintptr_t)srcs[s] & 15)) return SRF_EUNSUPPORTED;
+            nchunk += src_channels[s] / 32;
+        }
+    }
+    segs.nseg = n_src;
+    // Tile width and co-residency: all tiles cost the same and start together, so the launch takes
+    // ceil(tiles / (256 CUs * occ)) rounds of occ * TP "CU-pixel" units.  Pick the cheapest of {128, 64} pixels x
+    // {2, 3} workgroups per CU (fewer than 2 per CU cannot hide the barrier; dynamic LDS padding enforces the cap).
+    const int n_ctiles = Cout / 128;
+    int best_nq = 4, best_occ = 2;
+    long long best = -1;
+    for (int nq = 4; nq >= 2; nq -= 2)
+        for (int occ = 2; occ <= 3; ++occ) {
+            if (nq == 4 && occ == 3) continue;  // 230 registers: two waves per SIMD at most
+            const long long tiles = (long long)srf_ceil_div(HW, 32 * nq) * n_ctiles * N;
+            const long long cost = ((tiles + 256LL * occ - 1) / (256LL * occ)) * occ * (32 * nq + 8);  // + fixed per-tile work
+            if (best < 0 || cost < best) best = cost, best_nq = nq, best_occ = occ;
+        }
+    const int TP = 32 * best_nq;
+    const int n_ptiles = srf_ceil_div(HW, TP);
+    const long long blocks = (long long)n_ptiles * n_ctiles * N;
+    if (blocks > 0x7fffffff) return SRF_EUNSUPPORTED;
+    size_t lds = sizeof(float) * 2 * 32 * (TP + 32);
+    const size_t cap = (size_t)(160 * 1024) / best_occ;       // LDS per workgroup that leaves room for exactly best_occ
+    if (lds < cap - 8 * 1024) lds = cap - 8 * 1024;           // (the next integer occupancy would need <= 160K / (occ + 1))
+    if (best_occ == 2 && lds < 56 * 1024) lds = 56 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_conv1x1_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_conv1x1_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_set = true;
+    }
+    if (best_nq == 4)
+        hipLaunchKernelGGL(srf_conv1x1_k<4>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, segs, HW, nchunk, W_packed,
+                           Cout, scale, shift, relu, out, n_ptiles, n_ctiles);
+    else
+        hipLaunchKernelGGL(srf_conv1x1_k<2>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, segs, HW, nchunk, W_packed,
+                           Cout, scale, shift, relu, out, n_ptiles, n_ctiles);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}

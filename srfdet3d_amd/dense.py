@@ -47,6 +47,39 @@ def conv_bn_act(conv, bn, relu, x):
     return torch.relu_(y) if relu else y
 
 
+def _packed_1x1(conv):
+    vers = (conv.weight._version, conv.weight.data_ptr())
+    cache = getattr(conv, "_srf_packed", None)
+    if cache is None or cache[0] != vers:
+        cache = (vers, ops.pack_conv1x1_weights(conv.weight.detach()))
+        conv._srf_packed = cache
+    return cache[1]
+
+
+def _is_plain_1x1(conv):
+    return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+            and conv.groups == 1 and conv.dilation == (1, 1))
+
+
+def conv1x1_cat_bn_act(conv, bn, relu, xs):
+    """conv1x1(cat(xs, 1)) -> BN(eval) -> ReLU.  On the fused route the concatenation is never built: srf_conv1x1 reads
+    the sources in place and applies the folded BatchNorm (or the conv bias) and the ReLU as its epilogue."""
+    if (_is_plain_1x1(conv) and (bn is None or _foldable(bn)) and fusable(xs[0]) and ops.conv1x1_supported(xs, conv.out_channels)
+            and sum(x.shape[1] for x in xs) == conv.in_channels):
+        if bn is not None:
+            scale, shift = _fold_bn2d(bn)
+            if conv.bias is not None:
+                shift = shift + conv.bias * scale
+        else:
+            scale, shift = None, conv.bias
+        return ops.conv1x1(xs, _packed_1x1(conv), conv.out_channels, scale, shift, relu)
+    x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=1)
+    if bn is None:
+        y = conv(x)
+        return torch.relu_(y) if relu else y
+    return conv_bn_act(conv, bn, relu, x)
+
+
 def run_sequential(seq, x):
     """nn.Sequential forward with every [Conv2d, BatchNorm2d(eval), (ReLU)] run through `conv_bn_act`."""
     mods = list(seq.children())

@@ -410,6 +410,47 @@ def channel_affine(x, scale, shift, relu, out=None, residual=None):
     return out
 
 
+def pack_conv1x1_weights(weight):
+    """(Cout, K) or (Cout, K, 1, 1) -> the per-lane MFMA operand order srf_conv1x1 streams (once per layer)."""
+    weight = _dev(weight.reshape(weight.shape[0], -1), "weight", torch.float32)
+    Cout, K = weight.shape
+    L = _lib.lib()
+    nbytes = L.srf_conv1x1_packed_weight_bytes(Cout, K)
+    if nbytes == 0:
+        raise ValueError("conv1x1: Cout and K must be multiples of 32")
+    packed = _empty((nbytes // 4,), torch.float32, weight.device)
+    check(L.srf_conv1x1_pack_weights(_ptr(weight), Cout, K, _ptr(packed), _stream()), "conv1x1_pack_weights")
+    return packed
+
+
+def conv1x1_supported(xs, Cout):
+    """Shapes srf_conv1x1 takes: contiguous NCHW f32 sources of equal N, H, W, channels % 32 == 0, H*W % 4 == 0."""
+    x0 = xs[0]
+    hw = x0.shape[2] * x0.shape[3]
+    return (Cout % 128 == 0 and hw % 4 == 0 and hw >= 4 and 0 < len(xs) <= 8
+            and all(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and x.shape[1] % 32 == 0
+                    and x.shape[0] == x0.shape[0] and x.shape[2:] == x0.shape[2:] for x in xs))
+
+
+def conv1x1(xs, packed_weight, Cout, scale=None, shift=None, relu=False):
+    """1x1 convolution of cat(xs, dim=1) (never materialised) + per-channel scale/shift + ReLU -> (N, Cout, H, W)."""
+    import ctypes
+    if not conv1x1_supported(xs, Cout):
+        raise ValueError("conv1x1: unsupported shapes (see conv1x1_supported)")
+    N, _, H, W = xs[0].shape
+    out = _empty((N, Cout, H, W), torch.float32, xs[0].device)
+    ptrs = (ctypes.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+    chans = (ctypes.c_int * len(xs))(*[x.shape[1] for x in xs])
+    K = sum(x.shape[1] for x in xs)
+    if packed_weight.numel() != Cout * K:
+        raise ValueError("conv1x1: packed weight does not match the sources")
+    check(_lib.lib().srf_conv1x1(ptrs, chans, len(xs), N, H * W, _ptr(packed_weight), Cout,
+                                 None if scale is None else _ptr(_dev(scale, "scale", torch.float32)),
+                                 None if shift is None else _ptr(_dev(shift, "shift", torch.float32)), int(bool(relu)),
+                                 _ptr(out), _stream()), "conv1x1")
+    return out
+
+
 def _ptr_array(tensors):
     import ctypes
     arr = (ctypes.c_void_p * max(len(tensors), 1))()

@@ -16,7 +16,7 @@ from torch.nn.modules.batchnorm import _BatchNorm
 from ..compat.cnn import BaseModule
 from ..compat.registry import BACKBONES
 from .. import ops
-from ..dense import fusable, run_sequential
+from ..dense import conv1x1_cat_bn_act, fusable, run_sequential
 
 # name: (stem widths, per-stage conv width, per-stage output width, layers per block, blocks per stage, depthwise)
 SPECS = {
@@ -79,7 +79,9 @@ class OSAModule(nn.Module):
         for layer in self.layers:
             y = run_sequential(layer, y)
             feats.append(y)
-        return self.ese(run_sequential(self.concat, torch.cat(feats, dim=1)), x if self.identity else None)
+        conv, bn = self.concat[0], self.concat[1]
+        out = conv1x1_cat_bn_act(conv, bn, True, feats)
+        return self.ese(out, x if self.identity else None)
 
 
 def _stage(cin, width, cout, n_blocks, n_layers, idx, depthwise):

@@ -69,3 +69,39 @@ def test_channel_affine_gate_and_identity(dev):
     got = ops.channel_affine(x.clone(), gate.reshape(-1), None, False, residual=res)
     assert torch.equal(got, want)
     assert torch.equal(ops.channel_affine(x.clone(), gate.reshape(-1), None, False), x * gate)
+
+
+@pytest.mark.parametrize("N,chans,Cout,H,W", [(2, (128, 160, 160), 256, 12, 20), (1, (32,), 128, 2, 2), (3, (256, 64, 64, 64, 64, 64), 512, 29, 52),
+                                              (6, (512, 192, 192, 192, 192, 192), 768, 58, 100), (1, (96, 32), 128, 5, 36)])
+def test_conv1x1_over_concat_matches_torch(dev, N, chans, Cout, H, W):
+    """srf_conv1x1 (concat never built, BN + ReLU epilogue) against torch conv2d on the concatenation, float64."""
+    g = torch.Generator().manual_seed(N + Cout + H)
+    xs = [torch.randn(N, c, H, W, generator=g).to(dev) for c in chans]
+    K = sum(chans)
+    conv = nn.Conv2d(K, Cout, 1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(Cout, K, 1, 1, generator=g) / K ** 0.5)
+    conv = conv.to(dev)
+    bn = _bn(Cout, dev, g)
+    with torch.no_grad():
+        want = bn.double()(conv.double()(torch.cat(xs, 1).double())).relu()
+        bn.float(), conv.float()
+        got = dense.conv1x1_cat_bn_act(conv, bn, True, xs)
+        torch.testing.assert_close(got.double(), want, rtol=2e-5, atol=2e-5)
+        # bias instead of BatchNorm, no activation (an FPN lateral)
+        conv_b = nn.Conv2d(K, Cout, 1).to(dev)
+        want = conv_b.double()(torch.cat(xs, 1).double())
+        conv_b.float()
+        got = dense.conv1x1_cat_bn_act(conv_b, None, False, xs)
+        torch.testing.assert_close(got.double(), want, rtol=2e-5, atol=2e-5)
+
+
+def test_conv1x1_falls_back_on_unsupported_shapes(dev):
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(2, 24, 7, 5, generator=g).to(dev), torch.randn(2, 40, 7, 5, generator=g).to(dev)]   # C % 32 != 0, HW odd
+    conv = nn.Conv2d(64, 128, 1, bias=False).to(dev)
+    bn = _bn(128, dev, g)
+    with torch.no_grad():
+        want = bn(conv(torch.cat(xs, 1))).relu()
+        got = dense.conv1x1_cat_bn_act(conv, bn, True, xs)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
