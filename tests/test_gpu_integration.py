@@ -168,3 +168,34 @@ def test_checkpoint_round_trip(setup, dev):
         b = fresh.simple_test(None, [p], metas)[0]["pts_bbox"]
     assert torch.equal(a["labels_3d"], b["labels_3d"])
     torch.testing.assert_close(a["boxes_3d"].tensor, b["boxes_3d"].tensor, rtol=0, atol=1e-4)
+
+
+def test_lc_frame_eager_graphs_and_overlap_agree(dev):
+    """LC configuration end to end (small camera images so the test stays quick): eager, hipGraph tail + image-branch
+    graph on the main stream, and the image graph on a side stream must give the same detections; the fused dense route
+    (BN + ReLU pass, OSA concat convolution) must agree with the plain module chain."""
+    import copy
+    torch.manual_seed(2)
+    cpu = workloads.build("srfdet_voxel_nusc_LC", 48).eval()
+    _randomize_bn(cpu, 2)
+    eager = copy.deepcopy(cpu).to(dev)
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes, lidar2img=[m for m in S.camera_rig(f=1266.0 * 256 / 1600, cx=128.0, cy=80.0)])]
+    img = torch.from_numpy(S.camera_images(3000, h=160, w=256)).to(dev)
+    frames = [torch.from_numpy(S.nuscenes_sweep(2000 + i, 12000)).to(dev) for i in range(2)]
+    with torch.no_grad():
+        ref = [eager.simple_test(img, [p], copy.deepcopy(metas))[0]["pts_bbox"] for p in frames]
+        # plain module chain for the image branch (no fused passes): autocast-free fp32, grad mode on disables fusion
+        feats_fused = eager.extract_img_feat(img, copy.deepcopy(metas))
+    with torch.enable_grad():
+        feats_plain = eager.extract_img_feat(img, copy.deepcopy(metas))
+    for a, b in zip(feats_fused, feats_plain):
+        torch.testing.assert_close(a, b.detach(), rtol=1e-4, atol=1e-4)
+    for overlap in (False, True):
+        g = copy.deepcopy(cpu).to(dev).enable_hip_graphs(img_overlap=overlap)
+        for rep in range(2):  # second pass replays the captured graphs
+            for p, want in zip(frames, ref):
+                with torch.no_grad():
+                    got = g.simple_test(img, [p], copy.deepcopy(metas))[0]["pts_bbox"]
+                assert torch.equal(got["labels_3d"], want["labels_3d"])
+                torch.testing.assert_close(got["scores_3d"], want["scores_3d"], rtol=0, atol=1e-5)
+                torch.testing.assert_close(got["boxes_3d"].tensor, want["boxes_3d"].tensor, rtol=0, atol=1e-4)
