@@ -39,6 +39,31 @@ const char *srf_error_string(int code);
 /* Number of HIP devices visible, or a negative error.  Used by the Python loader to fail loudly. */
 int srf_device_count(void);
 
+/* ---- bitmap-rank rulebooks -------------------------------------------------------------------------------------
+ * The same indice-pair generation (spconv SubMConv3d / SparseConv3d, sparse_encoder_custom.py:73-107, :123-134, :182-201)
+ * for active sets whose rows are kept sorted by (b, y, x, z): one occupancy bit per cell of the level's grid plus an
+ * exclusive popcount prefix per 32-bit word give "active? which row?" without a hash table, and the prefix scan of a
+ * strided conv's output bitmap emits the new active set already sorted (a canonical order: independent of scheduling).
+ * cell = ((b*H + y)*W + x)*D + z.  shape = host {D,H,W}.  bitmap: srf_bitmap_words() uint32; prefix: as many ints. */
+size_t srf_bitmap_words(const int *shape, int batch);
+size_t srf_bitmap_workspace_bytes(size_t words);
+/* marks `indices` (A x 4 (b,z,y,x), distinct), ranks them; order[r] = original row of sorted row r and
+ * sorted_indices[r] = its coordinate (both optional, pass NULL for rows that are already sorted) */
+int srf_bitmap_build(const int *indices, int A, const int *shape, int batch, void *bitmap, int *prefix, int *order,
+                     int *sorted_indices, void *workspace, size_t workspace_bytes, srf_stream_t stream);
+int srf_bitmap_rulebook_subm(const int *sorted_indices, int A, const int *shape, int batch, const int *ksize,
+                             const void *bitmap, const int *prefix, int *nbr /* K x A */, int *pair_counts /* K */,
+                             srf_stream_t stream);
+/* phase 1 of a strided conv: bitmap + prefix of the OUTPUT level (sized for the output shape), the sorted output
+ * coordinates (at most out_capacity rows are written; use srf_strided_max_outputs) and their number */
+int srf_bitmap_strided_outputs(const int *indices, int A, const int *shape, int batch, const int *ksize, const int *stride,
+                               const int *pad, void *out_bitmap, int *out_prefix, int *out_indices, int out_capacity,
+                               int *num_out, void *workspace, size_t workspace_bytes, srf_stream_t stream);
+/* phase 2: nbr (K x A_out) from the INPUT level's bitmap + prefix */
+int srf_bitmap_strided_pairs(const int *out_indices, int A_out, const int *shape, int batch, const int *ksize,
+                             const int *stride, const int *pad, const void *in_bitmap, const int *in_prefix, int *nbr,
+                             int *pair_counts, srf_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * K2  dynamic voxelization.
  * Replaces mmcv.ops.Voxelization(max_num_points=-1).forward as called from SRFDet.voxelize,

@@ -313,3 +313,254 @@ extern "C" int srf_rulebook_strided_pairs(int A, const int *ksize, const void *o
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }
+
+// =====================================================================================================================
+// Bitmap-rank rulebooks.
+//
+// When the rows of every active set are kept in the lexicographic order of (b, y, x, z) -- the spatial row order the
+// sparse-conv kernels want anyway -- the row of a coordinate is its RANK among the occupied cells: one bit per cell of
+// the level's grid plus an exclusive popcount prefix per 32-bit word answer "is this cell active, and which row is it"
+// with two coherent reads (the 27 neighbours of a site touch 9 words, shared with the next sites), where the hash table
+// needs a random probe sequence per query.  A strided convolution marks the cells its inputs reach in the output
+// level's bitmap; the same prefix scan that ranks them also emits the new active set, already sorted.  No hash
+// tables, no candidate lists, no atomics beyond the atomicOr of the marks; the order of every active set is canonical
+// (sorted), so it does not depend on scheduling.
+//   cell(b, z, y, x) = ((b * H + y) * W + x) * D + z        bitmap word = cell >> 5, bit = cell & 31
+// =====================================================================================================================
+__device__ __forceinline__ uint32_t srf_bm_cell(int b, int z, int y, int x, const int *shape)
+{
+    return (((uint32_t)b * (uint32_t)shape[1] + (uint32_t)y) * (uint32_t)shape[2] + (uint32_t)x) * (uint32_t)shape[0] + (uint32_t)z;
+}
+
+__device__ __forceinline__ int srf_bm_rank(const uint32_t *__restrict__ bitmap, const int *__restrict__ prefix, uint32_t cell)
+{
+    const uint32_t w = cell >> 5, bit = 1u << (cell & 31);
+    const uint32_t bits = bitmap[w];
+    if (!(bits & bit)) return -1;
+    return prefix[w] + __popc(bits & (bit - 1u));
+}
+
+__global__ __launch_bounds__(256) void srf_bm_mark_k(const int4 *__restrict__ indices, int A, ConvGeom g, uint32_t *bitmap)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A) return;
+    const int4 c = indices[i];
+    const uint32_t cell = srf_bm_cell(c.x, c.y, c.z, c.w, g.shape);
+    atomicOr(&bitmap[cell >> 5], 1u << (cell & 31));
+}
+
+struct BmPop {
+    const uint32_t *bitmap;
+    __device__ int operator()(int w) const { return __popc(bitmap[w]); }
+};
+
+struct BmPrefix {
+    int *prefix;
+    __device__ void operator()(int w, int, int pre) const { prefix[w] = pre; }
+};
+
+// prefix + the sorted coordinate list of the set bits (at most cap rows are written)
+struct BmEmit {
+    const uint32_t *bitmap;
+    int *prefix;
+    int4 *out;
+    int D, H, W, cap;
+    __device__ void operator()(int w, int v, int pre) const
+    {
+        prefix[w] = pre;
+        if (!v) return;
+        uint32_t bits = bitmap[w];
+        int m = pre;
+        while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            uint32_t cell = ((uint32_t)w << 5) | (uint32_t)b;
+            const int z = (int)(cell % (uint32_t)D);
+            cell /= (uint32_t)D;
+            const int x = (int)(cell % (uint32_t)W);
+            cell /= (uint32_t)W;
+            const int y = (int)(cell % (uint32_t)H);
+            if (m < cap) out[m] = make_int4((int)(cell / (uint32_t)H), z, y, x);
+            ++m;
+        }
+    }
+};
+
+__global__ __launch_bounds__(256) void srf_bm_place_k(const int4 *__restrict__ indices, int A, ConvGeom g,
+                                                    const uint32_t *__restrict__ bitmap, const int *__restrict__ prefix,
+                                                    int *__restrict__ order, int4 *__restrict__ sorted)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A) return;
+    const int4 c = indices[i];
+    const int r = srf_bm_rank(bitmap, prefix, srf_bm_cell(c.x, c.y, c.z, c.w, g.shape));
+    if (r >= 0 && r < A) {
+        order[r] = i;
+        sorted[r] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void srf_bm_subm_k(const int4 *__restrict__ indices, int A, ConvGeom g,
+                                                   const uint32_t *__restrict__ bitmap, const int *__restrict__ prefix,
+                                                   int *__restrict__ nbr, int *pair_counts)
+{
+    __shared__ int hist[SRF_MAX_K];
+    if (threadIdx.x < SRF_MAX_K) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int k = (int)(tid / A);
+    const int o = (int)(tid % A);
+    if (k < g.K) {
+        const int4 c = indices[o];
+        const int kx = k % g.ks[2], t = k / g.ks[2];
+        const int ky = t % g.ks[1], kz = t / g.ks[1];
+        const int z = c.y + kz - g.ks[0] / 2, y = c.z + ky - g.ks[1] / 2, x = c.w + kx - g.ks[2] / 2;
+        int v = -1;
+        if (z >= 0 && z < g.shape[0] && y >= 0 && y < g.shape[1] && x >= 0 && x < g.shape[2])
+            v = srf_bm_rank(bitmap, prefix, srf_bm_cell(c.x, z, y, x, g.shape));
+        nbr[(size_t)k * A + o] = v;
+        if (v >= 0) atomicAdd(&hist[k], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < g.K && hist[threadIdx.x]) atomicAdd(&pair_counts[threadIdx.x], hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void srf_bm_strided_mark_k(const int4 *__restrict__ indices, int A, ConvGeom g,
+                                                           uint32_t *obitmap)
+{
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= (long long)A * g.K) return;
+    const int i = (int)(c / g.K), k = (int)(c % g.K);
+    const int4 ci = indices[i];
+    int q[3];
+    if (!srf_candidate(ci, k, g, q)) return;
+    const uint32_t cell = srf_bm_cell(ci.x, q[0], q[1], q[2], g.oshape);
+    const uint32_t bit = 1u << (cell & 31);
+    if (!(obitmap[cell >> 5] & bit)) atomicOr(&obitmap[cell >> 5], bit);  // most candidates find their cell marked already
+}
+
+// nbr[k][o] = row of the input site that offset k of output o reads, or -1
+__global__ __launch_bounds__(256) void srf_bm_strided_pairs_k(const int4 *__restrict__ out_indices, int A_out, ConvGeom g,
+                                                            const uint32_t *__restrict__ ibitmap,
+                                                            const int *__restrict__ iprefix, int *__restrict__ nbr,
+                                                            int *pair_counts)
+{
+    __shared__ int hist[SRF_MAX_K];
+    if (threadIdx.x < SRF_MAX_K) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int k = (int)(tid / A_out);
+    const int o = (int)(tid % A_out);
+    if (k < g.K) {
+        const int4 c = out_indices[o];
+        const int kx = k % g.ks[2], t = k / g.ks[2];
+        const int ky = t % g.ks[1], kz = t / g.ks[1];
+        const int z = c.y * g.st[0] - g.pd[0] + kz, y = c.z * g.st[1] - g.pd[1] + ky, x = c.w * g.st[2] - g.pd[2] + kx;
+        int v = -1;
+        if (z >= 0 && z < g.shape[0] && y >= 0 && y < g.shape[1] && x >= 0 && x < g.shape[2])
+            v = srf_bm_rank(ibitmap, iprefix, srf_bm_cell(c.x, z, y, x, g.shape));
+        nbr[(size_t)k * A_out + o] = v;
+        if (v >= 0) atomicAdd(&hist[k], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < g.K && hist[threadIdx.x]) atomicAdd(&pair_counts[threadIdx.x], hist[threadIdx.x]);
+}
+
+static long long srf_bm_cells(const int *shape, int batch)
+{
+    if (!shape || batch <= 0 || shape[0] <= 0 || shape[1] <= 0 || shape[2] <= 0) return -1;
+    const unsigned long long c = (unsigned long long)batch * shape[0] * shape[1] * shape[2];
+    return c < 0xFFFFFFFFull ? (long long)c : -1;
+}
+
+extern "C" size_t srf_bitmap_words(const int *shape, int batch)
+{
+    const long long c = srf_bm_cells(shape, batch);
+    return c < 0 ? 0 : (size_t)((c + 31) / 32);
+}
+
+extern "C" size_t srf_bitmap_workspace_bytes(size_t words) { return (size_t)(srf_scan_blocks((long long)words) + 1) * sizeof(int); }
+
+extern "C" int srf_bitmap_build(const int *indices, int A, const int *shape, int batch, void *bitmap, int *prefix, int *order,
+                                int *sorted_indices, void *workspace, size_t workspace_bytes, srf_stream_t stream)
+{
+    const size_t words = srf_bitmap_words(shape, batch);
+    if (A < 0 || words == 0 || !bitmap || !prefix || !workspace) return SRF_EINVAL;
+    if (workspace_bytes < srf_bitmap_workspace_bytes(words)) return SRF_EWORKSPACE;
+    ConvGeom g;
+    const int one[3] = {1, 1, 1};
+    if (!srf_fill_conv_geom(g, shape, one, one, nullptr, batch)) return SRF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    SRF_HIP_TRY(hipMemsetAsync(bitmap, 0, words * 4, st));
+    if (A > 0) {
+        if (!indices) return SRF_EINVAL;
+        hipLaunchKernelGGL(srf_bm_mark_k, dim3(srf_ceil_div(A, 256)), dim3(256), 0, st, (const int4 *)indices, A, g,
+                           (uint32_t *)bitmap);
+    }
+    int rc = srf_device_scan((int)words, BmPop{(const uint32_t *)bitmap}, BmPrefix{prefix}, (int *)workspace, nullptr, -1, st);
+    if (rc) return rc;
+    if (A > 0 && order && sorted_indices)
+        hipLaunchKernelGGL(srf_bm_place_k, dim3(srf_ceil_div(A, 256)), dim3(256), 0, st, (const int4 *)indices, A, g,
+                           (const uint32_t *)bitmap, prefix, order, (int4 *)sorted_indices);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+extern "C" int srf_bitmap_rulebook_subm(const int *sorted_indices, int A, const int *shape, int batch, const int *ksize,
+                                        const void *bitmap, const int *prefix, int *nbr, int *pair_counts, srf_stream_t stream)
+{
+    ConvGeom g;
+    if (A < 0 || !shape || !ksize || !pair_counts || !srf_fill_conv_geom(g, shape, ksize, nullptr, nullptr, batch)) return SRF_EINVAL;
+    for (int d = 0; d < 3; ++d)
+        if (!(ksize[d] & 1)) return SRF_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    SRF_HIP_TRY(hipMemsetAsync(pair_counts, 0, sizeof(int) * g.K, st));
+    if (A == 0) return SRF_OK;
+    if (!sorted_indices || !nbr || !bitmap || !prefix) return SRF_EINVAL;
+    hipLaunchKernelGGL(srf_bm_subm_k, dim3(srf_ceil_div((long long)A * g.K, 256)), dim3(256), 0, st, (const int4 *)sorted_indices, A,
+                       g, (const uint32_t *)bitmap, prefix, nbr, pair_counts);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+extern "C" int srf_bitmap_strided_outputs(const int *indices, int A, const int *shape, int batch, const int *ksize,
+                                          const int *stride, const int *pad, void *out_bitmap, int *out_prefix, int *out_indices,
+                                          int out_capacity, int *num_out, void *workspace, size_t workspace_bytes,
+                                          srf_stream_t stream)
+{
+    ConvGeom g;
+    if (A < 0 || !shape || !ksize || !stride || !pad || !num_out || !out_bitmap || !out_prefix || !workspace || out_capacity < 0)
+        return SRF_EINVAL;
+    if (!srf_fill_conv_geom(g, shape, ksize, stride, pad, batch)) return SRF_EINVAL;
+    const size_t words = srf_bitmap_words(g.oshape, batch);
+    if (words == 0) return SRF_EINVAL;
+    if (workspace_bytes < srf_bitmap_workspace_bytes(words)) return SRF_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    SRF_HIP_TRY(hipMemsetAsync(out_bitmap, 0, words * 4, st));
+    if (A > 0) {
+        if (!indices || !out_indices) return SRF_EINVAL;
+        hipLaunchKernelGGL(srf_bm_strided_mark_k, dim3(srf_ceil_div((long long)A * g.K, 256)), dim3(256), 0, st,
+                           (const int4 *)indices, A, g, (uint32_t *)out_bitmap);
+    }
+    return srf_device_scan((int)words, BmPop{(const uint32_t *)out_bitmap},
+                           BmEmit{(const uint32_t *)out_bitmap, out_prefix, (int4 *)out_indices, g.oshape[0], g.oshape[1], g.oshape[2],
+                                  out_capacity},
+                           (int *)workspace, num_out, -1, st);
+}
+
+extern "C" int srf_bitmap_strided_pairs(const int *out_indices, int A_out, const int *shape, int batch, const int *ksize,
+                                        const int *stride, const int *pad, const void *in_bitmap, const int *in_prefix, int *nbr,
+                                        int *pair_counts, srf_stream_t stream)
+{
+    ConvGeom g;
+    if (A_out < 0 || !shape || !ksize || !stride || !pad || !pair_counts) return SRF_EINVAL;
+    if (!srf_fill_conv_geom(g, shape, ksize, stride, pad, batch)) return SRF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    SRF_HIP_TRY(hipMemsetAsync(pair_counts, 0, sizeof(int) * g.K, st));
+    if (A_out == 0) return SRF_OK;
+    if (!out_indices || !nbr || !in_bitmap || !in_prefix) return SRF_EINVAL;
+    hipLaunchKernelGGL(srf_bm_strided_pairs_k, dim3(srf_ceil_div((long long)A_out * g.K, 256)), dim3(256), 0, st,
+                       (const int4 *)out_indices, A_out, g, (const uint32_t *)in_bitmap, in_prefix, nbr, pair_counts);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}

@@ -179,6 +179,79 @@ def rulebook_strided(indices, spatial_shape, batch, ksize, stride, pad):
     return out_idx[:A_out], nbr[:, :A_out], counts, table, out_spatial_shape(spatial_shape, ksize, stride, pad)
 
 
+# ---------------------------------------------------------------------------------------------- bitmap-rank rulebooks
+class BitmapLevel:
+    """Occupancy bitmap + popcount prefix of one level's grid; valid for rows sorted by (b, y, x, z)."""
+
+    def __init__(self, spatial_shape, batch, device):
+        self.shape = [int(v) for v in spatial_shape]
+        self.batch = int(batch)
+        self.words = _lib.lib().srf_bitmap_words(hi(self.shape), self.batch)
+        if self.words == 0:
+            raise ValueError("bitmap level: grid too large or empty")
+        self.bitmap = _empty((self.words,), torch.int32, device)
+        self.prefix = _empty((self.words,), torch.int32, device)
+
+    def workspace(self):
+        nbytes = _lib.lib().srf_bitmap_workspace_bytes(self.words)
+        return _empty((nbytes,), torch.uint8, self.bitmap.device), nbytes
+
+
+def bitmap_build(indices, spatial_shape, batch, want_order=True):
+    """Distinct active sites (A,4) (b,z,y,x) -> (BitmapLevel, order, sorted_indices): row r of the sorted set is
+    original row order[r].  One memset + mark + 3-launch scan + place; no host sync."""
+    indices = _dev(indices, "indices", torch.int32)
+    lvl = BitmapLevel(spatial_shape, batch, indices.device)
+    A = indices.shape[0]
+    order = _empty((max(A, 1),), torch.int32, indices.device) if want_order else None
+    sorted_idx = _empty((max(A, 1), 4), torch.int32, indices.device) if want_order else None
+    ws, nbytes = lvl.workspace()
+    check(_lib.lib().srf_bitmap_build(_ptr(indices), A, hi(lvl.shape), lvl.batch, _ptr(lvl.bitmap), _ptr(lvl.prefix), _ptr(order),
+                                      _ptr(sorted_idx), _ptr(ws), nbytes, _stream()), "bitmap_build")
+    if not want_order:
+        return lvl, None, None
+    return lvl, order[:A], sorted_idx[:A]
+
+
+def rulebook_subm_bitmap(sorted_indices, level, ksize):
+    sorted_indices = _dev(sorted_indices, "indices", torch.int32)
+    A = sorted_indices.shape[0]
+    K = int(np.prod(ksize))
+    nbr = _empty((K, max(A, 1)), torch.int32, sorted_indices.device)
+    counts = _empty((K,), torch.int32, sorted_indices.device)
+    check(_lib.lib().srf_bitmap_rulebook_subm(_ptr(sorted_indices), A, hi(level.shape), level.batch, hi(ksize), _ptr(level.bitmap),
+                                              _ptr(level.prefix), _ptr(nbr), _ptr(counts), _stream()), "bitmap_rulebook_subm")
+    return nbr[:, :A], counts
+
+
+def rulebook_strided_bitmap(indices, level, ksize, stride, pad):
+    """-> out_indices (A_out,4) sorted by (b,y,x,z), nbr (K,A_out), pair_counts (K,), the output BitmapLevel, out_shape.
+    One D2H sync for A_out."""
+    indices = _dev(indices, "indices", torch.int32)
+    L = _lib.lib()
+    dev = indices.device
+    A = indices.shape[0]
+    K = int(np.prod(ksize))
+    bound = L.srf_strided_max_outputs(A, level.batch, hi(level.shape), hi(ksize), hi(stride), hi(pad))
+    if bound < 0:
+        check(bound, "strided_max_outputs")
+    oshape = out_spatial_shape(level.shape, ksize, stride, pad)
+    out_lvl = BitmapLevel(oshape, level.batch, dev)
+    out_idx = _empty((max(bound, 1), 4), torch.int32, dev)
+    num_out = _empty((1,), torch.int32, dev)
+    ws, nbytes = out_lvl.workspace()
+    check(L.srf_bitmap_strided_outputs(_ptr(indices), A, hi(level.shape), level.batch, hi(ksize), hi(stride), hi(pad),
+                                       _ptr(out_lvl.bitmap), _ptr(out_lvl.prefix), _ptr(out_idx), bound, _ptr(num_out), _ptr(ws),
+                                       nbytes, _stream()), "bitmap_strided_outputs")
+    A_out = int(num_out.item())
+    nbr = _empty((K, max(A_out, 1)), torch.int32, dev)
+    counts = _empty((K,), torch.int32, dev)
+    check(L.srf_bitmap_strided_pairs(_ptr(out_idx), A_out, hi(level.shape), level.batch, hi(ksize), hi(stride), hi(pad),
+                                     _ptr(level.bitmap), _ptr(level.prefix), _ptr(nbr), _ptr(counts), _stream()),
+          "bitmap_strided_pairs")
+    return out_idx[:A_out], nbr[:, :A_out], counts, out_lvl, oshape
+
+
 # ---------------------------------------------------------------------------------------------- sparse conv
 # bench.py sets this to {"spconv": []}: every sparse-conv launch is then bracketed by HIP events on the launch stream
 KERNEL_TIMING = None

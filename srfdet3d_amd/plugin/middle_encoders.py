@@ -68,10 +68,10 @@ class SparseEncoderCustom(BaseModule):
         """(M,C) voxel features + (M,4) int (b,z,y,x) -> (B, C*D, H, W) BEV map."""
         coors = coors.int()
         if self.spatial_sort and coors.is_cuda and coors.shape[0] > 0:
-            from .. import ops
-            perm = ops.spatial_order(coors, self.sparse_shape, int(batch_size))
-            voxel_features, coors = voxel_features[perm], coors[perm]
-        x = SparseConvTensor(voxel_features, coors, self.sparse_shape, int(batch_size))
+            # rows into (b, y, x, z) order + the level's occupancy bitmap: all rulebooks below are built by bitmap rank
+            x = SparseConvTensor.sorted_by_bitmap(voxel_features, coors, self.sparse_shape, int(batch_size))
+        else:
+            x = SparseConvTensor(voxel_features, coors, self.sparse_shape, int(batch_size))
         x = self.conv_input(x)
         for stage in self.encoder_layers._modules.values():
             x = stage(x)

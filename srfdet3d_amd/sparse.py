@@ -50,10 +50,29 @@ class SparseConvTensor:
             self.indice_dict[key] = ops.coord_table_build(self.indices, self.spatial_shape, self.batch_size)
         return self.indice_dict[key]
 
+    def bitmap_level(self):
+        """The level's occupancy bitmap if the rows are known to be sorted by (b, y, x, z) (see `sorted_by_bitmap`)."""
+        return self.indice_dict.get(("bitmap",) + self._level_key())
+
+    @staticmethod
+    def sorted_by_bitmap(features, indices, spatial_shape, batch_size):
+        """Reorders distinct active sites into (b, y, x, z) order and attaches the level's bitmap: every rulebook down the
+        layer chain is then built by bitmap rank (ops.rulebook_*_bitmap) instead of hash tables, and every active
+        set stays sorted.  The dense result of an encoder does not depend on the row order."""
+        lvl, order, sorted_idx = ops.bitmap_build(indices if indices.dtype == torch.int32 else indices.int(), spatial_shape,
+                                                  batch_size)
+        t = SparseConvTensor(features[order.long()], sorted_idx, spatial_shape, batch_size)
+        t.indice_dict[("bitmap",) + t._level_key()] = lvl
+        return t
+
     def subm_rulebook(self, ksize):
         key = ("subm", tuple(ksize)) + self._level_key()
         if key not in self.indice_dict:
-            self.indice_dict[key] = ops.rulebook_subm(self.indices, self.spatial_shape, ksize, self.coord_table())
+            lvl = self.bitmap_level()
+            if lvl is not None:
+                self.indice_dict[key] = ops.rulebook_subm_bitmap(self.indices, lvl, ksize)
+            else:
+                self.indice_dict[key] = ops.rulebook_subm(self.indices, self.spatial_shape, ksize, self.coord_table())
         return self.indice_dict[key]
 
     def dense(self, channels_first=True):
@@ -121,10 +140,16 @@ class _SparseConv(SparseModule):
         key = ("strided", self.indice_key, tuple(self.kernel_size), tuple(self.stride), tuple(self.padding)) + \
             x._level_key()
         if key not in x.indice_dict:
-            out_idx, nbr, counts, table, oshape = ops.rulebook_strided(x.indices, x.spatial_shape, x.batch_size,
-                                                                       self.kernel_size, self.stride, self.padding)
+            lvl = x.bitmap_level()
+            if lvl is not None:
+                out_idx, nbr, counts, out_lvl, oshape = ops.rulebook_strided_bitmap(x.indices, lvl, self.kernel_size, self.stride,
+                                                                                   self.padding)
+                x.indice_dict[("bitmap", out_idx.data_ptr(), out_idx.shape[0], tuple(oshape))] = out_lvl
+            else:
+                out_idx, nbr, counts, table, oshape = ops.rulebook_strided(x.indices, x.spatial_shape, x.batch_size,
+                                                                           self.kernel_size, self.stride, self.padding)
+                x.indice_dict[("table", out_idx.data_ptr(), out_idx.shape[0], tuple(oshape))] = table
             x.indice_dict[key] = (out_idx, nbr, counts, oshape)
-            x.indice_dict[("table", out_idx.data_ptr(), out_idx.shape[0], tuple(oshape))] = table
         out_idx, nbr, counts, oshape = x.indice_dict[key]
         return nbr, counts, out_idx, oshape
 

@@ -142,3 +142,70 @@ def test_densify_exact(dev):
     got = ops.densify(torch.from_numpy(f).to(dev), torch.from_numpy(small).to(dev), 1, shape)
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
     assert got.view(1, 16 * shape[0], 64, 48).shape == (1, 16 * shape[0], 64, 48)
+
+
+def _sort_key(idx, shape):
+    """(b, y, x, z) lexicographic key = the bitmap cell index."""
+    D, H, W = shape
+    i = idx.astype(np.int64)
+    return ((i[:, 0] * H + i[:, 2]) * W + i[:, 3]) * D + i[:, 1]
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_bitmap_rulebook_chain_matches_oracle(dev, batch):
+    """Bitmap-rank rulebooks down the four strided levels of the nuScenes encoder: every active set comes out sorted by
+    (b, y, x, z); compared with the oracle (i) as the order-free canonical pair sets of SURVEY 8a and (ii) exactly,
+    after renumbering the oracle's rows into the same sorted order."""
+    idx0 = _level1(batch=batch)
+    shape = SHAPE1
+    lvl, order, sidx = ops.bitmap_build(torch.from_numpy(idx0).to(dev), shape, batch)
+    order = order.cpu().numpy()
+    want_order = np.argsort(_sort_key(idx0, shape), kind="stable")
+    np.testing.assert_array_equal(order, want_order)
+    np.testing.assert_array_equal(sidx.cpu().numpy(), idx0[want_order])
+    idx = idx0[want_order]
+    # SubM on the sorted rows: identical to the oracle run on the same (sorted) rows
+    nbr, cnt = O.rulebook_subm(idx, shape, [3, 3, 3])
+    gn, gc = ops.rulebook_subm_bitmap(sidx, lvl, [3, 3, 3])
+    np.testing.assert_array_equal(gn.cpu().numpy(), nbr)
+    np.testing.assert_array_equal(gc.cpu().numpy(), cnt)
+    specs = [([3, 3, 3], [2, 2, 2], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [0, 1, 1]),
+             ([3, 1, 1], [2, 1, 1], [0, 0, 0])]
+    g_idx = sidx
+    for ks, st, pd in specs:
+        oi, onbr, ocnt, osh = O.rulebook_strided(idx, shape, ks, st, pd)
+        gi, gn, gc, out_lvl, gsh = ops.rulebook_strided_bitmap(g_idx, lvl, ks, st, pd)
+        assert gsh == osh
+        gi_np = gi.cpu().numpy()
+        key = _sort_key(gi_np, osh)
+        assert np.all(np.diff(key) > 0)                       # sorted, distinct
+        # the oracle's outputs are in first-seen order: renumber them into sorted order and compare exactly
+        perm = np.argsort(_sort_key(oi, osh), kind="stable")
+        np.testing.assert_array_equal(gi_np, oi[perm])
+        np.testing.assert_array_equal(gn.cpu().numpy(), onbr[:, perm])
+        np.testing.assert_array_equal(gc.cpu().numpy(), ocnt)
+        for a, b in zip(_canon(gn.cpu().numpy(), idx, gi_np), _canon(onbr, idx, oi)):
+            np.testing.assert_array_equal(a, b)
+        # SubM on the new level through its bitmap
+        sn, sc = O.rulebook_subm(gi_np, osh, [3, 3, 3])
+        gsn, gsc = ops.rulebook_subm_bitmap(gi, out_lvl, [3, 3, 3])
+        np.testing.assert_array_equal(gsn.cpu().numpy(), sn)
+        np.testing.assert_array_equal(gsc.cpu().numpy(), sc)
+        idx, shape, g_idx, lvl = gi_np, osh, gi, out_lvl
+
+
+def test_bitmap_rulebook_empty_and_corner(dev):
+    e = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+    lvl, order, sidx = ops.bitmap_build(e, SHAPE1, 1)
+    gn, gc = ops.rulebook_subm_bitmap(sidx, lvl, [3, 3, 3])
+    assert gn.shape == (27, 0) and int(gc.sum()) == 0
+    gi, gn, gc, _, _ = ops.rulebook_strided_bitmap(sidx, lvl, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    assert gi.shape[0] == 0 and gn.shape == (27, 0)
+    one = np.array([[0, 40, 1471, 1471], [0, 0, 0, 0]], np.int32)  # far and near corner voxels
+    lvl, order, sidx = ops.bitmap_build(torch.from_numpy(one).to(dev), SHAPE1, 1)
+    np.testing.assert_array_equal(order.cpu().numpy(), [1, 0])
+    oi, nbr, cnt, osh = O.rulebook_strided(one[[1, 0]], SHAPE1, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    gi, gn, gc, _, _ = ops.rulebook_strided_bitmap(sidx, lvl, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    perm = np.argsort(_sort_key(oi, osh), kind="stable")
+    np.testing.assert_array_equal(gi.cpu().numpy(), oi[perm])
+    np.testing.assert_array_equal(gn.cpu().numpy(), nbr[:, perm])
