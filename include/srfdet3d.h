@@ -46,6 +46,9 @@ int srf_device_count(void);
  * strided conv's output bitmap emits the new active set already sorted (a canonical order: independent of scheduling).
  * cell = ((b*H + y)*W + x)*D + z.  shape = host {D,H,W}.  bitmap: srf_bitmap_words() uint32; prefix: as many ints. */
 size_t srf_bitmap_words(const int *shape, int batch);
+/* ints a pair_counts buffer of the srf_bitmap_* entry points must hold: the K counts come first, the rest is scratch
+ * (replicated counters: hundreds of workgroups adding to one address would serialise in L2) */
+size_t srf_bitmap_pair_count_ints(void);
 size_t srf_bitmap_workspace_bytes(size_t words);
 /* marks `indices` (A x 4 (b,z,y,x), distinct), ranks them; order[r] = original row of sorted row r and
  * sorted_indices[r] = its coordinate (both optional, pass NULL for rows that are already sorted) */
@@ -59,10 +62,12 @@ int srf_bitmap_rulebook_subm(const int *sorted_indices, int A, const int *shape,
 int srf_bitmap_strided_outputs(const int *indices, int A, const int *shape, int batch, const int *ksize, const int *stride,
                                const int *pad, void *out_bitmap, int *out_prefix, int *out_indices, int out_capacity,
                                int *num_out, void *workspace, size_t workspace_bytes, srf_stream_t stream);
-/* phase 2: nbr (K x A_out) from the INPUT level's bitmap + prefix */
-int srf_bitmap_strided_pairs(const int *out_indices, int A_out, const int *shape, int batch, const int *ksize,
-                             const int *stride, const int *pad, const void *in_bitmap, const int *in_prefix, int *nbr,
-                             int *pair_counts, srf_stream_t stream);
+/* phase 2: nbr (K rows of nbr_stride ints; columns >= *num_out untouched) from the INPUT level's bitmap + prefix.  The
+ * number of outputs is read on the device (num_out, as written by phase 1), so this launch need not wait for the host;
+ * max_out bounds the grid (the out_capacity of phase 1) */
+int srf_bitmap_strided_pairs(const int *out_indices, const int *num_out, int max_out, const int *shape, int batch,
+                             const int *ksize, const int *stride, const int *pad, const void *in_bitmap, const int *in_prefix,
+                             int *nbr, int nbr_stride, int *pair_counts, srf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K2  dynamic voxelization.

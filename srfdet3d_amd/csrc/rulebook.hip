@@ -359,33 +359,6 @@ struct BmPrefix {
     __device__ void operator()(int w, int, int pre) const { prefix[w] = pre; }
 };
 
-// prefix + the sorted coordinate list of the set bits (at most cap rows are written)
-struct BmEmit {
-    const uint32_t *bitmap;
-    int *prefix;
-    int4 *out;
-    int D, H, W, cap;
-    __device__ void operator()(int w, int v, int pre) const
-    {
-        prefix[w] = pre;
-        if (!v) return;
-        uint32_t bits = bitmap[w];
-        int m = pre;
-        while (bits) {
-            const int b = __ffs(bits) - 1;
-            bits &= bits - 1;
-            uint32_t cell = ((uint32_t)w << 5) | (uint32_t)b;
-            const int z = (int)(cell % (uint32_t)D);
-            cell /= (uint32_t)D;
-            const int x = (int)(cell % (uint32_t)W);
-            cell /= (uint32_t)W;
-            const int y = (int)(cell % (uint32_t)H);
-            if (m < cap) out[m] = make_int4((int)(cell / (uint32_t)H), z, y, x);
-            ++m;
-        }
-    }
-};
-
 __global__ __launch_bounds__(256) void srf_bm_place_k(const int4 *__restrict__ indices, int A, ConvGeom g,
                                                     const uint32_t *__restrict__ bitmap, const int *__restrict__ prefix,
                                                     int *__restrict__ order, int4 *__restrict__ sorted)
@@ -400,70 +373,144 @@ __global__ __launch_bounds__(256) void srf_bm_place_k(const int4 *__restrict__ i
     }
 }
 
+#define SRF_BM_REPLICAS 32
+// pairs of this workgroup (one kernel offset per workgroup): wave popcounts -> LDS -> ONE global atomic per workgroup.
+// Must be reached by every thread of the block.
+__device__ __forceinline__ void srf_bm_count(bool hit, int k, int *pair_counts)
+{
+    __shared__ int s_cnt[4];
+    const unsigned long long m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        // SRF_BM_REPLICAS counters per offset: hundreds of workgroups adding to ONE address serialise in L2
+        if (c) atomicAdd(&pair_counts[(blockIdx.x % SRF_BM_REPLICAS) * SRF_MAX_K + k], c);
+    }
+}
+
+__global__ __launch_bounds__(64) void srf_bm_fold_counts_k(const int *__restrict__ replicas, int K, int *__restrict__ pair_counts)
+{
+    const int k = threadIdx.x;
+    if (k >= K) return;
+    int s = 0;
+    for (int r = 0; r < SRF_BM_REPLICAS; ++r) s += replicas[r * SRF_MAX_K + k];
+    pair_counts[k] = s;
+}
+
+// grid = (ceil(A / 256), K): the kernel offset is uniform per workgroup (scalar index arithmetic, no divisions)
 __global__ __launch_bounds__(256) void srf_bm_subm_k(const int4 *__restrict__ indices, int A, ConvGeom g,
                                                    const uint32_t *__restrict__ bitmap, const int *__restrict__ prefix,
                                                    int *__restrict__ nbr, int *pair_counts)
 {
-    __shared__ int hist[SRF_MAX_K];
-    if (threadIdx.x < SRF_MAX_K) hist[threadIdx.x] = 0;
-    __syncthreads();
-    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int k = (int)(tid / A);
-    const int o = (int)(tid % A);
-    if (k < g.K) {
+    const int k = blockIdx.y;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    const int kx = k % g.ks[2], t = k / g.ks[2];
+    const int ky = t % g.ks[1], kz = t / g.ks[1];
+    int v = -1;
+    if (o < A) {
         const int4 c = indices[o];
-        const int kx = k % g.ks[2], t = k / g.ks[2];
-        const int ky = t % g.ks[1], kz = t / g.ks[1];
         const int z = c.y + kz - g.ks[0] / 2, y = c.z + ky - g.ks[1] / 2, x = c.w + kx - g.ks[2] / 2;
-        int v = -1;
         if (z >= 0 && z < g.shape[0] && y >= 0 && y < g.shape[1] && x >= 0 && x < g.shape[2])
             v = srf_bm_rank(bitmap, prefix, srf_bm_cell(c.x, z, y, x, g.shape));
         nbr[(size_t)k * A + o] = v;
-        if (v >= 0) atomicAdd(&hist[k], 1);
     }
-    __syncthreads();
-    if (threadIdx.x < g.K && hist[threadIdx.x]) atomicAdd(&pair_counts[threadIdx.x], hist[threadIdx.x]);
+    srf_bm_count(v >= 0, k, pair_counts);
 }
 
+__device__ __forceinline__ bool srf_div_stride(int v, int st, int &q)
+{
+    if ((st & (st - 1)) == 0) {  // 1, 2, 4: what the encoders use
+        if (v & (st - 1)) return false;
+        q = v >> (31 - __clz(st));
+        return true;
+    }
+    if (v % st) return false;
+    q = v / st;
+    return true;
+}
+
+// grid = (ceil(A / 256), K)
 __global__ __launch_bounds__(256) void srf_bm_strided_mark_k(const int4 *__restrict__ indices, int A, ConvGeom g,
                                                            uint32_t *obitmap)
 {
-    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (c >= (long long)A * g.K) return;
-    const int i = (int)(c / g.K), k = (int)(c % g.K);
+    const int k = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A) return;
+    const int kx = k % g.ks[2], t = k / g.ks[2];
+    const int ky = t % g.ks[1], kz = t / g.ks[1];
     const int4 ci = indices[i];
-    int q[3];
-    if (!srf_candidate(ci, k, g, q)) return;
-    const uint32_t cell = srf_bm_cell(ci.x, q[0], q[1], q[2], g.oshape);
+    int qz, qy, qx;
+    const int vz = ci.y + g.pd[0] - kz, vy = ci.z + g.pd[1] - ky, vx = ci.w + g.pd[2] - kx;
+    if (vz < 0 || vy < 0 || vx < 0) return;
+    if (!srf_div_stride(vz, g.st[0], qz) || !srf_div_stride(vy, g.st[1], qy) || !srf_div_stride(vx, g.st[2], qx)) return;
+    if (qz >= g.oshape[0] || qy >= g.oshape[1] || qx >= g.oshape[2]) return;
+    const uint32_t cell = srf_bm_cell(ci.x, qz, qy, qx, g.oshape);
     const uint32_t bit = 1u << (cell & 31);
     if (!(obitmap[cell >> 5] & bit)) atomicOr(&obitmap[cell >> 5], bit);  // most candidates find their cell marked already
 }
 
-// nbr[k][o] = row of the input site that offset k of output o reads, or -1
-__global__ __launch_bounds__(256) void srf_bm_strided_pairs_k(const int4 *__restrict__ out_indices, int A_out, ConvGeom g,
-                                                            const uint32_t *__restrict__ ibitmap,
+// sorted coordinate list of the set bits: one thread per bitmap word (most words are empty)
+__global__ __launch_bounds__(256) void srf_bm_emit_k(const uint32_t *__restrict__ bitmap, const int *__restrict__ prefix, int nwords,
+                                                   int D, int H, int W, int cap, int4 *__restrict__ out)
+{
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nwords) return;
+    uint32_t bits = bitmap[w];
+    if (!bits) return;
+    int m = prefix[w];
+    // decode the word's first cell with divisions, then walk: cells advance in z with carries into x, y, b
+    uint32_t cell = (uint32_t)w << 5;
+    int z = (int)(cell % (uint32_t)D);
+    cell /= (uint32_t)D;
+    int x = (int)(cell % (uint32_t)W);
+    cell /= (uint32_t)W;
+    int y = (int)(cell % (uint32_t)H);
+    int bb = (int)(cell / (uint32_t)H);
+    int at = 0;
+    while (bits) {
+        const int b = __ffs(bits) - 1;
+        bits &= bits - 1;
+        z += b - at;
+        at = b;
+        while (z >= D) {
+            z -= D;
+            if (++x == W) {
+                x = 0;
+                if (++y == H) {
+                    y = 0;
+                    ++bb;
+                }
+            }
+        }
+        if (m < cap) out[m] = make_int4(bb, z, y, x);
+        ++m;
+    }
+}
+
+// nbr[k][o] = row of the input site that offset k of output o reads, or -1.  grid = (ceil(capacity / 256), K); the number
+// of outputs is read from device memory, so the launch does not wait for the host to learn it
+__global__ __launch_bounds__(256) void srf_bm_strided_pairs_k(const int4 *__restrict__ out_indices, const int *__restrict__ num_out,
+                                                            int nbr_stride, ConvGeom g, const uint32_t *__restrict__ ibitmap,
                                                             const int *__restrict__ iprefix, int *__restrict__ nbr,
                                                             int *pair_counts)
 {
-    __shared__ int hist[SRF_MAX_K];
-    if (threadIdx.x < SRF_MAX_K) hist[threadIdx.x] = 0;
-    __syncthreads();
-    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int k = (int)(tid / A_out);
-    const int o = (int)(tid % A_out);
-    if (k < g.K) {
+    const int k = blockIdx.y;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    int A_out = *num_out;
+    A_out = A_out < nbr_stride ? A_out : nbr_stride;
+    if ((int)(blockIdx.x * 256) >= A_out) return;
+    const int kx = k % g.ks[2], t = k / g.ks[2];
+    const int ky = t % g.ks[1], kz = t / g.ks[1];
+    int v = -1;
+    if (o < A_out) {
         const int4 c = out_indices[o];
-        const int kx = k % g.ks[2], t = k / g.ks[2];
-        const int ky = t % g.ks[1], kz = t / g.ks[1];
         const int z = c.y * g.st[0] - g.pd[0] + kz, y = c.z * g.st[1] - g.pd[1] + ky, x = c.w * g.st[2] - g.pd[2] + kx;
-        int v = -1;
         if (z >= 0 && z < g.shape[0] && y >= 0 && y < g.shape[1] && x >= 0 && x < g.shape[2])
             v = srf_bm_rank(ibitmap, iprefix, srf_bm_cell(c.x, z, y, x, g.shape));
-        nbr[(size_t)k * A_out + o] = v;
-        if (v >= 0) atomicAdd(&hist[k], 1);
+        nbr[(size_t)k * nbr_stride + o] = v;
     }
-    __syncthreads();
-    if (threadIdx.x < g.K && hist[threadIdx.x]) atomicAdd(&pair_counts[threadIdx.x], hist[threadIdx.x]);
+    srf_bm_count(v >= 0, k, pair_counts);
 }
 
 static long long srf_bm_cells(const int *shape, int batch)
@@ -472,6 +519,8 @@ static long long srf_bm_cells(const int *shape, int batch)
     const unsigned long long c = (unsigned long long)batch * shape[0] * shape[1] * shape[2];
     return c < 0xFFFFFFFFull ? (long long)c : -1;
 }
+
+extern "C" size_t srf_bitmap_pair_count_ints(void) { return (size_t)SRF_MAX_K * (SRF_BM_REPLICAS + 1); }
 
 extern "C" size_t srf_bitmap_words(const int *shape, int batch)
 {
@@ -514,11 +563,12 @@ extern "C" int srf_bitmap_rulebook_subm(const int *sorted_indices, int A, const 
     for (int d = 0; d < 3; ++d)
         if (!(ksize[d] & 1)) return SRF_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    SRF_HIP_TRY(hipMemsetAsync(pair_counts, 0, sizeof(int) * g.K, st));
+    SRF_HIP_TRY(hipMemsetAsync(pair_counts, 0, sizeof(int) * SRF_MAX_K * (SRF_BM_REPLICAS + 1), st));
     if (A == 0) return SRF_OK;
     if (!sorted_indices || !nbr || !bitmap || !prefix) return SRF_EINVAL;
-    hipLaunchKernelGGL(srf_bm_subm_k, dim3(srf_ceil_div((long long)A * g.K, 256)), dim3(256), 0, st, (const int4 *)sorted_indices, A,
-                       g, (const uint32_t *)bitmap, prefix, nbr, pair_counts);
+    hipLaunchKernelGGL(srf_bm_subm_k, dim3(srf_ceil_div(A, 256), g.K), dim3(256), 0, st, (const int4 *)sorted_indices, A, g,
+                       (const uint32_t *)bitmap, prefix, nbr, pair_counts + SRF_MAX_K);
+    hipLaunchKernelGGL(srf_bm_fold_counts_k, dim3(1), dim3(64), 0, st, pair_counts + SRF_MAX_K, g.K, pair_counts);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }
@@ -539,28 +589,32 @@ extern "C" int srf_bitmap_strided_outputs(const int *indices, int A, const int *
     SRF_HIP_TRY(hipMemsetAsync(out_bitmap, 0, words * 4, st));
     if (A > 0) {
         if (!indices || !out_indices) return SRF_EINVAL;
-        hipLaunchKernelGGL(srf_bm_strided_mark_k, dim3(srf_ceil_div((long long)A * g.K, 256)), dim3(256), 0, st,
-                           (const int4 *)indices, A, g, (uint32_t *)out_bitmap);
+        hipLaunchKernelGGL(srf_bm_strided_mark_k, dim3(srf_ceil_div(A, 256), g.K), dim3(256), 0, st, (const int4 *)indices, A, g,
+                           (uint32_t *)out_bitmap);
     }
-    return srf_device_scan((int)words, BmPop{(const uint32_t *)out_bitmap},
-                           BmEmit{(const uint32_t *)out_bitmap, out_prefix, (int4 *)out_indices, g.oshape[0], g.oshape[1], g.oshape[2],
-                                  out_capacity},
-                           (int *)workspace, num_out, -1, st);
+    int rc = srf_device_scan((int)words, BmPop{(const uint32_t *)out_bitmap}, BmPrefix{out_prefix}, (int *)workspace, num_out, -1, st);
+    if (rc) return rc;
+    if (A > 0)
+        hipLaunchKernelGGL(srf_bm_emit_k, dim3(srf_ceil_div((long long)words, 256)), dim3(256), 0, st, (const uint32_t *)out_bitmap,
+                           out_prefix, (int)words, g.oshape[0], g.oshape[1], g.oshape[2], out_capacity, (int4 *)out_indices);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
 }
 
-extern "C" int srf_bitmap_strided_pairs(const int *out_indices, int A_out, const int *shape, int batch, const int *ksize,
-                                        const int *stride, const int *pad, const void *in_bitmap, const int *in_prefix, int *nbr,
-                                        int *pair_counts, srf_stream_t stream)
+extern "C" int srf_bitmap_strided_pairs(const int *out_indices, const int *num_out, int max_out, const int *shape, int batch,
+                                        const int *ksize, const int *stride, const int *pad, const void *in_bitmap,
+                                        const int *in_prefix, int *nbr, int nbr_stride, int *pair_counts, srf_stream_t stream)
 {
     ConvGeom g;
-    if (A_out < 0 || !shape || !ksize || !stride || !pad || !pair_counts) return SRF_EINVAL;
+    if (max_out < 0 || nbr_stride < max_out || !shape || !ksize || !stride || !pad || !pair_counts || !num_out) return SRF_EINVAL;
     if (!srf_fill_conv_geom(g, shape, ksize, stride, pad, batch)) return SRF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    SRF_HIP_TRY(hipMemsetAsync(pair_counts, 0, sizeof(int) * g.K, st));
-    if (A_out == 0) return SRF_OK;
+    SRF_HIP_TRY(hipMemsetAsync(pair_counts, 0, sizeof(int) * SRF_MAX_K * (SRF_BM_REPLICAS + 1), st));
+    if (max_out == 0) return SRF_OK;
     if (!out_indices || !nbr || !in_bitmap || !in_prefix) return SRF_EINVAL;
-    hipLaunchKernelGGL(srf_bm_strided_pairs_k, dim3(srf_ceil_div((long long)A_out * g.K, 256)), dim3(256), 0, st,
-                       (const int4 *)out_indices, A_out, g, (const uint32_t *)in_bitmap, in_prefix, nbr, pair_counts);
+    hipLaunchKernelGGL(srf_bm_strided_pairs_k, dim3(srf_ceil_div(max_out, 256), g.K), dim3(256), 0, st, (const int4 *)out_indices,
+                       num_out, nbr_stride, g, (const uint32_t *)in_bitmap, in_prefix, nbr, pair_counts + SRF_MAX_K);
+    hipLaunchKernelGGL(srf_bm_fold_counts_k, dim3(1), dim3(64), 0, st, pair_counts + SRF_MAX_K, g.K, pair_counts);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

@@ -218,10 +218,10 @@ def rulebook_subm_bitmap(sorted_indices, level, ksize):
     A = sorted_indices.shape[0]
     K = int(np.prod(ksize))
     nbr = _empty((K, max(A, 1)), torch.int32, sorted_indices.device)
-    counts = _empty((K,), torch.int32, sorted_indices.device)
+    counts = _empty((_lib.lib().srf_bitmap_pair_count_ints(),), torch.int32, sorted_indices.device)
     check(_lib.lib().srf_bitmap_rulebook_subm(_ptr(sorted_indices), A, hi(level.shape), level.batch, hi(ksize), _ptr(level.bitmap),
                                               _ptr(level.prefix), _ptr(nbr), _ptr(counts), _stream()), "bitmap_rulebook_subm")
-    return nbr[:, :A], counts
+    return nbr[:, :A], counts[:K]
 
 
 def rulebook_strided_bitmap(indices, level, ksize, stride, pad):
@@ -243,13 +243,16 @@ def rulebook_strided_bitmap(indices, level, ksize, stride, pad):
     check(L.srf_bitmap_strided_outputs(_ptr(indices), A, hi(level.shape), level.batch, hi(ksize), hi(stride), hi(pad),
                                        _ptr(out_lvl.bitmap), _ptr(out_lvl.prefix), _ptr(out_idx), bound, _ptr(num_out), _ptr(ws),
                                        nbytes, _stream()), "bitmap_strided_outputs")
-    A_out = int(num_out.item())
-    nbr = _empty((K, max(A_out, 1)), torch.int32, dev)
-    counts = _empty((K,), torch.int32, dev)
-    check(L.srf_bitmap_strided_pairs(_ptr(out_idx), A_out, hi(level.shape), level.batch, hi(ksize), hi(stride), hi(pad),
-                                     _ptr(level.bitmap), _ptr(level.prefix), _ptr(nbr), _ptr(counts), _stream()),
+    # phase 2 reads the count on the device: it is enqueued before the host learns A_out, so the read-back below
+    # overlaps it instead of leaving the GPU idle
+    cap = max(bound, 1)
+    nbr = _empty((K, cap), torch.int32, dev)
+    counts = _empty((L.srf_bitmap_pair_count_ints(),), torch.int32, dev)
+    check(L.srf_bitmap_strided_pairs(_ptr(out_idx), _ptr(num_out), bound, hi(level.shape), level.batch, hi(ksize), hi(stride),
+                                     hi(pad), _ptr(level.bitmap), _ptr(level.prefix), _ptr(nbr), cap, _ptr(counts), _stream()),
           "bitmap_strided_pairs")
-    return out_idx[:A_out], nbr[:, :A_out], counts, out_lvl, oshape
+    A_out = int(num_out.item())
+    return out_idx[:A_out], nbr[:, :A_out], counts[:K], out_lvl, oshape
 
 
 # ---------------------------------------------------------------------------------------------- sparse conv

@@ -84,6 +84,24 @@ def install():
         return 16 * A_in + 4 * K * A_in + 16 * A_out + 4 * K * A_out, 0, None
     _wrap("rulebook_strided", "hbm", w_strided)
 
+    def w_bm(a, k, out):
+        lvl = out[0]
+        return 2 * 4 * lvl.words * 2 + 16 * a[0].shape[0] * 2 + 4 * a[0].shape[0], 0, None
+    _wrap("bitmap_build", "hbm", w_bm)
+
+    def w_subm_bm(a, k, out):
+        A = a[0].shape[0]
+        K = a[2][0] * a[2][1] * a[2][2]
+        return 16 * A + 4 * K * A, 0, None
+    _wrap("rulebook_subm_bitmap", "hbm", w_subm_bm)
+
+    def w_strided_bm(a, k, out):
+        A_in = a[0].shape[0]
+        K = a[2][0] * a[2][1] * a[2][2]
+        A_out = out[0].shape[0]
+        return 16 * A_in + 2 * 4 * out[3].words * 2 + 16 * A_out + 4 * K * A_out, 0, None
+    _wrap("rulebook_strided_bitmap", "hbm", w_strided_bm)
+
     def w_spconv(a, k, out):
         feats, weight, nbr = a[0], a[1], a[2]
         K, Cin, Cout = weight.shape
