@@ -12,7 +12,15 @@ from . import _lib
 from ._lib import FeatMap, check, hf, hi
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream.  torch.cuda.current_stream() costs ~9 us of Python per call (35 calls per
+    frame); the raw accessor the graph-capture machinery itself uses is ~30x cheaper."""
+    if _raw_stream is not None and _cur_device is not None:
+        return ctypes.c_void_p(_raw_stream(_cur_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
