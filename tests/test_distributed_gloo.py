@@ -3,6 +3,7 @@
 import os
 import socket
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -30,7 +31,9 @@ def _worker(rank, world, port, q):
     frames = list(range(rank, 10, world))
     t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    q.put((rank, y.detach(), bn.running_mean.clone(), bn.running_var.clone(), x.grad.clone(), frames, t.item()))
+    # numpy (pickled by value): torch tensors travel through /dev/shm files that disappear if this process exits first
+    q.put((rank, y.detach().numpy(), bn.running_mean.numpy().copy(), bn.running_var.numpy().copy(), x.grad.numpy().copy(), frames,
+           t.item()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -44,6 +47,7 @@ def test_sync_bn_and_sharding_two_ranks():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    res = [tuple(torch.from_numpy(v) if isinstance(v, np.ndarray) else v for v in r) for r in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
