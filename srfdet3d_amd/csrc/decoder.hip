@@ -418,11 +418,35 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
     float *img_h = img_obj + 4 * 1024;    // 4 chunks: one 128-wide slice of the FFN hidden layer / tower activations
     float *s_w = img_h + 4 * 1024;        // one weight block (4 chunks x 128 cols)
     float(*s_out)[LIN_TN + 4] = reinterpret_cast<float(*)[LIN_TN + 4]>(s_w + 4 * LIN_TN * 32);
+    // every bias / LayerNorm vector of the chain, fetched ONCE up front: read from global inside the chain each of the
+    // 15 dependent blocks would pay an L2 round trip for them
+    float *s_par = reinterpret_cast<float *>(s_out) + 32 * (LIN_TN + 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * 32;
     const int C = TAIL_C, F = tw.F;
+    float *p_b1 = s_par, *p_b2 = p_b1 + 4 * LIN_TN, *p_n3g = p_b2 + C, *p_n3b = p_n3g + C;
+    float *p_tw = p_n3b + C;                                 // towers: [cls g, b] x 4, [reg g, b] x 4
+    float *p_bl = p_tw + 4 * TAIL_MAX_TOWER * C, *p_bd = p_bl + 32;
     TailBlock blk;
     srf_tail_load(blk, tw.w1, C, 0, F, 0);
+    for (int e = tid; e < F; e += 256) p_b1[e] = tw.b1[e];
+    if (tid < C) {
+        p_b2[tid] = tw.b2[tid];
+        p_n3g[tid] = tw.n3_g[tid];
+        p_n3b[tid] = tw.n3_b[tid];
+        for (int l = 0; l < tw.n_cls; ++l) {
+            p_tw[(2 * l) * C + tid] = tw.cls_g[l][tid];
+            p_tw[(2 * l + 1) * C + tid] = tw.cls_b[l][tid];
+        }
+        for (int l = 0; l < tw.n_reg; ++l) {
+            p_tw[(2 * TAIL_MAX_TOWER + 2 * l) * C + tid] = tw.reg_g[l][tid];
+            p_tw[(2 * TAIL_MAX_TOWER + 2 * l + 1) * C + tid] = tw.reg_b[l][tid];
+        }
+    } else if (tid < C + 32) {
+        const int i = tid - C;
+        p_bl[i] = i < tw.ncls ? tw.bl[i] : 0.f;
+        p_bd[i] = i < tw.Dd ? tw.bd[i] : 0.f;
+    }
     {  // obj tile -> image
         const int r = tid >> 3, q = tid & 7, row = row0 + r;
 #pragma unroll
@@ -445,7 +469,7 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
         __syncthreads();
         for (int e = tid; e < 32 * LIN_TN; e += 256) {
             const int r = e >> 7, c = e & (LIN_TN - 1);
-            const float v = s_out[r][c] + tw.b1[n0 + c];
+            const float v = s_out[r][c] + p_b1[n0 + c];
             s_out[r][c] = v > 0.f ? v : 0.f;
         }
         __syncthreads();
@@ -462,7 +486,7 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
     srf_tail_spill(acc2, s_out);
     __syncthreads();
     {
-        RowEpilogue ep = {tw.b2, nullptr, nullptr, obj_in, tw.n3_g, tw.n3_b, C, 0, 0, 0.f, tw.eps_n3};
+        RowEpilogue ep = {p_b2, nullptr, nullptr, obj_in, p_n3g, p_n3b, C, 0, 0, 0.f, tw.eps_n3};
         for (int r = wave * 8; r < wave * 8 + 8; ++r) {
             const int row = row0 + r;
             float v[2] = {s_out[r][lane], s_out[r][lane + 64]};
@@ -499,8 +523,8 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
             srf_tail_spill(acc, s_out);
             __syncthreads();
             if (l < nl) {
-                RowEpilogue ep = {nullptr, tower == 0 ? tw.cls_g[l] : tw.reg_g[l], tower == 0 ? tw.cls_b[l] : tw.reg_b[l], nullptr,
-                                  nullptr, nullptr, 0, 1, 0, tower == 0 ? tw.eps_cls[l] : tw.eps_reg[l], 0.f};
+                const float *pg = p_tw + (2 * TAIL_MAX_TOWER * tower + 2 * l) * C;
+                RowEpilogue ep = {nullptr, pg, pg + C, nullptr, nullptr, nullptr, 0, 1, 0, tower == 0 ? tw.eps_cls[l] : tw.eps_reg[l], 0.f};
                 for (int r = wave * 8; r < wave * 8 + 8; ++r) {
                     float v[2] = {s_out[r][lane], s_out[r][lane + 64]};
                     srf_row_epilogue<2>(v, C, lane, row0 + r, ep);
@@ -513,7 +537,7 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
             } else if (tower == 0) {
                 for (int e = tid; e < 32 * N; e += 256) {
                     const int r = e / N, c = e % N, row = row0 + r;
-                    if (row < R) logits[(size_t)row * N + c] = s_out[r][c] + tw.bl[c];
+                    if (row < R) logits[(size_t)row * N + c] = s_out[r][c] + p_bl[c];
                 }
             } else if (tid < 32 && row0 + tid < R) {
                 const int row = row0 + tid;
@@ -522,14 +546,14 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const float size = expf(b[3 + i]);
-                    const float ctr = ((s_out[tid][i] + tw.bd[i]) / g.w[i]) * size + b[i];
+                    const float ctr = ((s_out[tid][i] + p_bd[i]) / g.w[i]) * size + b[i];
                     float n = (ctr - g.lo[i]) / g.ext[i];
                     o[i] = n < 0.f ? 0.f : (n > 1.f ? 1.f : n);
-                    float ds = (s_out[tid][3 + i] + tw.bd[3 + i]) / g.w[3 + i];
+                    float ds = (s_out[tid][3 + i] + p_bd[3 + i]) / g.w[3 + i];
                     ds = ds > g.clamp ? g.clamp : ds;
                     o[3 + i] = logf(expf(ds) * size);
                 }
-                for (int i = 6; i < N; ++i) o[i] = s_out[tid][i] + tw.bd[i];
+                for (int i = 6; i < N; ++i) o[i] = s_out[tid][i] + p_bd[i];
             }
             __syncthreads();
         }
@@ -841,7 +865,8 @@ extern "C" int srf_stage_tail(const float *obj_in, int R, int C, int F, const fl
         g.ext[i] = pc_range[3 + i] - pc_range[i];
     }
     g.clamp = scale_clamp;
-    const size_t sh = sizeof(float) * (4 * 1024 + 4 * 1024 + 4 * LIN_TN * 32 + 32 * (LIN_TN + 4));  // 113 KB
+    const size_t sh = sizeof(float) * (4 * 1024 + 4 * 1024 + 4 * LIN_TN * 32 + 32 * (LIN_TN + 4) + 4 * LIN_TN + 3 * TAIL_C +
+                                       4 * TAIL_MAX_TOWER * TAIL_C + 64);  // 125 KB
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
         SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_stage_tail_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));

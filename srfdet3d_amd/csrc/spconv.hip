@@ -747,6 +747,82 @@ __global__ __launch_bounds__(256) void srf_spconv_mfma16_k(const float *__restri
     }
 }
 
+// COUT = 16, Cin <= 16 (the 41 x 1472 x 1472 level: conv_input and the first two basic blocks).  These layers are bound by
+// the gathers, not by arithmetic (27 x 64 B per output row out of L2), so the kernel has no LDS and no barriers at all:
+// a wave owns 16 output rows; its B operands -- all K x Cin x 16 weights, STEPS*K registers per lane -- are loaded once
+// and stay in registers; the neighbour indices of all offsets are fetched up front, and the gathered A operands go
+// global -> registers in MFMA order (v_mfma_f32_16x16x4_f32: lane (row, q) supplies channel 4j + q of step j), nine
+// offsets in flight at a time.  Accumulation order as everywhere: offset ascending, channel ascending.
+template <int STEPS>  // ceil(Cin / 4)
+__global__ __launch_bounds__(256) void srf_spconv_c16_k(const float *__restrict__ in, int Cin, const float *__restrict__ W, int K,
+                                                      const int *__restrict__ nbr, int nbr_stride, int A_out,
+                                                      const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                      const float *__restrict__ residual, int relu, float *__restrict__ out)
+{
+    constexpr int COUT = 16, KM = SRF_KMAX, G = 9;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = (blockIdx.x * 4 + wave) * 16;
+    if (row0 >= A_out) return;  // no barriers in this kernel: waves are independent
+    const int r = lane & 15, q = lane >> 4;
+    const int row = row0 + r;
+    // weights: lane (col = r, q) holds W[k][4j + q][col]
+    float wreg[KM][STEPS];
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int j = 0; j < STEPS; ++j) {
+            const int c = 4 * j + q;
+            wreg[k][j] = (k < K && c < Cin) ? W[((size_t)k * Cin + c) * COUT + r] : 0.f;
+        }
+    int idx[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) idx[k] = (k < K && row < A_out) ? nbr[(size_t)k * nbr_stride + row] : -1;
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float a[2][G][STEPS];
+#pragma unroll
+    for (int t = 0; t < G; ++t)
+#pragma unroll
+        for (int j = 0; j < STEPS; ++j) {
+            const int c = 4 * j + q;
+            a[0][t][j] = (idx[t] >= 0 && c < Cin) ? in[(size_t)idx[t] * Cin + c] : 0.f;  // predicated: 9 of 10 neighbours are absent here
+        }
+#pragma unroll
+    for (int g0 = 0; g0 < KM; g0 += G) {
+        const int cur = (g0 / G) & 1;
+        if (g0 + G < KM) {
+#pragma unroll
+            for (int t = 0; t < G; ++t)
+#pragma unroll
+                for (int j = 0; j < STEPS; ++j) {
+                    const int k = g0 + G + t, c = 4 * j + q;
+                    a[cur ^ 1][t][j] = (idx[k] >= 0 && c < Cin) ? in[(size_t)idx[k] * Cin + c] : 0.f;
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < G; ++t) {
+            const int k = g0 + t;
+#pragma unroll
+            for (int j = 0; j < STEPS; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][t][j], wreg[k][j], acc, 0, 0, 0);
+            }
+        }
+    }
+    // C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + i
+    const float al = alpha ? alpha[r] : 1.f, be = alpha ? beta[r] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int orow = row0 + q * 4 + i;
+        if (orow < A_out) {
+            float v = acc[i];
+            if (alpha) v = __fmaf_rn(v, al, be);
+            if (residual) v = __fadd_rn(v, residual[(size_t)orow * COUT + r]);
+            if (relu) v = v > 0.f ? v : 0.f;
+            out[(size_t)orow * COUT + r] = v;
+        }
+    }
+}
+
 extern "C" int srf_spconv_fwd(const float *in, int A_in, int Cin, const float *W, int K, const int *nbr, int nbr_stride,
                               int A_out, int Cout, const float *alpha, const float *beta, const float *residual,
                               int relu, float *out, srf_stream_t stream)
@@ -760,8 +836,15 @@ extern "C" int srf_spconv_fwd(const float *in, int A_in, int Cin, const float *W
 #define SRF_ARGS in, Cin, W, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out
     switch (Cout) {
     case 16:
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_mfma16_k<64>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0, st,
-                           SRF_ARGS);
+        if (Cin <= 16 && K == SRF_KMAX && A_in > 0) {  // register-resident weights, LDS-free gather
+            if (Cin <= 8)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_c16_k<2>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0, st, SRF_ARGS);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_c16_k<4>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0, st, SRF_ARGS);
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_mfma16_k<64>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0, st,
+                               SRF_ARGS);
+        }
         break;
     case 32:
         hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_mfma32_k<32, 128, 4, 1>), dim3(srf_ceil_div(A_out, 128)), dim3(256),
