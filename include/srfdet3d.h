@@ -50,7 +50,8 @@ size_t srf_bitmap_words(const int *shape, int batch);
  * (replicated counters: hundreds of workgroups adding to one address would serialise in L2) */
 size_t srf_bitmap_pair_count_ints(void);
 size_t srf_bitmap_workspace_bytes(size_t words);
-/* marks `indices` (A x 4 (b,z,y,x), distinct), ranks them; order[r] = original row of sorted row r and
+/* marks `indices` (A x 4 (b,z,y,x), distinct; rows with b < 0 are padding and are skipped by every srf_bitmap_* entry
+ * point and by srf_densify), ranks them; order[r] = original row of sorted row r and
  * sorted_indices[r] = its coordinate (both optional, pass NULL for rows that are already sorted) */
 int srf_bitmap_build(const int *indices, int A, const int *shape, int batch, void *bitmap, int *prefix, int *order,
                      int *sorted_indices, void *workspace, size_t workspace_bytes, srf_stream_t stream);
@@ -62,12 +63,14 @@ int srf_bitmap_rulebook_subm(const int *sorted_indices, int A, const int *shape,
 int srf_bitmap_strided_outputs(const int *indices, int A, const int *shape, int batch, const int *ksize, const int *stride,
                                const int *pad, void *out_bitmap, int *out_prefix, int *out_indices, int out_capacity,
                                int *num_out, void *workspace, size_t workspace_bytes, srf_stream_t stream);
-/* phase 2: nbr (K rows of nbr_stride ints; columns >= *num_out untouched) from the INPUT level's bitmap + prefix.  The
- * number of outputs is read on the device (num_out, as written by phase 1), so this launch need not wait for the host;
- * max_out bounds the grid (the out_capacity of phase 1) */
+/* phase 2: nbr (K rows of nbr_stride ints) from the INPUT level's bitmap + prefix.  The number of outputs is read on
+ * the device (num_out, as written by phase 1), so this launch need not wait for the host; max_out bounds the grid (the
+ * out_capacity of phase 1).  Columns >= *num_out are left untouched, or set to -1 when fill_tail != 0 (static-shape
+ * levels: rows >= *num_out are padding whose coordinates are -1 and which every kernel here skips).  in_rows = rows of
+ * the input level's arrays: ranks beyond it (possible only after a capacity overflow upstream) become -1. */
 int srf_bitmap_strided_pairs(const int *out_indices, const int *num_out, int max_out, const int *shape, int batch,
                              const int *ksize, const int *stride, const int *pad, const void *in_bitmap, const int *in_prefix,
-                             int *nbr, int nbr_stride, int *pair_counts, srf_stream_t stream);
+                             int in_rows, int *nbr, int nbr_stride, int fill_tail, int *pair_counts, srf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K2  dynamic voxelization.
@@ -150,10 +153,12 @@ int srf_rulebook_strided_pairs(int A, const int *ksize, const void *out_table, i
  * out[o] = sum_k W[k]^T in[nbr[k][o]] accumulated as an f32 fma chain (k ascending, c ascending);
  * then y = fma(x, alpha, beta) if alpha, y += residual[o] if residual, y = max(y,0) if relu.
  * W: (K, Cin, Cout) row-major.  Supported Cout: 16 (any Cin <= 512) and 32, 64, 128 (Cin a multiple of 4).
+ * rows_dev (may be NULL): device int; output rows >= *rows_dev are padding of a static-shape level and are skipped
+ * (their tiles return at once), so a hipGraph can launch the layer at its capacity without paying for it.
  * ------------------------------------------------------------------------------------------------------- */
 int srf_spconv_fwd(const float *in, int A_in, int Cin, const float *W, int K, const int *nbr, int nbr_stride,
                    int A_out, int Cout, const float *alpha, const float *beta, const float *residual, int relu,
-                   float *out, srf_stream_t stream);
+                   float *out, const int *rows_dev, srf_stream_t stream);
 
 /* Fast path of K5 for constant weights: re-lay W once (srf_spconv_pack_weights -> packed, of
  * srf_spconv_packed_weight_bytes bytes) into the LDS operand image of the kernel, then call srf_spconv_fwd_packed with
@@ -162,7 +167,8 @@ size_t srf_spconv_packed_weight_bytes(int K, int Cin, int Cout);
 int srf_spconv_pack_weights(const float *W, int K, int Cin, int Cout, float *packed, srf_stream_t stream);
 int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const float *W_packed, int K, const int *nbr,
                           int nbr_stride, int A_out, int Cout, const float *alpha, const float *beta,
-                          const float *residual, int relu, float *out, srf_stream_t stream);
+                          const float *residual, int relu, float *out, const int *rows_dev,
+                         srf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K6  SparseConvTensor.dense() (+ the view to (B, C*D, H, W), which is a no-op on this layout).

@@ -65,6 +65,29 @@ __device__ __forceinline__ int srf_table_find(const uint32_t *__restrict__ keys,
 }
 
 // ---------------------------------------------------------------------------------------------
+// device fill.  A kernel, not hipMemsetAsync: memset NODES of a captured hipGraph stopped taking effect on replay once
+// other work had run between replays (ROCm 7.2; the whole-frame graph then saw stale hash tables), and a kernel node
+// costs the same.  nbytes must be a multiple of 4 and ptr 4-byte aligned (every use here is).
+// ---------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void srf_fill_words_k(uint32_t *__restrict__ p, uint32_t v, size_t nwords)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride) p[i] = v;
+}
+
+static inline hipError_t srf_fill_bytes(void *ptr, int byte, size_t nbytes, hipStream_t st)
+{
+    if (nbytes == 0) return hipSuccess;
+    if ((nbytes & 3) || ((uintptr_t)ptr & 3)) return hipMemsetAsync(ptr, byte, nbytes, st);
+    const uint32_t b = (uint32_t)(byte & 0xFF);
+    const size_t nwords = nbytes >> 2;
+    size_t blocks = (nwords + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(srf_fill_words_k, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t *)ptr, b * 0x01010101u, nwords);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // wave / block scans (256-thread blocks)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int srf_wave_inclusive_scan(int v)

@@ -164,7 +164,7 @@ extern "C" int srf_nms_rotated(const float *boxes, int n, float iou_threshold, i
     if (workspace_bytes < srf_nms_rotated_workspace_bytes(n)) return SRF_EWORKSPACE;
     const int words = (n + 63) / 64;
     hipStream_t st = (hipStream_t)stream;
-    SRF_HIP_TRY(hipMemsetAsync(workspace, 0, srf_nms_rotated_workspace_bytes(n), st));
+    SRF_HIP_TRY(srf_fill_bytes(workspace, 0, srf_nms_rotated_workspace_bytes(n), st));
     hipLaunchKernelGGL(srf_nms_mask_k, dim3(words, words), dim3(64), 0, st, boxes, n, iou_threshold,
                        (unsigned long long *)workspace, words);
     hipLaunchKernelGGL(srf_nms_reduce_k, dim3(1), dim3(64), 0, st, (const unsigned long long *)workspace, n, words, keep);

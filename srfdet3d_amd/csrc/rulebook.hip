@@ -192,7 +192,7 @@ extern "C" int srf_coord_table_build(const int *indices, int A, const int *shape
     ConvGeom g;
     if (!srf_fill_conv_geom(g, shape, one, one, nullptr, batch)) return SRF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    SRF_HIP_TRY(hipMemsetAsync(table, 0xFF, (size_t)capacity * 8, st));
+    SRF_HIP_TRY(srf_fill_bytes(table, 0xFF, (size_t)capacity * 8, st));
     if (A == 0) return SRF_OK;
     if (!indices) return SRF_EINVAL;
     uint32_t *keys = (uint32_t *)table;
@@ -211,7 +211,7 @@ extern "C" int srf_rulebook_subm(const int *indices, int A, const int *shape, co
     const int one[3] = {1, 1, 1};
     if (!srf_fill_conv_geom(g, shape, ksize, one, nullptr, 1)) return SRF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    SRF_HIP_TRY(hipMemsetAsync(pair_counts, 0, sizeof(int) * g.K, st));
+    SRF_HIP_TRY(srf_fill_bytes(pair_counts, 0, sizeof(int) * g.K, st));
     if (A == 0) return SRF_OK;
     if (!indices || !nbr) return SRF_EINVAL;
     const uint32_t *keys = (const uint32_t *)table;
@@ -277,10 +277,10 @@ extern "C" int srf_rulebook_strided_outputs(const int *indices, int A, const int
     int *cand_slot = (int *)workspace;
     int *mincand = (int *)((char *)workspace + off_min);
     int *partial = (int *)((char *)workspace + off_partial);
-    SRF_HIP_TRY(hipMemsetAsync(out_table, 0xFF, (size_t)out_capacity * 8, st));
-    SRF_HIP_TRY(hipMemsetAsync(mincand, 0x7F, (size_t)out_capacity * 4, st));
+    SRF_HIP_TRY(srf_fill_bytes(out_table, 0xFF, (size_t)out_capacity * 8, st));
+    SRF_HIP_TRY(srf_fill_bytes(mincand, 0x7F, (size_t)out_capacity * 4, st));
     if (A == 0) {
-        SRF_HIP_TRY(hipMemsetAsync(num_out, 0, sizeof(int), st));
+        SRF_HIP_TRY(srf_fill_bytes(num_out, 0, sizeof(int), st));
         return SRF_OK;
     }
     if (!indices || !out_indices) return SRF_EINVAL;
@@ -302,10 +302,10 @@ extern "C" int srf_rulebook_strided_pairs(int A, const int *ksize, const void *o
     const int K = ksize[0] * ksize[1] * ksize[2];
     if (K <= 0 || K > SRF_MAX_K) return SRF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    SRF_HIP_TRY(hipMemsetAsync(pair_counts, 0, sizeof(int) * K, st));
+    SRF_HIP_TRY(srf_fill_bytes(pair_counts, 0, sizeof(int) * K, st));
     if (A == 0 || num_out_host == 0) return SRF_OK;
     if (!nbr) return SRF_EINVAL;
-    SRF_HIP_TRY(hipMemsetAsync(nbr, 0xFF, (size_t)K * num_out_host * 4, st));
+    SRF_HIP_TRY(srf_fill_bytes(nbr, 0xFF, (size_t)K * num_out_host * 4, st));
     const int *orows = (const int *)((const uint32_t *)out_table + out_capacity);
     const int *cand_slot = (const int *)workspace;
     hipLaunchKernelGGL(srf_strided_fill_k, dim3(srf_ceil_div((long long)A * K, 256)), dim3(256), 0, st, A, K, cand_slot,
@@ -345,6 +345,7 @@ __global__ __launch_bounds__(256) void srf_bm_mark_k(const int4 *__restrict__ in
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= A) return;
     const int4 c = indices[i];
+    if (c.x < 0) return;  // padding row of a capacity-sized (static shape) active set
     const uint32_t cell = srf_bm_cell(c.x, c.y, c.z, c.w, g.shape);
     atomicOr(&bitmap[cell >> 5], 1u << (cell & 31));
 }
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(256) void srf_bm_place_k(const int4 *__restrict__ i
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= A) return;
     const int4 c = indices[i];
+    if (c.x < 0) return;
     const int r = srf_bm_rank(bitmap, prefix, srf_bm_cell(c.x, c.y, c.z, c.w, g.shape));
     if (r >= 0 && r < A) {
         order[r] = i;
@@ -411,8 +413,9 @@ __global__ __launch_bounds__(256) void srf_bm_subm_k(const int4 *__restrict__ in
     if (o < A) {
         const int4 c = indices[o];
         const int z = c.y + kz - g.ks[0] / 2, y = c.z + ky - g.ks[1] / 2, x = c.w + kx - g.ks[2] / 2;
-        if (z >= 0 && z < g.shape[0] && y >= 0 && y < g.shape[1] && x >= 0 && x < g.shape[2])
+        if (c.x >= 0 && z >= 0 && z < g.shape[0] && y >= 0 && y < g.shape[1] && x >= 0 && x < g.shape[2])
             v = srf_bm_rank(bitmap, prefix, srf_bm_cell(c.x, z, y, x, g.shape));
+        if (v >= A) v = -1;  // only after a capacity overflow upstream (the caller checks the counts and redoes the frame)
         nbr[(size_t)k * A + o] = v;
     }
     srf_bm_count(v >= 0, k, pair_counts);
@@ -440,6 +443,7 @@ __global__ __launch_bounds__(256) void srf_bm_strided_mark_k(const int4 *__restr
     const int kx = k % g.ks[2], t = k / g.ks[2];
     const int ky = t % g.ks[1], kz = t / g.ks[1];
     const int4 ci = indices[i];
+    if (ci.x < 0) return;
     int qz, qy, qx;
     const int vz = ci.y + g.pd[0] - kz, vy = ci.z + g.pd[1] - ky, vx = ci.w + g.pd[2] - kx;
     if (vz < 0 || vy < 0 || vx < 0) return;
@@ -491,15 +495,18 @@ __global__ __launch_bounds__(256) void srf_bm_emit_k(const uint32_t *__restrict_
 // nbr[k][o] = row of the input site that offset k of output o reads, or -1.  grid = (ceil(capacity / 256), K); the number
 // of outputs is read from device memory, so the launch does not wait for the host to learn it
 __global__ __launch_bounds__(256) void srf_bm_strided_pairs_k(const int4 *__restrict__ out_indices, const int *__restrict__ num_out,
-                                                            int nbr_stride, ConvGeom g, const uint32_t *__restrict__ ibitmap,
-                                                            const int *__restrict__ iprefix, int *__restrict__ nbr,
-                                                            int *pair_counts)
+                                                            int nbr_stride, int in_rows, int fill_tail, ConvGeom g,
+                                                            const uint32_t *__restrict__ ibitmap, const int *__restrict__ iprefix,
+                                                            int *__restrict__ nbr, int *pair_counts)
 {
     const int k = blockIdx.y;
     const int o = blockIdx.x * 256 + threadIdx.x;
     int A_out = *num_out;
     A_out = A_out < nbr_stride ? A_out : nbr_stride;
-    if ((int)(blockIdx.x * 256) >= A_out) return;
+    if ((int)(blockIdx.x * 256) >= A_out) {
+        if (fill_tail && o < nbr_stride) nbr[(size_t)k * nbr_stride + o] = -1;  // padding rows of a static-shape level
+        return;
+    }
     const int kx = k % g.ks[2], t = k / g.ks[2];
     const int ky = t % g.ks[1], kz = t / g.ks[1];
     int v = -1;
@@ -508,7 +515,10 @@ __global__ __launch_bounds__(256) void srf_bm_strided_pairs_k(const int4 *__rest
         const int z = c.y * g.st[0] - g.pd[0] + kz, y = c.z * g.st[1] - g.pd[1] + ky, x = c.w * g.st[2] - g.pd[2] + kx;
         if (z >= 0 && z < g.shape[0] && y >= 0 && y < g.shape[1] && x >= 0 && x < g.shape[2])
             v = srf_bm_rank(ibitmap, iprefix, srf_bm_cell(c.x, z, y, x, g.shape));
+        if (v >= in_rows) v = -1;  // see srf_bm_subm_k
         nbr[(size_t)k * nbr_stride + o] = v;
+    } else if (fill_tail && o < nbr_stride) {
+        nbr[(size_t)k * nbr_stride + o] = -1;
     }
     srf_bm_count(v >= 0, k, pair_counts);
 }
@@ -540,7 +550,7 @@ extern "C" int srf_bitmap_build(const int *indices, int A, const int *shape, int
     const int one[3] = {1, 1, 1};
     if (!srf_fill_conv_geom(g, shape, one, one, nullptr, batch)) return SRF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    SRF_HIP_TRY(hipMemsetAsync(bitmap, 0, words * 4, st));
+    SRF_HIP_TRY(srf_fill_bytes(bitmap, 0, words * 4, st));
     if (A > 0) {
         if (!indices) return SRF_EINVAL;
         hipLaunchKernelGGL(srf_bm_mark_k, dim3(srf_ceil_div(A, 256)), dim3(256), 0, st, (const int4 *)indices, A, g,
@@ -563,7 +573,7 @@ extern "C" int srf_bitmap_rulebook_subm(const int *sorted_indices, int A, const 
     for (int d = 0; d < 3; ++d)
         if (!(ksize[d] & 1)) return SRF_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    SRF_HIP_TRY(hipMemsetAsync(pair_counts, 0, sizeof(int) * SRF_MAX_K * (SRF_BM_REPLICAS + 1), st));
+    SRF_HIP_TRY(srf_fill_bytes(pair_counts, 0, sizeof(int) * SRF_MAX_K * (SRF_BM_REPLICAS + 1), st));
     if (A == 0) return SRF_OK;
     if (!sorted_indices || !nbr || !bitmap || !prefix) return SRF_EINVAL;
     hipLaunchKernelGGL(srf_bm_subm_k, dim3(srf_ceil_div(A, 256), g.K), dim3(256), 0, st, (const int4 *)sorted_indices, A, g,
@@ -586,7 +596,7 @@ extern "C" int srf_bitmap_strided_outputs(const int *indices, int A, const int *
     if (words == 0) return SRF_EINVAL;
     if (workspace_bytes < srf_bitmap_workspace_bytes(words)) return SRF_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    SRF_HIP_TRY(hipMemsetAsync(out_bitmap, 0, words * 4, st));
+    SRF_HIP_TRY(srf_fill_bytes(out_bitmap, 0, words * 4, st));
     if (A > 0) {
         if (!indices || !out_indices) return SRF_EINVAL;
         hipLaunchKernelGGL(srf_bm_strided_mark_k, dim3(srf_ceil_div(A, 256), g.K), dim3(256), 0, st, (const int4 *)indices, A, g,
@@ -603,17 +613,20 @@ extern "C" int srf_bitmap_strided_outputs(const int *indices, int A, const int *
 
 extern "C" int srf_bitmap_strided_pairs(const int *out_indices, const int *num_out, int max_out, const int *shape, int batch,
                                         const int *ksize, const int *stride, const int *pad, const void *in_bitmap,
-                                        const int *in_prefix, int *nbr, int nbr_stride, int *pair_counts, srf_stream_t stream)
+                                        const int *in_prefix, int in_rows, int *nbr, int nbr_stride, int fill_tail,
+                                        int *pair_counts, srf_stream_t stream)
 {
     ConvGeom g;
-    if (max_out < 0 || nbr_stride < max_out || !shape || !ksize || !stride || !pad || !pair_counts || !num_out) return SRF_EINVAL;
+    if (max_out < 0 || nbr_stride < max_out || in_rows < 0 || !shape || !ksize || !stride || !pad || !pair_counts || !num_out)
+        return SRF_EINVAL;
     if (!srf_fill_conv_geom(g, shape, ksize, stride, pad, batch)) return SRF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    SRF_HIP_TRY(hipMemsetAsync(pair_counts, 0, sizeof(int) * SRF_MAX_K * (SRF_BM_REPLICAS + 1), st));
+    SRF_HIP_TRY(srf_fill_bytes(pair_counts, 0, sizeof(int) * SRF_MAX_K * (SRF_BM_REPLICAS + 1), st));
     if (max_out == 0) return SRF_OK;
     if (!out_indices || !nbr || !in_bitmap || !in_prefix) return SRF_EINVAL;
     hipLaunchKernelGGL(srf_bm_strided_pairs_k, dim3(srf_ceil_div(max_out, 256), g.K), dim3(256), 0, st, (const int4 *)out_indices,
-                       num_out, nbr_stride, g, (const uint32_t *)in_bitmap, in_prefix, nbr, pair_counts + SRF_MAX_K);
+                       num_out, nbr_stride, in_rows, fill_tail, g, (const uint32_t *)in_bitmap, in_prefix, nbr,
+                       pair_counts + SRF_MAX_K);
     hipLaunchKernelGGL(srf_bm_fold_counts_k, dim3(1), dim3(64), 0, st, pair_counts + SRF_MAX_K, g.K, pair_counts);
     SRF_LAUNCH_CHECK();
     return SRF_OK;

@@ -182,7 +182,7 @@ extern "C" int srf_voxel_unique(const int *coors, int n, const int *grid_zyx, in
     if (n < 0 || !srf_scatter_geom(g, grid_zyx, batch) || !num_voxels) return SRF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
-        SRF_HIP_TRY(hipMemsetAsync(num_voxels, 0, sizeof(int), st));
+        SRF_HIP_TRY(srf_fill_bytes(num_voxels, 0, sizeof(int), st));
         return SRF_OK;
     }
     if (!coors || !out_coors || !point2voxel || !counts || !offsets || !order || !workspace) return SRF_EINVAL;
@@ -193,9 +193,9 @@ extern "C" int srf_voxel_unique(const int *coors, int n, const int *grid_zyx, in
     int *cursor = (int *)((char *)workspace + o_cursor);
     int *partial = (int *)((char *)workspace + o_partial);
 
-    SRF_HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)g.nwords * 4, st));
-    SRF_HIP_TRY(hipMemsetAsync(cursor, 0, (size_t)n * 4, st));
-    SRF_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n * 4, st));
+    SRF_HIP_TRY(srf_fill_bytes(bitmap, 0, (size_t)g.nwords * 4, st));
+    SRF_HIP_TRY(srf_fill_bytes(cursor, 0, (size_t)n * 4, st));
+    SRF_HIP_TRY(srf_fill_bytes(counts, 0, (size_t)n * 4, st));
     const int nblk = srf_ceil_div(n, 256);
     hipLaunchKernelGGL(srf_vu_mark_k, dim3(nblk), dim3(256), 0, st, (const int4 *)coors, n, g, bitmap);
     SRF_LAUNCH_CHECK();

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void srf_spconv_mfma32_k(const float *__restri
                                                          const int *__restrict__ nbr, int nbr_stride, int A_out,
                                                          const float *__restrict__ alpha, const float *__restrict__ beta,
                                                          const float *__restrict__ residual, int relu,
-                                                         float *__restrict__ out)
+                                                         float *__restrict__ out, const int *__restrict__ rows_dev)
 {
     static_assert(WR * WC == 4 && TM == WR * 32, "one 32-row tile per wave row");
     constexpr int CT = COUT / WC / 32;
@@ -173,7 +173,15 @@ __global__ __launch_bounds__(256) void srf_spconv_mfma32_k(const float *__restri
     __shared__ float s_a[2][TM][SRF_KC + 1];
     __shared__ __attribute__((aligned(16))) float s_w[2][SRF_KC][COUT];
 
-    const int row0 = srf_xcd_tile(blockIdx.x, gridDim.x) * TM;
+    if (rows_dev) {  // static-shape levels: rows >= *rows_dev are padding; their tiles do nothing
+        const int live = *rows_dev;
+        A_out = A_out < live ? A_out : live;
+    }
+    // tiles of LIVE rows only, dealt XCD-contiguously over the first n_tiles workgroups (a capacity-sized launch must not
+    // leave whole XCDs with nothing but padding)
+    const int n_tiles = (A_out + TM - 1) / TM;
+    if ((int)blockIdx.x >= n_tiles) return;
+    const int row0 = srf_xcd_tile(blockIdx.x, n_tiles) * TM;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(256) void srf_spconv_packed_k(const float *__restri
                                                          const int *__restrict__ nbr, int nbr_stride, int A_out,
                                                          const float *__restrict__ alpha, const float *__restrict__ beta,
                                                          const float *__restrict__ residual, int relu,
-                                                         float *__restrict__ out)
+                                                         float *__restrict__ out, const int *__restrict__ rows_dev)
 {
     static_assert(WR * WC == 4 && TM == WR * 32, "one 32-row tile per wave row");
     constexpr int CT = COUT / WC / 32;
@@ -394,7 +402,15 @@ __global__ __launch_bounds__(256) void srf_spconv_packed_k(const float *__restri
     __shared__ __attribute__((aligned(16))) float s_a[2][TM * 32];
     __shared__ __attribute__((aligned(16))) float s_w[2][COUT * 32];
 
-    const int row0 = srf_xcd_tile(blockIdx.x, gridDim.x) * TM;
+    if (rows_dev) {  // static-shape levels: rows >= *rows_dev are padding; their tiles do nothing
+        const int live = *rows_dev;
+        A_out = A_out < live ? A_out : live;
+    }
+    // tiles of LIVE rows only, dealt XCD-contiguously over the first n_tiles workgroups (a capacity-sized launch must not
+    // leave whole XCDs with nothing but padding)
+    const int n_tiles = (A_out + TM - 1) / TM;
+    if ((int)blockIdx.x >= n_tiles) return;
+    const int row0 = srf_xcd_tile(blockIdx.x, n_tiles) * TM;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
@@ -552,7 +568,7 @@ __global__ __launch_bounds__(256) void srf_spconv_direct_k(const float *__restri
                                                          const int *__restrict__ nbr, int nbr_stride, int A_out,
                                                          const float *__restrict__ alpha, const float *__restrict__ beta,
                                                          const float *__restrict__ residual, int relu,
-                                                         float *__restrict__ out)
+                                                         float *__restrict__ out, const int *__restrict__ rows_dev)
 {
     constexpr int COUT = 128, RT = TM / 32, NA = TM * 8 * NCH / 256;
     __shared__ int s_nbr[SRF_KMAX * TM];
@@ -560,7 +576,15 @@ __global__ __launch_bounds__(256) void srf_spconv_direct_k(const float *__restri
     __shared__ int s_klist[SRF_KMAX + 1];
     __shared__ __attribute__((aligned(16))) float s_a[NBUF][NCH * TM * 32];
 
-    const int row0 = srf_xcd_tile(blockIdx.x, gridDim.x) * TM;
+    if (rows_dev) {  // static-shape levels: rows >= *rows_dev are padding; their tiles do nothing
+        const int live = *rows_dev;
+        A_out = A_out < live ? A_out : live;
+    }
+    // tiles of LIVE rows only, dealt XCD-contiguously over the first n_tiles workgroups (a capacity-sized launch must not
+    // leave whole XCDs with nothing but padding)
+    const int n_tiles = (A_out + TM - 1) / TM;
+    if ((int)blockIdx.x >= n_tiles) return;
+    const int row0 = srf_xcd_tile(blockIdx.x, n_tiles) * TM;
     const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
     srf_load_nbr_tile<TM>(nbr, nbr_stride, K, row0, A_out, s_nbr, s_any);
     if (tid == 0) {
@@ -643,7 +667,7 @@ __global__ __launch_bounds__(256) void srf_spconv_direct_k(const float *__restri
 
 extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const float *W_packed, int K, const int *nbr,
                                      int nbr_stride, int A_out, int Cout, const float *alpha, const float *beta,
-                                     const float *residual, int relu, float *out, srf_stream_t stream)
+                                     const float *residual, int relu, float *out, const int *rows_dev, srf_stream_t stream)
 {
     if (A_in < 0 || A_out < 0 || Cin <= 0 || Cin > 512 || K <= 0 || K > SRF_KMAX || nbr_stride < A_out) return SRF_EINVAL;
     if ((alpha == nullptr) != (beta == nullptr)) return SRF_EINVAL;
@@ -651,7 +675,7 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
     if (!in || !W_packed || !nbr || !out) return SRF_EINVAL;
     if ((Cin & 3) || A_in == 0) return SRF_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-#define SRF_ARGS in, Cin, W_packed, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out
+#define SRF_ARGS in, Cin, W_packed, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev
     switch (Cout) {
     case 32:
         hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_packed_k<32, 128, 4, 1>), dim3(srf_ceil_div(A_out, 128)), dim3(256),
@@ -663,7 +687,7 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
         break;
     case 128: {
         if (srf_direct_layout(Cin, Cout)) {
-#define SRF_DARGS in, W_packed, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out
+#define SRF_DARGS in, W_packed, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev
             if (Cin == 128)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_direct_k<32, 4, 2>), dim3(srf_ceil_div(A_out, 32)), dim3(256), 0, st,
                                    SRF_DARGS);
@@ -699,7 +723,7 @@ __global__ __launch_bounds__(256) void srf_spconv_mfma16_k(const float *__restri
                                                          const int *__restrict__ nbr, int nbr_stride, int A_out,
                                                          const float *__restrict__ alpha, const float *__restrict__ beta,
                                                          const float *__restrict__ residual, int relu,
-                                                         float *__restrict__ out)
+                                                         float *__restrict__ out, const int *__restrict__ rows_dev)
 {
     constexpr int COUT = 16;
     static_assert(TM == 64, "four 16-row wave tiles");
@@ -708,7 +732,12 @@ __global__ __launch_bounds__(256) void srf_spconv_mfma16_k(const float *__restri
     __shared__ float s_a[TM][SRF_KC + 1];
     __shared__ __attribute__((aligned(16))) float s_w[SRF_KC][COUT];
 
+    if (rows_dev) {  // static-shape levels: rows >= *rows_dev are padding; their tiles do nothing
+        const int live = *rows_dev;
+        A_out = A_out < live ? A_out : live;
+    }
     const int row0 = blockIdx.x * TM;
+    if (row0 >= A_out) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     srf_load_nbr_tile<TM>(nbr, nbr_stride, K, row0, A_out, s_nbr, s_any);
 
@@ -757,9 +786,14 @@ template <int STEPS>  // ceil(Cin / 4)
 __global__ __launch_bounds__(256) void srf_spconv_c16_k(const float *__restrict__ in, int Cin, const float *__restrict__ W, int K,
                                                       const int *__restrict__ nbr, int nbr_stride, int A_out,
                                                       const float *__restrict__ alpha, const float *__restrict__ beta,
-                                                      const float *__restrict__ residual, int relu, float *__restrict__ out)
+                                                      const float *__restrict__ residual, int relu, float *__restrict__ out,
+                                                      const int *__restrict__ rows_dev)
 {
     constexpr int COUT = 16, KM = SRF_KMAX, G = 9;
+    if (rows_dev) {  // static-shape levels: rows >= *rows_dev are padding; their tiles do nothing
+        const int live = *rows_dev;
+        A_out = A_out < live ? A_out : live;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = (blockIdx.x * 4 + wave) * 16;
     if (row0 >= A_out) return;  // no barriers in this kernel: waves are independent
@@ -825,7 +859,7 @@ __global__ __launch_bounds__(256) void srf_spconv_c16_k(const float *__restrict_
 
 extern "C" int srf_spconv_fwd(const float *in, int A_in, int Cin, const float *W, int K, const int *nbr, int nbr_stride,
                               int A_out, int Cout, const float *alpha, const float *beta, const float *residual,
-                              int relu, float *out, srf_stream_t stream)
+                              int relu, float *out, const int *rows_dev, srf_stream_t stream)
 {
     if (A_in < 0 || A_out < 0 || Cin <= 0 || Cin > 512 || K <= 0 || K > SRF_KMAX || nbr_stride < A_out) return SRF_EINVAL;
     if ((alpha == nullptr) != (beta == nullptr)) return SRF_EINVAL;
@@ -833,7 +867,7 @@ extern "C" int srf_spconv_fwd(const float *in, int A_in, int Cin, const float *W
     if (!in || !W || !nbr || !out) return SRF_EINVAL;
     if (Cout != 16 && ((Cin & 3) || A_in == 0)) return SRF_EUNSUPPORTED;  // the wide kernels gather whole float4s
     hipStream_t st = (hipStream_t)stream;
-#define SRF_ARGS in, Cin, W, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out
+#define SRF_ARGS in, Cin, W, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev
     switch (Cout) {
     case 16:
         if (Cin <= 16 && K == SRF_KMAX && A_in > 0) {  // register-resident weights, LDS-free gather
@@ -877,6 +911,7 @@ __global__ __launch_bounds__(256) void srf_densify_k(const float *__restrict__ f
     if (t >= (long long)A * C) return;
     const int a = (int)(t / C), c = (int)(t % C);
     const int4 p = indices[a];
+    if (p.x < 0) return;  // padding row of a capacity-sized active set
     out[((((size_t)p.x * C + c) * D + p.y) * H + p.z) * W + p.w] = feats[t];
 }
 
@@ -885,7 +920,7 @@ extern "C" int srf_densify(const float *feats, const int *indices, int A, int C,
 {
     if (A < 0 || C <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || !out) return SRF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (zero_fill) SRF_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C * D * H * W, st));
+    if (zero_fill) SRF_HIP_TRY(srf_fill_bytes(out, 0, sizeof(float) * (size_t)B * C * D * H * W, st));
     if (A == 0) return SRF_OK;
     if (!feats || !indices) return SRF_EINVAL;
     hipLaunchKernelGGL(srf_densify_k, dim3(srf_ceil_div((long long)A * C, 256)), dim3(256), 0, st, feats,

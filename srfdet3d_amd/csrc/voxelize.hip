@@ -220,7 +220,7 @@ extern "C" int srf_hard_voxelize(const float *points, int n, int nf, const float
     if (mean && (mean_features <= 0 || mean_features > nf)) return SRF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
-        SRF_HIP_TRY(hipMemsetAsync(voxel_num, 0, sizeof(int), st));
+        SRF_HIP_TRY(srf_fill_bytes(voxel_num, 0, sizeof(int), st));
         return SRF_OK;
     }
     if (!points || !voxels || !coors || !num || !workspace) return SRF_EINVAL;
@@ -242,9 +242,9 @@ extern "C" int srf_hard_voxelize(const float *points, int n, int nf, const float
     w += srf_align256((size_t)n * 4);
     int *partial = (int *)w;
 
-    SRF_HIP_TRY(hipMemsetAsync(keys, 0xFF, srf_align256(cap * 4), st));
+    SRF_HIP_TRY(srf_fill_bytes(keys, 0xFF, srf_align256(cap * 4), st));
     // minidx and top are adjacent: one fill with the 0x7F7F7F7F sentinel
-    SRF_HIP_TRY(hipMemsetAsync(minidx, 0x7F, srf_align256(cap * 4) + srf_align256(cap * (size_t)max_points * 4), st));
+    SRF_HIP_TRY(srf_fill_bytes(minidx, 0x7F, srf_align256(cap * 4) + srf_align256(cap * (size_t)max_points * 4), st));
 
     hipLaunchKernelGGL(srf_hv_insert_k, dim3(srf_ceil_div(n, 256)), dim3(256), 256 * nf * sizeof(float), st, points, n,
                        nf, g, max_points, keys, (uint32_t)(cap - 1), minidx, top, pslot);

@@ -107,3 +107,121 @@ class GraphedImageBranch:
         e = dict(graph=graph, img=static_img, feats=feats, done=torch.cuda.Event())
         self.entries[key] = e
         return e
+
+
+class GraphedFrame:
+    """The WHOLE LiDAR frame -- hard voxelization, VFE, sparse encoder, SECOND, FPN, decoder, decode -- as one hipGraph.
+
+    The sparse half has data-dependent sizes (voxels, active sites per level).  It is made replayable by giving every
+    level a fixed capacity: arrays are allocated at capacity, the rows past the real count are PADDING (coordinates -1)
+    that the rulebook kernels and `densify` skip, and a sparse-conv tile made of padding costs a neighbour-tile read and
+    an epilogue, not the convolution.  Nothing is read back during the frame: the real counts come back together with
+    the detections, and a frame whose counts exceed a capacity (or whose sweep has more points than the point buffer) is
+    simply redone on the eager path, after which the capacities are raised and the graph is recaptured.
+    Conditions: one sample per call, hard voxelization with the mean fused in (HardSimpleVFE), no images.
+    """
+
+    HEADROOM = 1.5
+
+    def __init__(self, model, warmup=2):
+        self.model = model
+        self.warmup = warmup
+        self.entry = None
+        self.stats = dict(replays=0, eager=0, captures=0)
+
+    @staticmethod
+    def eligible(model):
+        from .plugin.voxel_encoders import HardSimpleVFE
+        vl = getattr(model, "pts_voxel_layer", None)
+        return (vl is not None and vl.max_num_points != -1 and isinstance(model.pts_voxel_encoder, HardSimpleVFE)
+                and vl.fused_mean_features == model.pts_voxel_encoder.num_features
+                and getattr(model.pts_middle_encoder, "spatial_sort", False))
+
+    # ---- capacities ---------------------------------------------------------------------------------------------
+    def _measure(self, pts):
+        """One eager pass of the sparse half to learn this sweep's sizes."""
+        m = self.model
+        voxels, num, coors = m.voxelize([pts])
+        vf = m.pts_voxel_encoder(voxels, num, coors)
+        enc = m.pts_middle_encoder
+        from .sparse import SparseConvTensor, _SparseConv
+        sizes = {}
+        hooks = []
+        for mod in enc.modules():
+            if isinstance(mod, _SparseConv) and not mod.subm:
+                hooks.append(mod.register_forward_hook(lambda mm, a, out: sizes.__setitem__(mm.indice_key, out.indices.shape[0])))
+        bev = enc(vf, coors, 1)
+        for h in hooks:
+            h.remove()
+        return bev, sizes
+
+    @staticmethod
+    def _round(n):
+        return max(4096, (int(n) + 4095) // 4096 * 4096)
+
+    def _capture(self, pts, img_metas, sizes, n_cap):
+        m = self.model
+        caps = {k: self._round(v * self.HEADROOM) for k, v in sizes.items()}
+        far = torch.full((n_cap, pts.shape[1]), 1.0e6, dtype=pts.dtype, device=pts.device)  # out of every range: dropped
+        static_pts = far.clone()
+        static_pts[:pts.shape[0]] = pts
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(self.warmup):
+                self._run(static_pts, caps, img_metas)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            scores, boxes, counts = self._run(static_pts, caps, img_metas)
+        self.stats["captures"] += 1
+        self.entry = dict(graph=graph, pts=static_pts, far=far, n_cap=n_cap, nf=pts.shape[1], caps=caps, scores=scores, boxes=boxes,
+                          counts=counts[0], limits=counts[1])
+        return self.entry
+
+    def _run(self, static_pts, caps, img_metas):
+        m = self.model
+        bev, counts = m.extract_bev_static(static_pts, caps)
+        x = m.pts_backbone(bev)
+        if m.pts_neck is not None:
+            x = m.pts_neck(x)
+        logits, boxes = m.bbox_head(None, x, img_metas)
+        scores, dec = m.bbox_head.decode(logits, boxes)
+        dev_counts = torch.cat([c[1].view(1) for c in counts])
+        limits = [c[2] for c in counts]
+        return scores, dec, (dev_counts, limits)
+
+    def _eager(self, pts, img_metas):
+        m = self.model
+        self.stats["eager"] += 1
+        bev, sizes = self._measure(pts)
+        x = m.pts_backbone(bev)
+        if m.pts_neck is not None:
+            x = m.pts_neck(x)
+        logits, boxes = m.bbox_head(None, x, img_metas)
+        scores, dec = m.bbox_head.decode(logits, boxes)
+        return scores, dec, sizes
+
+    def __call__(self, pts, img_metas):
+        e = self.entry
+        if e is None or pts.shape[0] > e["n_cap"] or pts.shape[1] != e["nf"]:
+            scores, dec, sizes = self._eager(pts, img_metas)
+            if e is not None:  # keep the larger of the old and new requirements
+                sizes = {k: max(v, int(e["caps"][k] / self.HEADROOM)) for k, v in sizes.items()}
+            n_cap = self._round(max(pts.shape[0] * 1.1, e["n_cap"] if e is not None else 0))
+            self._capture(pts, img_metas, sizes, n_cap)
+            return scores, dec
+        n = pts.shape[0]
+        e["pts"][:n].copy_(pts)
+        if n < e["n_cap"]:
+            e["pts"][n:].copy_(e["far"][n:])
+        e["graph"].replay()
+        self.stats["replays"] += 1
+        counts = e["counts"].tolist()  # the one read-back of the frame; the detections are complete by then
+        if any(c > lim for c, lim in zip(counts, e["limits"])):
+            scores, dec, sizes = self._eager(pts, img_metas)
+            sizes = {k: max(v, int(e["caps"][k] / self.HEADROOM)) for k, v in sizes.items()}
+            self._capture(pts, img_metas, sizes, e["n_cap"])
+            return scores, dec
+        return e["scores"], e["boxes"]

@@ -58,23 +58,33 @@ def dynamic_voxelize(points, voxel_size, pc_range):
     return coors
 
 
-def hard_voxelize(points, voxel_size, pc_range, max_points, max_voxels, mean_features=0):
-    """-> voxels (M,max_points,nf), coors (M,3) zyx, num (M,), mean (M,mean_features) or None.  One D2H sync for M."""
+def hard_voxelize(points, voxel_size, pc_range, max_points, max_voxels, mean_features=0, static=False):
+    """-> voxels (M,max_points,nf), coors (M,3) zyx, num (M,), mean (M,mean_features) or None.  One D2H sync for M.
+    static=True: no sync; all min(n, max_voxels) rows are returned, rows >= M being padding (coors -1, num 0, zeros),
+    followed by the device scalar M -- the fixed-shape form a hipGraph can replay."""
     points = _dev(points, "points", torch.float32)
     n, nf = points.shape
     L = _lib.lib()
     dev = points.device
     rows = max(min(n, max_voxels), 1)
-    voxels = _empty((rows, max_points, nf), torch.float32, dev)
-    coors = _empty((rows, 3), torch.int32, dev)
-    num = _empty((rows,), torch.int32, dev)
+    if static:
+        voxels = torch.zeros((rows, max_points, nf), dtype=torch.float32, device=dev)
+        coors = torch.full((rows, 3), -1, dtype=torch.int32, device=dev)
+        num = torch.zeros((rows,), dtype=torch.int32, device=dev)
+        mean = torch.zeros((rows, mean_features), dtype=torch.float32, device=dev) if mean_features else None
+    else:
+        voxels = _empty((rows, max_points, nf), torch.float32, dev)
+        coors = _empty((rows, 3), torch.int32, dev)
+        num = _empty((rows,), torch.int32, dev)
+        mean = _empty((rows, mean_features), torch.float32, dev) if mean_features else None
     vnum = _empty((1,), torch.int32, dev)
-    mean = _empty((rows, mean_features), torch.float32, dev) if mean_features else None
     ws_bytes = L.srf_hard_voxelize_workspace_bytes(n, max_points)
     ws = _empty((max(ws_bytes, 1),), torch.uint8, dev)
     check(L.srf_hard_voxelize(_ptr(points), n, nf, hf(voxel_size), hf(pc_range), hi(grid_size(voxel_size, pc_range)),
                               max_points, max_voxels, _ptr(voxels), _ptr(coors), _ptr(num), _ptr(vnum), _ptr(mean),
                               mean_features, _ptr(ws), ws_bytes, _stream()), "hard_voxelize")
+    if static:
+        return voxels, coors, num, mean, vnum
     M = int(vnum.item())
     return voxels[:M], coors[:M], num[:M], (mean[:M] if mean is not None else None)
 
@@ -205,14 +215,21 @@ class BitmapLevel:
         return _empty((nbytes,), torch.uint8, self.bitmap.device), nbytes
 
 
-def bitmap_build(indices, spatial_shape, batch, want_order=True):
+def bitmap_build(indices, spatial_shape, batch, want_order=True, padded=False):
     """Distinct active sites (A,4) (b,z,y,x) -> (BitmapLevel, order, sorted_indices): row r of the sorted set is
-    original row order[r].  One memset + mark + 3-launch scan + place; no host sync."""
+    original row order[r].  One memset + mark + 3-launch scan + place; no host sync.  padded=True: rows with b < 0 are
+    padding of a capacity-sized set; the valid rows come first in the sorted result, padding stays (-1,...)."""
     indices = _dev(indices, "indices", torch.int32)
     lvl = BitmapLevel(spatial_shape, batch, indices.device)
     A = indices.shape[0]
-    order = _empty((max(A, 1),), torch.int32, indices.device) if want_order else None
-    sorted_idx = _empty((max(A, 1), 4), torch.int32, indices.device) if want_order else None
+    order = sorted_idx = None
+    if want_order:
+        if padded:  # rows with b < 0 are padding: their sorted slots stay (-1,-1,-1,-1) and point at row 0
+            order = torch.zeros((max(A, 1),), dtype=torch.int32, device=indices.device)
+            sorted_idx = torch.full((max(A, 1), 4), -1, dtype=torch.int32, device=indices.device)
+        else:
+            order = _empty((max(A, 1),), torch.int32, indices.device)
+            sorted_idx = _empty((max(A, 1), 4), torch.int32, indices.device)
     ws, nbytes = lvl.workspace()
     check(_lib.lib().srf_bitmap_build(_ptr(indices), A, hi(lvl.shape), lvl.batch, _ptr(lvl.bitmap), _ptr(lvl.prefix), _ptr(order),
                                       _ptr(sorted_idx), _ptr(ws), nbytes, _stream()), "bitmap_build")
@@ -232,20 +249,27 @@ def rulebook_subm_bitmap(sorted_indices, level, ksize):
     return nbr[:, :A], counts[:K]
 
 
-def rulebook_strided_bitmap(indices, level, ksize, stride, pad):
+def rulebook_strided_bitmap(indices, level, ksize, stride, pad, out_capacity=None):
     """-> out_indices (A_out,4) sorted by (b,y,x,z), nbr (K,A_out), pair_counts (K,), the output BitmapLevel, out_shape.
-    One D2H sync for A_out."""
+    One D2H sync for A_out.  With out_capacity the shapes are static: out_indices has out_capacity rows (padding rows are
+    -1), nbr is (K, out_capacity) with -1 in the padding columns, nothing is read back, and the device scalar A_out is
+    returned as a sixth value (the caller compares it with out_capacity once the frame is done)."""
     indices = _dev(indices, "indices", torch.int32)
     L = _lib.lib()
     dev = indices.device
     A = indices.shape[0]
     K = int(np.prod(ksize))
-    bound = L.srf_strided_max_outputs(A, level.batch, hi(level.shape), hi(ksize), hi(stride), hi(pad))
-    if bound < 0:
-        check(bound, "strided_max_outputs")
+    static = out_capacity is not None
+    if static:
+        bound = int(out_capacity)
+    else:
+        bound = L.srf_strided_max_outputs(A, level.batch, hi(level.shape), hi(ksize), hi(stride), hi(pad))
+        if bound < 0:
+            check(bound, "strided_max_outputs")
     oshape = out_spatial_shape(level.shape, ksize, stride, pad)
     out_lvl = BitmapLevel(oshape, level.batch, dev)
-    out_idx = _empty((max(bound, 1), 4), torch.int32, dev)
+    cap = max(bound, 1)
+    out_idx = torch.full((cap, 4), -1, dtype=torch.int32, device=dev) if static else _empty((cap, 4), torch.int32, dev)
     num_out = _empty((1,), torch.int32, dev)
     ws, nbytes = out_lvl.workspace()
     check(L.srf_bitmap_strided_outputs(_ptr(indices), A, hi(level.shape), level.batch, hi(ksize), hi(stride), hi(pad),
@@ -253,12 +277,13 @@ def rulebook_strided_bitmap(indices, level, ksize, stride, pad):
                                        nbytes, _stream()), "bitmap_strided_outputs")
     # phase 2 reads the count on the device: it is enqueued before the host learns A_out, so the read-back below
     # overlaps it instead of leaving the GPU idle
-    cap = max(bound, 1)
     nbr = _empty((K, cap), torch.int32, dev)
     counts = _empty((L.srf_bitmap_pair_count_ints(),), torch.int32, dev)
     check(L.srf_bitmap_strided_pairs(_ptr(out_idx), _ptr(num_out), bound, hi(level.shape), level.batch, hi(ksize), hi(stride),
-                                     hi(pad), _ptr(level.bitmap), _ptr(level.prefix), _ptr(nbr), cap, _ptr(counts), _stream()),
-          "bitmap_strided_pairs")
+                                     hi(pad), _ptr(level.bitmap), _ptr(level.prefix), A, _ptr(nbr), cap, int(static), _ptr(counts),
+                                     _stream()), "bitmap_strided_pairs")
+    if static:
+        return out_idx, nbr, counts[:K], out_lvl, oshape, num_out
     A_out = int(num_out.item())
     return out_idx[:A_out], nbr[:, :A_out], counts[:K], out_lvl, oshape
 
@@ -278,7 +303,8 @@ def pack_spconv_weights(weight):
     return packed
 
 
-def spconv_fwd(feats, weight, nbr, alpha=None, beta=None, residual=None, relu=False, pair_counts=None, packed=None):
+def spconv_fwd(feats, weight, nbr, alpha=None, beta=None, residual=None, relu=False, pair_counts=None, packed=None,
+               rows_dev=None):
     """feats (A_in,Cin); weight (K,Cin,Cout); nbr (K,A_out) (row stride nbr.stride(0)) -> (A_out,Cout).
     `packed` = pack_spconv_weights(weight) selects the packed-weight kernel (Cout >= 32, Cin % 4 == 0)."""
     feats = _dev(feats, "feats", torch.float32)
@@ -291,18 +317,21 @@ def spconv_fwd(feats, weight, nbr, alpha=None, beta=None, residual=None, relu=Fa
     if residual is not None:
         residual = _dev(residual, "residual", torch.float32)
     timing = KERNEL_TIMING
+    if timing is not None and torch.cuda.is_current_stream_capturing():
+        timing = None  # events recorded inside a graph capture are not timing events
     if timing is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     if packed is not None and Cout >= 32 and Cin % 4 == 0 and feats.shape[0] > 0:
         check(_lib.lib().srf_spconv_fwd_packed(_ptr(feats), feats.shape[0], Cin, _ptr(packed), K, _ptr(nbr),
                                                nbr.stride(0) if A_out > 0 else 0, A_out, Cout, _ptr(alpha), _ptr(beta),
-                                               _ptr(residual), int(bool(relu)), _ptr(out), _stream()), "spconv_fwd_packed")
+                                               _ptr(residual), int(bool(relu)), _ptr(out), _ptr(rows_dev), _stream()),
+              "spconv_fwd_packed")
     else:
         check(_lib.lib().srf_spconv_fwd(_ptr(feats), feats.shape[0], Cin, _ptr(weight), K, _ptr(nbr),
                                         nbr.stride(0) if A_out > 0 else 0, A_out, Cout,
-                                        _ptr(alpha), _ptr(beta), _ptr(residual), int(bool(relu)), _ptr(out), _stream()),
-              "spconv_fwd")
+                                        _ptr(alpha), _ptr(beta), _ptr(residual), int(bool(relu)), _ptr(out), _ptr(rows_dev),
+                                        _stream()), "spconv_fwd")
     if timing is not None:
         ev1.record()
         timing["spconv"].append(_SpconvRecord(ev0, ev1, Cin, Cout, K, feats.shape[0], A_out, pair_counts))

@@ -48,19 +48,23 @@ class SRFDet(BaseModule):
         self.test_cfg = test_cfg
         self._graphed_tail = None
         self._graphed_img = None
+        self._graphed_frame = None
         # None = fp32 (the configs' default).  torch.float16 / torch.bfloat16 run the image backbone + neck under
         # autocast with fp32 outputs, i.e. the reference's `auto_fp16(apply_to=('img'), out_fp32=True)` mode
         # (srfdet.py:141); opt-in, never the default.
         self.img_autocast_dtype = None
 
-    def enable_hip_graphs(self, enabled=True, img_overlap=False):
+    def enable_hip_graphs(self, enabled=True, img_overlap=False, whole_frame=True):
         """Replay the static-shape tail (SECOND -> FPN -> decoder -> decode) as a captured hipGraph in `simple_test`
         (see srfdet3d_amd/graphs.py), and with images the VoVNet -> FPN branch as a second graph.  Results are identical
         to the eager path; opt-in because a graph pins its buffers for the lifetime of the model.  img_overlap=True
         replays the image graph on a side stream beside the eager LiDAR half."""
-        from ..graphs import GraphedImageBranch, GraphedTail
+        from ..graphs import GraphedFrame, GraphedImageBranch, GraphedTail
         self._graphed_tail = GraphedTail(self) if enabled else None
         self._graphed_img = GraphedImageBranch(self, overlap=img_overlap) if (enabled and self.use_img) else None
+        # LiDAR-only, hard voxelization: the whole frame replays as one graph (no host read-back inside the frame)
+        self._graphed_frame = GraphedFrame(self) if (enabled and whole_frame and not self.use_img and GraphedFrame.eligible(self)) \
+            else None
         return self
 
     def init_weights(self):
@@ -88,6 +92,9 @@ class SRFDet(BaseModule):
         return self.simple_test(img[0], points[0], img_metas[0], **kwargs)
 
     def _test_bboxes(self, img, points, img_metas):
+        if (self._graphed_frame is not None and not self.training and img is None and points is not None and len(points) == 1):
+            scores, boxes = self._graphed_frame(points[0], img_metas)
+            return self.bbox_head.get_bboxes(None, None, img_metas, decoded=(scores, boxes))
         if self._graphed_tail is not None and not self.training and points is not None:
             img_static = False
             if img is not None and self._graphed_img is not None:
@@ -151,6 +158,24 @@ class SRFDet(BaseModule):
         if len(points) == 1:
             return points[0], coors[0]
         return torch.cat(points, 0), torch.cat(coors, 0)
+
+    def extract_bev_static(self, points, static_caps):
+        """One sample, hard voxelization, fixed shapes (see graphs.GraphedFrame): `points` (N_cap, C) with out-of-range
+        filler rows -> (bev, [(name, device count, capacity), ...]); nothing is read back to the host."""
+        from .. import ops
+        vl = self.pts_voxel_layer
+        max_voxels = vl.max_voxels[0] if self.training else vl.max_voxels[1]
+        if max_voxels == -1:
+            max_voxels = points.shape[0]
+        voxels, coors, num, mean, vnum = ops.hard_voxelize(points, vl.voxel_size, vl.point_cloud_range, vl.max_num_points,
+                                                           max_voxels, vl.fused_mean_features, static=True)
+        if mean is not None:
+            voxels.srf_vfe_mean = mean
+        batch = torch.where(coors[:, :1] < 0, -1, 0).to(coors.dtype)  # padding rows keep b = -1
+        coors = torch.cat([batch, coors], dim=1)
+        voxel_features = self.pts_voxel_encoder(voxels, num, coors)
+        bev, counts = self.pts_middle_encoder(voxel_features, coors, 1, static_caps=dict(static_caps, __rows__=vnum))
+        return bev, [("voxels", vnum, voxels.shape[0])] + counts
 
     def extract_point_features(self, points):
         x = self.pts_backbone(self.extract_bev(points))

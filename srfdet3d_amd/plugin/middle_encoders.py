@@ -64,9 +64,21 @@ class SparseEncoderCustom(BaseModule):
             self.encoder_layers.add_module(f"encoder_layer{i + 1}", SparseSequential(*blocks))
         return out_channels
 
-    def forward(self, voxel_features, coors, batch_size):
-        """(M,C) voxel features + (M,4) int (b,z,y,x) -> (B, C*D, H, W) BEV map."""
+    def forward(self, voxel_features, coors, batch_size, static_caps=None):
+        """(M,C) voxel features + (M,4) int (b,z,y,x) -> (B, C*D, H, W) BEV map.
+        static_caps ({indice_key of a strided conv: rows}): fixed-shape execution for hipGraph replay -- `coors` may hold
+        padding rows (b < 0), every level is padded to its capacity, nothing is read back to the host; returns
+        (bev, [(indice_key, device count, capacity), ...]) and the caller checks the counts afterwards."""
         coors = coors.int()
+        if static_caps is not None:
+            x = SparseConvTensor.sorted_by_bitmap(voxel_features, coors, self.sparse_shape, int(batch_size), static_caps)
+            static = x.indice_dict["static"]
+            x = self.conv_input(x)
+            for stage in self.encoder_layers._modules.values():
+                x = stage(x)
+            dense = self.conv_out(x).dense()
+            N, C, D, H, W = dense.shape
+            return dense.view(N, C * D, H, W), static["counts"]
         if self.spatial_sort and coors.is_cuda and coors.shape[0] > 0:
             # rows into (b, y, x, z) order + the level's occupancy bitmap: all rulebooks below are built by bitmap rank
             x = SparseConvTensor.sorted_by_bitmap(voxel_features, coors, self.sparse_shape, int(batch_size))

@@ -30,7 +30,9 @@ def _triple(v):
 
 
 class SparseConvTensor:
-    def __init__(self, features, indices, spatial_shape, batch_size, indice_dict=None):
+    def __init__(self, features, indices, spatial_shape, batch_size, indice_dict=None, num_rows=None):
+        # num_rows: device int with the number of real rows when the arrays are padded to a capacity (static shapes)
+        self.num_rows = num_rows
         self.features = features
         self.indices = indices if indices.dtype == torch.int32 else indices.int()
         self.spatial_shape = [int(s) for s in spatial_shape]
@@ -38,7 +40,7 @@ class SparseConvTensor:
         self.indice_dict = indice_dict if indice_dict is not None else {}
 
     def replace_feature(self, features):
-        return SparseConvTensor(features, self.indices, self.spatial_shape, self.batch_size, self.indice_dict)
+        return SparseConvTensor(features, self.indices, self.spatial_shape, self.batch_size, self.indice_dict, self.num_rows)
 
     # coordinate table / SubM rulebook of this tensor's active set, built once and shared along the layer chain
     def _level_key(self):
@@ -55,14 +57,20 @@ class SparseConvTensor:
         return self.indice_dict.get(("bitmap",) + self._level_key())
 
     @staticmethod
-    def sorted_by_bitmap(features, indices, spatial_shape, batch_size):
+    def sorted_by_bitmap(features, indices, spatial_shape, batch_size, static_caps=None):
         """Reorders distinct active sites into (b, y, x, z) order and attaches the level's bitmap: every rulebook down the
         layer chain is then built by bitmap rank (ops.rulebook_*_bitmap) instead of hash tables, and every active
         set stays sorted.  The dense result of an encoder does not depend on the row order."""
         lvl, order, sorted_idx = ops.bitmap_build(indices if indices.dtype == torch.int32 else indices.int(), spatial_shape,
-                                                  batch_size)
+                                                  batch_size, padded=static_caps is not None)
         t = SparseConvTensor(features[order.long()], sorted_idx, spatial_shape, batch_size)
         t.indice_dict[("bitmap",) + t._level_key()] = lvl
+        if static_caps is not None:
+            # static-shape mode (whole-frame hipGraph): `indices` may carry padding rows (b < 0); every strided conv
+            # below produces static_caps[indice_key] rows, the surplus being padding, and appends its device-side
+            # output count to "counts" for the caller's overflow check
+            t.indice_dict["static"] = dict(caps={k: v for k, v in static_caps.items() if k != "__rows__"}, counts=[])
+            t.num_rows = static_caps.get("__rows__")
         return t
 
     def subm_rulebook(self, ksize):
@@ -136,12 +144,20 @@ class _SparseConv(SparseModule):
     def _rulebook(self, x):
         if self.subm:
             nbr, counts = x.subm_rulebook(self.kernel_size)
-            return nbr, counts, x.indices, x.spatial_shape
+            return nbr, counts, x.indices, x.spatial_shape, x.num_rows
         key = ("strided", self.indice_key, tuple(self.kernel_size), tuple(self.stride), tuple(self.padding)) + \
             x._level_key()
         if key not in x.indice_dict:
             lvl = x.bitmap_level()
-            if lvl is not None:
+            static = x.indice_dict.get("static")
+            if lvl is not None and static is not None:
+                cap = static["caps"][self.indice_key]
+                out_idx, nbr, counts, out_lvl, oshape, num_out = ops.rulebook_strided_bitmap(
+                    x.indices, lvl, self.kernel_size, self.stride, self.padding, out_capacity=cap)
+                static["counts"].append((self.indice_key, num_out, cap))
+                x.indice_dict[("rows", out_idx.data_ptr())] = num_out
+                x.indice_dict[("bitmap", out_idx.data_ptr(), out_idx.shape[0], tuple(oshape))] = out_lvl
+            elif lvl is not None:
                 out_idx, nbr, counts, out_lvl, oshape = ops.rulebook_strided_bitmap(x.indices, lvl, self.kernel_size, self.stride,
                                                                                    self.padding)
                 x.indice_dict[("bitmap", out_idx.data_ptr(), out_idx.shape[0], tuple(oshape))] = out_lvl
@@ -151,11 +167,11 @@ class _SparseConv(SparseModule):
                 x.indice_dict[("table", out_idx.data_ptr(), out_idx.shape[0], tuple(oshape))] = table
             x.indice_dict[key] = (out_idx, nbr, counts, oshape)
         out_idx, nbr, counts, oshape = x.indice_dict[key]
-        return nbr, counts, out_idx, oshape
+        return nbr, counts, out_idx, oshape, x.indice_dict.get(("rows", out_idx.data_ptr()))
 
     def forward(self, x, bn=None, relu=False, residual=None):
         """conv, optionally with an eval-mode BatchNorm1d, residual rows and ReLU fused into the same kernel."""
-        nbr, counts, out_idx, oshape = self._rulebook(x)
+        nbr, counts, out_idx, oshape, rows_dev = self._rulebook(x)
         K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
         w = self.weight.view(K, self.in_channels, self.out_channels)
         alpha = beta = None
@@ -174,8 +190,9 @@ class _SparseConv(SparseModule):
                     cache = (vers, ops.pack_spconv_weights(w.detach()))
                 self._srf_packed = cache
             packed = cache[1]
-        feats = ops.spconv_fwd(x.features, w, nbr, alpha, beta, residual, relu, pair_counts=counts, packed=packed)
-        return SparseConvTensor(feats, out_idx, oshape, x.batch_size, x.indice_dict)
+        feats = ops.spconv_fwd(x.features, w, nbr, alpha, beta, residual, relu, pair_counts=counts, packed=packed,
+                               rows_dev=rows_dev)
+        return SparseConvTensor(feats, out_idx, oshape, x.batch_size, x.indice_dict, rows_dev)
 
 
 @CONV_LAYERS.register_module("SubMConv3d")

@@ -43,7 +43,7 @@ def test_host_side_helpers():
     assert L.srf_voxel_unique_workspace_bytes(1000, hi([40, 1600, 1408]), 1) > 40 * 1600 * 1408 // 8
     assert L.srf_voxel_unique_workspace_bytes(1000, hi([41, 1472, 1472]), 64) == 0  # exceeds 32-bit keys
     # argument validation happens before any HIP call
-    assert L.srf_spconv_fwd(None, 0, 16, None, 27, None, 0, 10, 24, None, None, None, 0, None, None) == -1
+    assert L.srf_spconv_fwd(None, 0, 16, None, 27, None, 0, 10, 24, None, None, None, 0, None, None, None) == -1
     assert L.srf_roi_extract(None, 0, 128, None, 0, 7, 2, 56.0, None, 0, 0, 0, 0, None, None) == -1
 
 

@@ -199,3 +199,51 @@ def test_lc_frame_eager_graphs_and_overlap_agree(dev):
                 assert torch.equal(got["labels_3d"], want["labels_3d"])
                 torch.testing.assert_close(got["scores_3d"], want["scores_3d"], rtol=0, atol=1e-5)
                 torch.testing.assert_close(got["boxes_3d"].tensor, want["boxes_3d"].tensor, rtol=0, atol=1e-4)
+
+
+def test_whole_frame_graph_equals_eager(setup, dev):
+    """GraphedFrame: voxelization + sparse encoder + tail as ONE hipGraph with capacity-padded levels.  Must reproduce the
+    eager detections on replay, on a sweep with fewer points (filler rows), after a sweep with MORE points than the
+    point buffer (eager fallback + recapture), and after a capacity overflow (forced with a tiny headroom)."""
+    import copy
+    from srfdet3d_amd.graphs import GraphedFrame
+    cpu, gpu, _ = setup
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes)]
+
+    def same(a, b):
+        assert torch.equal(a["labels_3d"], b["labels_3d"])
+        torch.testing.assert_close(a["scores_3d"], b["scores_3d"], rtol=0, atol=1e-5)
+        torch.testing.assert_close(a["boxes_3d"].tensor, b["boxes_3d"].tensor, rtol=0, atol=1e-4)
+
+    g = copy.deepcopy(gpu).enable_hip_graphs()
+    assert g._graphed_frame is not None
+    sweeps = [S.nuscenes_sweep(2000, 30000), S.nuscenes_sweep(2001, 30000), S.nuscenes_sweep(2002, 24000),
+              S.nuscenes_sweep(2003, 45000), S.nuscenes_sweep(2000, 30000)]
+    for sw in sweeps:
+        p = torch.from_numpy(sw).to(dev)
+        with torch.no_grad():
+            same(g.simple_test(None, [p], metas)[0]["pts_bbox"], gpu.simple_test(None, [p], metas)[0]["pts_bbox"])
+    st = g._graphed_frame.stats
+    assert st["replays"] >= 3 and st["captures"] == 2 and st["eager"] == 2, st   # first frame + the 45k-point sweep
+    # the BEV map of the static path is bit-identical to the dynamic one (padding rows are never read)
+    with torch.no_grad():
+        p = torch.from_numpy(sweeps[0]).to(dev)
+        bev = gpu.extract_bev([p])
+        far = torch.full((4096, p.shape[1]), 1.0e6, device=dev)
+        caps = dict(g._graphed_frame.entry["caps"])
+        bev_s, counts = gpu.extract_bev_static(torch.cat([p, far]), caps)
+        assert torch.equal(bev, bev_s)
+        assert all(int(c[1].item()) <= c[2] for c in counts)
+    # overflow: capacities sized for a sparse sweep, then a dense one
+    old = GraphedFrame.HEADROOM
+    GraphedFrame.HEADROOM = 1.0
+    try:
+        g2 = copy.deepcopy(gpu).enable_hip_graphs()
+        small = torch.from_numpy(S.nuscenes_sweep(2005, 12000)).to(dev)
+        big = torch.cat([torch.from_numpy(S.nuscenes_sweep(2006, 6000)), torch.from_numpy(S.nuscenes_sweep(2007, 6000))]).to(dev)
+        with torch.no_grad():
+            same(g2.simple_test(None, [small], metas)[0]["pts_bbox"], gpu.simple_test(None, [small], metas)[0]["pts_bbox"])
+            for _ in range(2):
+                same(g2.simple_test(None, [big], metas)[0]["pts_bbox"], gpu.simple_test(None, [big], metas)[0]["pts_bbox"])
+    finally:
+        GraphedFrame.HEADROOM = old
