@@ -289,6 +289,10 @@ int srf_box_iou_rotated(const float *boxes_a, int n, const float *boxes_b, int m
 size_t srf_nms_rotated_workspace_bytes(int n);
 int srf_nms_rotated(const float *boxes, int n, float iou_threshold, int *keep, void *workspace, size_t workspace_bytes,
                     srf_stream_t stream);
+/* the same over the first *n_dev (device int, <= n) boxes only; keep[i] = 0 for the rest.  A fixed-shape form for
+ * hipGraph replay: n is the capacity, the number of candidates above the score threshold is decided on the device. */
+int srf_nms_rotated_counted(const float *boxes_xywhr, int n, const int *n_dev, float iou_threshold, int *keep,
+                            void *workspace, size_t workspace_bytes, srf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -94,10 +94,15 @@ __device__ float srf_rotated_iou(const float *a, const float *b)
 }
 
 __global__ __launch_bounds__(64) void srf_nms_mask_k(const float *__restrict__ boxes, int n, float thr,
-                                                   unsigned long long *__restrict__ mask, int words)
+                                                   unsigned long long *__restrict__ mask, int words,
+                                                   const int *__restrict__ n_dev)
 {
     const int rb = blockIdx.y, cb = blockIdx.x;
-    if (cb < rb) return;  // only later boxes can be suppressed
+    if (n_dev) {  // static-shape call: only the first *n_dev boxes are candidates
+        const int live = *n_dev;
+        n = n < live ? n : live;
+    }
+    if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;  // only later boxes can be suppressed
     __shared__ float sb[64 * 5];
     const int ncol = min(n - cb * 64, 64);
     if ((int)threadIdx.x < ncol)
@@ -116,9 +121,14 @@ __global__ __launch_bounds__(64) void srf_nms_mask_k(const float *__restrict__ b
 
 // one wave; lane l owns word l of the removed set
 __global__ __launch_bounds__(64) void srf_nms_reduce_k(const unsigned long long *__restrict__ mask, int n, int words,
-                                                     int *__restrict__ keep)
+                                                     int *__restrict__ keep, const int *__restrict__ n_dev)
 {
     const int lane = threadIdx.x;
+    if (n_dev) {
+        const int live = *n_dev < n ? *n_dev : n;
+        for (int i = live + lane; i < n; i += 64) keep[i] = 0;  // the rest are not candidates
+        n = live;
+    }
     unsigned long long removed = 0;
     for (int i = 0; i < n; ++i) {
         const unsigned long long w = __shfl(removed, i >> 6, 64);
@@ -155,8 +165,24 @@ extern "C" size_t srf_nms_rotated_workspace_bytes(int n)
     return (size_t)n * ((n + 63) / 64) * 8;
 }
 
+static int srf_nms_launch(const float *boxes, int n, const int *n_dev, float iou_threshold, int *keep, void *workspace,
+                          size_t workspace_bytes, srf_stream_t stream);
+
 extern "C" int srf_nms_rotated(const float *boxes, int n, float iou_threshold, int *keep, void *workspace,
                                size_t workspace_bytes, srf_stream_t stream)
+{
+    return srf_nms_launch(boxes, n, nullptr, iou_threshold, keep, workspace, workspace_bytes, stream);
+}
+
+extern "C" int srf_nms_rotated_counted(const float *boxes, int n, const int *n_dev, float iou_threshold, int *keep,
+                                       void *workspace, size_t workspace_bytes, srf_stream_t stream)
+{
+    if (!n_dev) return SRF_EINVAL;
+    return srf_nms_launch(boxes, n, n_dev, iou_threshold, keep, workspace, workspace_bytes, stream);
+}
+
+static int srf_nms_launch(const float *boxes, int n, const int *n_dev, float iou_threshold, int *keep, void *workspace,
+                          size_t workspace_bytes, srf_stream_t stream)
 {
     if (n < 0 || n > 4096) return n < 0 ? SRF_EINVAL : SRF_EUNSUPPORTED;
     if (n == 0) return SRF_OK;
@@ -166,8 +192,8 @@ extern "C" int srf_nms_rotated(const float *boxes, int n, float iou_threshold, i
     hipStream_t st = (hipStream_t)stream;
     SRF_HIP_TRY(srf_fill_bytes(workspace, 0, srf_nms_rotated_workspace_bytes(n), st));
     hipLaunchKernelGGL(srf_nms_mask_k, dim3(words, words), dim3(64), 0, st, boxes, n, iou_threshold,
-                       (unsigned long long *)workspace, words);
-    hipLaunchKernelGGL(srf_nms_reduce_k, dim3(1), dim3(64), 0, st, (const unsigned long long *)workspace, n, words, keep);
+                       (unsigned long long *)workspace, words, n_dev);
+    hipLaunchKernelGGL(srf_nms_reduce_k, dim3(1), dim3(64), 0, st, (const unsigned long long *)workspace, n, words, keep, n_dev);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

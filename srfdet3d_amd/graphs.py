@@ -23,7 +23,9 @@ class GraphedTail:
         if m.pts_neck is not None:
             x = m.pts_neck(x)
         logits, boxes = m.bbox_head(img_feats, x, img_metas)
-        return m.bbox_head.decode(logits, boxes)
+        scores, dec = m.bbox_head.decode(logits, boxes)
+        sel = m.bbox_head.select_static(scores, dec) if getattr(m.bbox_head, "use_nms", False) else None
+        return scores, dec, sel
 
     def __call__(self, bev, img_feats, img_metas, img_static=False):
         """img_static: img_feats are the persistent output buffers of a GraphedImageBranch -- the tail is captured
@@ -38,7 +40,7 @@ class GraphedTail:
             for dst, src in zip(e["img"], img_feats):
                 dst.copy_(src)
         e["graph"].replay()
-        return e["scores"], e["boxes"]
+        return e["scores"], e["boxes"], e["sel"]
 
     def _capture(self, key, bev, img_feats, img_metas, img_static=False):
         static_bev = bev.clone()
@@ -54,8 +56,8 @@ class GraphedTail:
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(graph):
-            scores, boxes = self._run(static_bev, static_img, img_metas)
-        e = dict(graph=graph, bev=static_bev, img=static_img, scores=scores, boxes=boxes)
+            scores, boxes, sel = self._run(static_bev, static_img, img_metas)
+        e = dict(graph=graph, bev=static_bev, img=static_img, scores=scores, boxes=boxes, sel=sel)
         self.entries[key] = e
         return e
 
@@ -174,10 +176,10 @@ class GraphedFrame:
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(graph):
-            scores, boxes, counts = self._run(static_pts, caps, img_metas)
+            scores, boxes, counts, sel = self._run(static_pts, caps, img_metas)
         self.stats["captures"] += 1
         self.entry = dict(graph=graph, pts=static_pts, far=far, n_cap=n_cap, nf=pts.shape[1], caps=caps, scores=scores, boxes=boxes,
-                          counts=counts[0], limits=counts[1])
+                          counts=counts[0], limits=counts[1], sel=sel)
         return self.entry
 
     def _run(self, static_pts, caps, img_metas):
@@ -188,9 +190,10 @@ class GraphedFrame:
             x = m.pts_neck(x)
         logits, boxes = m.bbox_head(None, x, img_metas)
         scores, dec = m.bbox_head.decode(logits, boxes)
+        sel = m.bbox_head.select_static(scores, dec) if getattr(m.bbox_head, "use_nms", False) else None
         dev_counts = torch.cat([c[1].view(1) for c in counts])
         limits = [c[2] for c in counts]
-        return scores, dec, (dev_counts, limits)
+        return scores, dec, (dev_counts, limits), sel
 
     def _eager(self, pts, img_metas):
         m = self.model
@@ -211,7 +214,7 @@ class GraphedFrame:
                 sizes = {k: max(v, int(e["caps"][k] / self.HEADROOM)) for k, v in sizes.items()}
             n_cap = self._round(max(pts.shape[0] * 1.1, e["n_cap"] if e is not None else 0))
             self._capture(pts, img_metas, sizes, n_cap)
-            return scores, dec
+            return scores, dec, None
         n = pts.shape[0]
         e["pts"][:n].copy_(pts)
         if n < e["n_cap"]:
@@ -223,5 +226,5 @@ class GraphedFrame:
             scores, dec, sizes = self._eager(pts, img_metas)
             sizes = {k: max(v, int(e["caps"][k] / self.HEADROOM)) for k, v in sizes.items()}
             self._capture(pts, img_metas, sizes, e["n_cap"])
-            return scores, dec
-        return e["scores"], e["boxes"]
+            return scores, dec, None
+        return e["scores"], e["boxes"], e["sel"]

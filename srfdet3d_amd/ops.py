@@ -428,6 +428,22 @@ def nms_rotated(boxes_xywhr, scores, iou_threshold):
     return order[keep.bool()]
 
 
+def nms_rotated_counted(sorted_boxes_xywhr, n_live, iou_threshold):
+    """Greedy rotated NMS over the first n_live (device int32 scalar) rows of boxes already in descending score order;
+    returns keep flags (n,) int32, zero past n_live.  Fixed shapes, nothing read back: graph-capturable."""
+    b = _dev(sorted_boxes_xywhr, "boxes", torch.float32)
+    n = b.shape[0]
+    keep = _empty((max(n, 1),), torch.int32, b.device)
+    if n == 0:
+        return keep[:0]
+    L = _lib.lib()
+    ws_bytes = L.srf_nms_rotated_workspace_bytes(n)
+    ws = _empty((ws_bytes,), torch.uint8, b.device)
+    check(L.srf_nms_rotated_counted(_ptr(b), n, _ptr(_dev(n_live, "n_live", torch.int32)), float(iou_threshold), _ptr(keep),
+                                    _ptr(ws), ws_bytes, _stream()), "nms_rotated_counted")
+    return keep
+
+
 # ---------------------------------------------------------------------------------------------- decoder stage
 def _ln(ln):
     """nn.LayerNorm or (gamma, beta, eps) or None -> (ptr_g, ptr_b, eps)."""

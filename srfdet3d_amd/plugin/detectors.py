@@ -93,8 +93,7 @@ class SRFDet(BaseModule):
 
     def _test_bboxes(self, img, points, img_metas):
         if (self._graphed_frame is not None and not self.training and img is None and points is not None and len(points) == 1):
-            scores, boxes = self._graphed_frame(points[0], img_metas)
-            return self.bbox_head.get_bboxes(None, None, img_metas, decoded=(scores, boxes))
+            return self._finish(*self._graphed_frame(points[0], img_metas), img_metas)
         if self._graphed_tail is not None and not self.training and points is not None:
             img_static = False
             if img is not None and self._graphed_img is not None:
@@ -106,10 +105,18 @@ class SRFDet(BaseModule):
             bev = self.extract_bev(points)
             if img_static:
                 torch.cuda.current_stream().wait_event(img_done)
-            scores, boxes = self._graphed_tail(bev, img_feats, img_metas, img_static=img_static)
-            return self.bbox_head.get_bboxes(None, None, img_metas, decoded=(scores, boxes))
+            return self._finish(*self._graphed_tail(bev, img_feats, img_metas, img_static=img_static), img_metas)
         img_feats, point_feats = self.extract_feat(img, points, img_metas)
         return self.bbox_head.simple_test_bboxes(img_feats, point_feats, img_metas)
+
+    def _finish(self, scores, boxes, sel, img_metas):
+        """Detections from a graph replay: the NMS ran inside the graph with fixed shapes (`select_static`); one copy brings
+        the survivors to the host.  Falls back to the eager selection if a sample overflowed the static capacity."""
+        if sel is not None:
+            res = self.bbox_head.results_from_static(sel[0].cpu(), sel[1].cpu(), img_metas)
+            if res is not None:
+                return res
+        return self.bbox_head.get_bboxes(None, None, img_metas, decoded=(scores, boxes))
 
     def simple_test(self, img, points, img_metas, rescale=False):
         bbox_list = self._test_bboxes(img, points, img_metas)
@@ -200,6 +207,15 @@ class SRFDet(BaseModule):
 @DETECTORS.register_module()
 class SRFDetWaymo(SRFDet):
     """Same model; results are returned without the `pts_bbox` wrapper (srfdetwaymo.py:13-41)."""
+
+    def _finish(self, scores, boxes, sel, img_metas):
+        """Detections from a graph replay: the NMS ran inside the graph with fixed shapes (`select_static`); one copy brings
+        the survivors to the host.  Falls back to the eager selection if a sample overflowed the static capacity."""
+        if sel is not None:
+            res = self.bbox_head.results_from_static(sel[0].cpu(), sel[1].cpu(), img_metas)
+            if res is not None:
+                return res
+        return self.bbox_head.get_bboxes(None, None, img_metas, decoded=(scores, boxes))
 
     def simple_test(self, img, points, img_metas, rescale=False):
         return [bbox3d2result(b, s, l) for b, s, l in self._test_bboxes(img, points, img_metas)]

@@ -587,6 +587,39 @@ class SRFDetHead(BaseModule):
         boxes[..., 2] = boxes[..., 2] - boxes[..., 5] * 0.5
         return scores, boxes
 
+    def select_static(self, scores, boxes):
+        """Fixed-shape, sync-free form of the NMS of `get_bboxes` (for hipGraph capture): (bs,n_p,#cls), (bs,n_p,D) ->
+        packed (bs, L, D+2) rows [box, score, label] whose first counts[b,0] rows are the survivors in the reference's order,
+        and counts (bs, 2) int32 [survivors, candidates above the threshold]."""
+        from ..postprocess import box3d_multiclass_nms_static
+        cfg = self.test_cfg
+        packed, counts = [], []
+        for i in range(scores.shape[0]):
+            b, s, l, kept, cand = box3d_multiclass_nms_static(boxes[i], scores[i], cfg["score_thr"], cfg["nms_thr"])
+            packed.append(torch.cat([b, s.unsqueeze(1), l.to(b.dtype).unsqueeze(1)], dim=1))
+            counts.append(torch.cat([kept, cand]))
+        return torch.stack(packed), torch.stack(counts)
+
+    def results_from_static(self, packed, counts, img_metas):
+        """Host side of `select_static`: packed / counts already on the CPU -> the list `get_bboxes` returns, or None when a
+        sample had more candidates than the static capacity (the caller then runs `get_bboxes`)."""
+        cfg = self.test_cfg
+        results = []
+        L, D = packed.shape[1], packed.shape[2] - 2
+        for i in range(packed.shape[0]):
+            kept, cand = int(counts[i, 0]), int(counts[i, 1])
+            if cand > L:
+                return None
+            rows = packed[i, :kept]
+            boxes, scores, labels = rows[:, :D], rows[:, D], rows[:, D + 1].long()
+            if kept > cfg["max_per_img"]:
+                top = scores.sort(descending=True)[1][:cfg["max_per_img"]]
+                boxes, scores, labels = boxes[top], scores[top], labels[top]
+            rng = torch.tensor(cfg["post_center_range"], dtype=boxes.dtype)
+            keep = (boxes[..., :3] >= rng[:3]).all(1) & (boxes[..., :3] <= rng[3:]).all(1)
+            results.append([img_metas[i]["box_type_3d"](boxes[keep], boxes.shape[-1]), scores[keep], labels[keep]])
+        return results
+
     def get_bboxes(self, pred_logits, pred_bboxes, img_metas, decoded=None):
         from ..postprocess import box3d_multiclass_nms
         cfg = self.test_cfg

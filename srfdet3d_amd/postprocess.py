@@ -35,3 +35,33 @@ def box3d_multiclass_nms(boxes, scores, score_thr, max_num, nms_thr):
         top = out_s.sort(descending=True)[1][:max_num]
         out_b, out_s, out_l = out_b[top], out_s[top], out_l[top]
     return out_b, out_s, out_l
+
+
+STATIC_CANDIDATES = 2048  # capacity of the fixed-shape NMS (the kernel takes up to 4096)
+
+
+def box3d_multiclass_nms_static(boxes, scores, score_thr, nms_thr, capacity=STATIC_CANDIDATES):
+    """The same selection with FIXED shapes and no host read-back, so that it can live inside a hipGraph.
+
+    boxes (n, D), scores (n, C) -> (out_boxes (L, D), out_scores (L,), out_labels (L,), kept, candidates) with
+    L = min(n*C, capacity): the first `kept` (device int32) rows are the NMS survivors in the reference's order (class-major,
+    descending score inside a class); `candidates` (device int32) is the number of (box, class) pairs above the score
+    threshold -- if it exceeds L the caller must redo the frame with `box3d_multiclass_nms`."""
+    n, C = scores.shape
+    flat = scores.reshape(-1)
+    valid = flat > score_thr
+    L = min(n * C, int(capacity))
+    key = torch.where(valid, flat, torch.full_like(flat, -1.0))
+    top_s, top_i = torch.topk(key, L, sorted=True)           # descending score, candidates first
+    m = valid.sum().to(torch.int32).view(1)
+    bi, ci = torch.div(top_i, C, rounding_mode="floor"), top_i % C
+    cand = boxes[bi]
+    span = (boxes[:, :2].abs().max() + boxes[:, 3:5].abs().max()) * 4 + 1
+    # (a list index would upload an index tensor: not allowed while a stream is capturing)
+    bev = torch.stack([cand[:, 0] + ci.to(cand.dtype) * span, cand[:, 1], cand[:, 3], cand[:, 4], cand[:, 6]], dim=1)
+    keep = ops.nms_rotated_counted(bev, torch.clamp(m, max=L), nms_thr).bool()
+    # survivors first, class-major, descending score inside a class (the per-class loop of the reference)
+    key2 = torch.where(keep, ci.to(flat.dtype) * 4 - top_s.clamp(0, 1) * 2, torch.full_like(top_s, 1.0e9))
+    o2 = torch.argsort(key2, stable=True)
+    kept = keep.sum().to(torch.int32).view(1)
+    return cand[o2], top_s[o2], ci[o2], kept, m
