@@ -58,6 +58,10 @@ def main():
     ap.add_argument("--np", type=int, default=200, help="num_proposals override (BASELINE.json: np~200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not replay the static tail as a hipGraph")
+    ap.add_argument("--whole-frame", default="auto", choices=["auto", "on", "off"],
+                    help="replay voxelization + sparse encoder + tail as ONE hipGraph (capacity-padded static shapes). auto = on "
+                         "for the LiDAR-only workloads; off for LC, where it is worth 0.5 %% and would take the per-launch HIP "
+                         "events of `roofline` out of the timed region")
     ap.add_argument("--img-overlap", action="store_true",
                     help="LC only: replay the image-branch graph on a side stream beside the LiDAR half (about 2.5 %% "
                          "more frames/s, but the sparse-conv kernels then share the chip and their per-launch times "
@@ -94,7 +98,8 @@ def main():
     import copy
     model = copy.deepcopy(model_cpu).to(dev)
     if not args.eager:
-        model.enable_hip_graphs(img_overlap=args.img_overlap)
+        whole = args.whole_frame == "on" or (args.whole_frame == "auto" and not model.use_img)
+        model.enable_hip_graphs(img_overlap=args.img_overlap, whole_frame=whole)
     if args.img_dtype != "fp32":
         model.img_autocast_dtype = dict(fp16=torch.float16, bf16=torch.bfloat16)[args.img_dtype]
         model.img_backbone.to(memory_format=torch.channels_last)

@@ -120,7 +120,8 @@ class GraphedFrame:
     an epilogue, not the convolution.  Nothing is read back during the frame: the real counts come back together with
     the detections, and a frame whose counts exceed a capacity (or whose sweep has more points than the point buffer) is
     simply redone on the eager path, after which the capacities are raised and the graph is recaptured.
-    Conditions: one sample per call, hard voxelization with the mean fused in (HardSimpleVFE), no images.
+    Conditions: one sample per call, hard voxelization with the mean fused in (HardSimpleVFE).  With cameras (LC) the
+    image features are the persistent buffers of a GraphedImageBranch, read in place.
     """
 
     HEADROOM = 1.5
@@ -161,7 +162,7 @@ class GraphedFrame:
     def _round(n):
         return max(4096, (int(n) + 4095) // 4096 * 4096)
 
-    def _capture(self, pts, img_metas, sizes, n_cap):
+    def _capture(self, pts, img_metas, sizes, n_cap, img_feats=None):
         m = self.model
         caps = {k: self._round(v * self.HEADROOM) for k, v in sizes.items()}
         far = torch.full((n_cap, pts.shape[1]), 1.0e6, dtype=pts.dtype, device=pts.device)  # out of every range: dropped
@@ -171,49 +172,52 @@ class GraphedFrame:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(self.warmup):
-                self._run(static_pts, caps, img_metas)
+                self._run(static_pts, caps, img_metas, img_feats)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(graph):
-            scores, boxes, counts, sel = self._run(static_pts, caps, img_metas)
+            scores, boxes, counts, sel = self._run(static_pts, caps, img_metas, img_feats)
         self.stats["captures"] += 1
         self.entry = dict(graph=graph, pts=static_pts, far=far, n_cap=n_cap, nf=pts.shape[1], caps=caps, scores=scores, boxes=boxes,
-                          counts=counts[0], limits=counts[1], sel=sel)
+                          counts=counts[0], limits=counts[1], sel=sel,
+                          img_key=None if img_feats is None else tuple(f.data_ptr() for f in img_feats))
         return self.entry
 
-    def _run(self, static_pts, caps, img_metas):
+    def _run(self, static_pts, caps, img_metas, img_feats=None):
         m = self.model
         bev, counts = m.extract_bev_static(static_pts, caps)
         x = m.pts_backbone(bev)
         if m.pts_neck is not None:
             x = m.pts_neck(x)
-        logits, boxes = m.bbox_head(None, x, img_metas)
+        logits, boxes = m.bbox_head(img_feats, x, img_metas)
         scores, dec = m.bbox_head.decode(logits, boxes)
         sel = m.bbox_head.select_static(scores, dec) if getattr(m.bbox_head, "use_nms", False) else None
         dev_counts = torch.cat([c[1].view(1) for c in counts])
         limits = [c[2] for c in counts]
         return scores, dec, (dev_counts, limits), sel
 
-    def _eager(self, pts, img_metas):
+    def _eager(self, pts, img_metas, img_feats=None):
         m = self.model
         self.stats["eager"] += 1
         bev, sizes = self._measure(pts)
         x = m.pts_backbone(bev)
         if m.pts_neck is not None:
             x = m.pts_neck(x)
-        logits, boxes = m.bbox_head(None, x, img_metas)
+        logits, boxes = m.bbox_head(img_feats, x, img_metas)
         scores, dec = m.bbox_head.decode(logits, boxes)
         return scores, dec, sizes
 
-    def __call__(self, pts, img_metas):
+    def __call__(self, pts, img_metas, img_feats=None):
+        """img_feats: persistent image-feature buffers (GraphedImageBranch) already scheduled on the current stream."""
         e = self.entry
-        if e is None or pts.shape[0] > e["n_cap"] or pts.shape[1] != e["nf"]:
-            scores, dec, sizes = self._eager(pts, img_metas)
+        img_key = None if img_feats is None else tuple(f.data_ptr() for f in img_feats)
+        if e is None or pts.shape[0] > e["n_cap"] or pts.shape[1] != e["nf"] or e["img_key"] != img_key:
+            scores, dec, sizes = self._eager(pts, img_metas, img_feats)
             if e is not None:  # keep the larger of the old and new requirements
                 sizes = {k: max(v, int(e["caps"][k] / self.HEADROOM)) for k, v in sizes.items()}
             n_cap = self._round(max(pts.shape[0] * 1.1, e["n_cap"] if e is not None else 0))
-            self._capture(pts, img_metas, sizes, n_cap)
+            self._capture(pts, img_metas, sizes, n_cap, img_feats)
             return scores, dec, None
         n = pts.shape[0]
         e["pts"][:n].copy_(pts)
@@ -223,8 +227,8 @@ class GraphedFrame:
         self.stats["replays"] += 1
         counts = e["counts"].tolist()  # the one read-back of the frame; the detections are complete by then
         if any(c > lim for c, lim in zip(counts, e["limits"])):
-            scores, dec, sizes = self._eager(pts, img_metas)
+            scores, dec, sizes = self._eager(pts, img_metas, img_feats)
             sizes = {k: max(v, int(e["caps"][k] / self.HEADROOM)) for k, v in sizes.items()}
-            self._capture(pts, img_metas, sizes, e["n_cap"])
+            self._capture(pts, img_metas, sizes, e["n_cap"], img_feats)
             return scores, dec, None
         return e["scores"], e["boxes"], e["sel"]

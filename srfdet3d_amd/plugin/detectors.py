@@ -62,9 +62,9 @@ class SRFDet(BaseModule):
         from ..graphs import GraphedFrame, GraphedImageBranch, GraphedTail
         self._graphed_tail = GraphedTail(self) if enabled else None
         self._graphed_img = GraphedImageBranch(self, overlap=img_overlap) if (enabled and self.use_img) else None
-        # LiDAR-only, hard voxelization: the whole frame replays as one graph (no host read-back inside the frame)
-        self._graphed_frame = GraphedFrame(self) if (enabled and whole_frame and not self.use_img and GraphedFrame.eligible(self)) \
-            else None
+        # hard voxelization: the whole LiDAR frame replays as one graph (no host read-back inside the frame); with
+        # cameras it reads the image graph's feature buffers in place
+        self._graphed_frame = GraphedFrame(self) if (enabled and whole_frame and GraphedFrame.eligible(self)) else None
         return self
 
     def init_weights(self):
@@ -92,8 +92,13 @@ class SRFDet(BaseModule):
         return self.simple_test(img[0], points[0], img_metas[0], **kwargs)
 
     def _test_bboxes(self, img, points, img_metas):
-        if (self._graphed_frame is not None and not self.training and img is None and points is not None and len(points) == 1):
-            return self._finish(*self._graphed_frame(points[0], img_metas), img_metas)
+        if (self._graphed_frame is not None and not self.training and points is not None and len(points) == 1
+                and (img is None or self._graphed_img is not None)):
+            img_feats = None
+            if img is not None:
+                img_feats, img_done = self._graphed_img(img, img_metas)
+                torch.cuda.current_stream().wait_event(img_done)
+            return self._finish(*self._graphed_frame(points[0], img_metas, img_feats), img_metas)
         if self._graphed_tail is not None and not self.training and points is not None:
             img_static = False
             if img is not None and self._graphed_img is not None:
