@@ -77,7 +77,8 @@ def test_decoder_stage_by_stage_on_real_features(setup, dev):
 def test_hip_graph_tail_equals_eager(setup, dev):
     cpu, gpu, pts = setup
     import copy
-    g = copy.deepcopy(gpu).enable_hip_graphs()
+    g = copy.deepcopy(gpu).enable_hip_graphs(whole_frame=False)   # tail-only graph: what the dynamic-voxel configs use
+    assert g._graphed_frame is None
     metas = [dict(box_type_3d=LiDARInstance3DBoxes)]
     for seed in (2000, 2001, 2000):
         p = torch.from_numpy(S.nuscenes_sweep(seed)).to(dev)
@@ -190,8 +191,8 @@ def test_lc_frame_eager_graphs_and_overlap_agree(dev):
         feats_plain = eager.extract_img_feat(img, copy.deepcopy(metas))
     for a, b in zip(feats_fused, feats_plain):
         torch.testing.assert_close(a, b.detach(), rtol=1e-4, atol=1e-4)
-    for overlap in (False, True):
-        g = copy.deepcopy(cpu).to(dev).enable_hip_graphs(img_overlap=overlap)
+    for overlap, whole in ((False, True), (True, True), (False, False)):
+        g = copy.deepcopy(cpu).to(dev).enable_hip_graphs(img_overlap=overlap, whole_frame=whole)
         for rep in range(2):  # second pass replays the captured graphs
             for p, want in zip(frames, ref):
                 with torch.no_grad():
