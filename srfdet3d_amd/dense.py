@@ -94,3 +94,29 @@ def run_sequential(seq, x):
             x = m(x)
             i += 1
     return x
+
+
+def linear_graph_safe(lin, x):
+    """nn.Linear for inference on the GPU through this library's f32-MFMA GEMM (ops.linear) instead of rocBLAS / hipBLASLt.
+
+    Why: for skinny problems (the DPG layers have M = batch size) the BLAS libraries pick split-K kernels that accumulate
+    with atomics into an output they first clear with hipMemsetAsync; captured into a hipGraph that clear becomes a memset
+    node, which on this ROCm does not reliably take effect on replay -- the layer then returns correct values on the first
+    replay and different ones from the second on (found on `dpg_fc1_img`, 900 -> 1500 at M = 1).  ops.linear has no
+    memsets.  K is zero-padded to a multiple of 4 (cached) when needed."""
+    if not (fusable(x) and x.dim() == 2 and lin.weight.is_cuda):
+        return lin(x)
+    K = lin.in_features
+    w = lin.weight
+    if K % 4:
+        vers = (w._version, w.data_ptr())
+        cache = getattr(lin, "_srf_padded", None)
+        if cache is None or cache[0] != vers:
+            Kp = (K + 3) // 4 * 4
+            wp = w.new_zeros((w.shape[0], Kp))
+            wp[:, :K] = w.detach()
+            cache = (vers, wp)
+            lin._srf_padded = cache
+        w = cache[1]
+        x = torch.nn.functional.pad(x, (0, w.shape[1] - K))
+    return ops.linear(x.contiguous(), w, lin.bias)

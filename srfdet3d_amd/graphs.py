@@ -8,7 +8,73 @@ the data-dependent head of the path (voxelization, rulebooks, sparse convs) and 
 Capture is legal because nothing in the tail allocates through hipMalloc, synchronises or reads back to the host:
 the C-ABI entry points only enqueue on the current stream, and workspaces come from torch's graph-private pool.
 """
+import numpy as np
 import torch
+
+
+def _l2i_host(img_metas):
+    """(bs, n_cam, 4, 4) float32 lidar->image matrices of this call, or None (as heads._lidar2img lays them out)."""
+    if not img_metas or not isinstance(img_metas[0], dict) or "lidar2img" not in img_metas[0]:
+        return None
+    m = np.asarray([meta["lidar2img"] for meta in img_metas], dtype=np.float32)
+    return np.ascontiguousarray(m[:, None] if m.ndim == 3 else m)
+
+
+def _graph_safe_convs():
+    """Context for everything that is warmed up for / captured into a hipGraph.
+
+    MIOpen's split-K implicit-GEMM kernels (`..._gkgs`) accumulate with atomics into an output that MIOpen first clears
+    with hipMemsetAsync.  Captured, that clear becomes a graph MEMSET NODE, and on this ROCm memset nodes do not reliably
+    take effect on replay (the same defect that made this library replace its own memsets by fill kernels): the
+    convolution then keeps adding to the previous replay's output -- correct on the first replay, wrong by a constant
+    amount from the second on.  Those kernels are non-deterministic, so asking for deterministic algorithms keeps
+    MIOpen away from them inside graphs; eager execution is unaffected."""
+    return torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True)
+
+
+class GraphValidationError(RuntimeError):
+    pass
+
+
+def _validate(graph, outputs, reference, what, rtol=1e-3, atol=1e-4):
+    """Replay a freshly captured graph THREE times on unchanged inputs and require every replay to reproduce the eager
+    result.  A captured library call that depends on a memset node (see _graph_safe_convs / dense.linear_graph_safe) is
+    right on the first replay and wrong afterwards; this turns that silent corruption into an error at capture time, and
+    the caller falls back to eager execution."""
+    for rep in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        for o, r in zip(outputs, reference):
+            if not torch.allclose(o.float(), r.float(), rtol=rtol, atol=atol):
+                err = (o.float() - r.float()).abs().max().item()
+                raise GraphValidationError(f"{what}: replay {rep} differs from eager execution by {err:.3e}; "
+                                           f"the graph is discarded and this path runs eagerly")
+
+
+class _StaticMetas:
+    """The head reads `lidar2img` through a device tensor cached in the metas ("srf_lidar2img_dev").  A captured graph
+    would keep reading the capture-time matrices, while real data brings new ones every frame (ego-motion between the
+    camera and LiDAR timestamps): the graph therefore owns ONE persistent device buffer, captured by address, that is
+    refreshed with a small host->device copy before a replay whenever the matrices changed."""
+
+    def __init__(self, img_metas, device):
+        self.host = _l2i_host(img_metas)
+        self.metas = [dict(m) if isinstance(m, dict) else m for m in img_metas]
+        self.dev = None
+        if self.host is not None:
+            self.dev = torch.from_numpy(self.host).to(device)
+            self.metas[0]["srf_lidar2img_dev"] = self.dev
+
+    def refresh(self, img_metas):
+        if self.dev is None:
+            return True
+        h = _l2i_host(img_metas)
+        if h is None or h.shape != self.host.shape:
+            return False  # different rig layout: the caller recaptures
+        if not np.array_equal(h, self.host):
+            self.host = h
+            self.dev.copy_(torch.from_numpy(h), non_blocking=False)
+        return True
 
 
 class GraphedTail:
@@ -33,6 +99,8 @@ class GraphedTail:
         key = (tuple(bev.shape), None if img_feats is None else tuple(tuple(f.shape) for f in img_feats),
                None if not img_static else tuple(f.data_ptr() for f in img_feats))
         e = self.entries.get(key)
+        if e is not None and not e["metas"].refresh(img_metas):
+            e = None
         if e is None:
             e = self._capture(key, bev, img_feats, img_metas, img_static)
         e["bev"].copy_(bev)
@@ -47,17 +115,20 @@ class GraphedTail:
         static_img = None
         if img_feats is not None:
             static_img = list(img_feats) if img_static else [f.clone() for f in img_feats]
+        sm = _StaticMetas(img_metas, bev.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
+        with torch.cuda.stream(side), torch.no_grad(), _graph_safe_convs():
             for _ in range(self.warmup):  # MIOpen / rocBLAS pick their kernels here, outside the capture
-                self._run(static_bev, static_img, img_metas)
+                ref = self._run(static_bev, static_img, sm.metas)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        ref = [ref[0].clone(), ref[1].clone()]
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph):
-            scores, boxes, sel = self._run(static_bev, static_img, img_metas)
-        e = dict(graph=graph, bev=static_bev, img=static_img, scores=scores, boxes=boxes, sel=sel)
+        with torch.no_grad(), _graph_safe_convs(), torch.cuda.graph(graph):
+            scores, boxes, sel = self._run(static_bev, static_img, sm.metas)
+        _validate(graph, [scores, boxes], ref, "tail graph")
+        e = dict(graph=graph, bev=static_bev, img=static_img, scores=scores, boxes=boxes, sel=sel, metas=sm)
         self.entries[key] = e
         return e
 
@@ -97,15 +168,17 @@ class GraphedImageBranch:
         static_img = img.clone()
         side = self.stream
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
+        with torch.cuda.stream(side), torch.no_grad(), _graph_safe_convs():
             for _ in range(self.warmup):
-                m.extract_img_feat(static_img, img_metas)
+                ref = m.extract_img_feat(static_img, img_metas)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        ref = [r.clone() for r in ref]
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph, stream=side):
+        with torch.no_grad(), _graph_safe_convs(), torch.cuda.graph(graph, stream=side):
             feats = m.extract_img_feat(static_img, img_metas)
         torch.cuda.synchronize()
+        _validate(graph, feats, ref, "image-branch graph")
         e = dict(graph=graph, img=static_img, feats=feats, done=torch.cuda.Event())
         self.entries[key] = e
         return e
@@ -168,19 +241,22 @@ class GraphedFrame:
         far = torch.full((n_cap, pts.shape[1]), 1.0e6, dtype=pts.dtype, device=pts.device)  # out of every range: dropped
         static_pts = far.clone()
         static_pts[:pts.shape[0]] = pts
+        sm = _StaticMetas(img_metas, pts.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
+        with torch.cuda.stream(side), torch.no_grad(), _graph_safe_convs():
             for _ in range(self.warmup):
-                self._run(static_pts, caps, img_metas, img_feats)
+                ref = self._run(static_pts, caps, sm.metas, img_feats)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        ref = [ref[0].clone(), ref[1].clone()]
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph):
-            scores, boxes, counts, sel = self._run(static_pts, caps, img_metas, img_feats)
+        with torch.no_grad(), _graph_safe_convs(), torch.cuda.graph(graph):
+            scores, boxes, counts, sel = self._run(static_pts, caps, sm.metas, img_feats)
+        _validate(graph, [scores, boxes], ref, "whole-frame graph")
         self.stats["captures"] += 1
         self.entry = dict(graph=graph, pts=static_pts, far=far, n_cap=n_cap, nf=pts.shape[1], caps=caps, scores=scores, boxes=boxes,
-                          counts=counts[0], limits=counts[1], sel=sel,
+                          counts=counts[0], limits=counts[1], sel=sel, metas=sm,
                           img_key=None if img_feats is None else tuple(f.data_ptr() for f in img_feats))
         return self.entry
 
@@ -212,7 +288,8 @@ class GraphedFrame:
         """img_feats: persistent image-feature buffers (GraphedImageBranch) already scheduled on the current stream."""
         e = self.entry
         img_key = None if img_feats is None else tuple(f.data_ptr() for f in img_feats)
-        if e is None or pts.shape[0] > e["n_cap"] or pts.shape[1] != e["nf"] or e["img_key"] != img_key:
+        if (e is None or pts.shape[0] > e["n_cap"] or pts.shape[1] != e["nf"] or e["img_key"] != img_key
+                or not e["metas"].refresh(img_metas)):
             scores, dec, sizes = self._eager(pts, img_metas, img_feats)
             if e is not None:  # keep the larger of the old and new requirements
                 sizes = {k: max(v, int(e["caps"][k] / self.HEADROOM)) for k, v in sizes.items()}

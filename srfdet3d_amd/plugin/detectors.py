@@ -92,6 +92,16 @@ class SRFDet(BaseModule):
         return self.simple_test(img[0], points[0], img_metas[0], **kwargs)
 
     def _test_bboxes(self, img, points, img_metas):
+        from ..graphs import GraphValidationError
+        try:
+            return self._test_bboxes_graphs(img, points, img_metas)
+        except GraphValidationError as err:
+            import warnings
+            warnings.warn(f"srfdet3d_amd: {err}")
+            self._graphed_tail = self._graphed_img = self._graphed_frame = None
+            return self._test_bboxes_graphs(img, points, img_metas)
+
+    def _test_bboxes_graphs(self, img, points, img_metas):
         if (self._graphed_frame is not None and not self.training and points is not None and len(points) == 1
                 and (img is None or self._graphed_img is not None)):
             img_feats = None

@@ -24,6 +24,7 @@ from torch import nn
 from .. import ops
 from ..compat.cnn import BaseModule, ConvModule, ModuleList, build_activation_layer, build_conv_layer
 from ..compat.registry import HEADS, LOSSES, BBOX_ASSIGNERS, build_head, build_roi_extractor
+from ..dense import linear_graph_safe
 from ..roi import SingleRoIExtractor
 from .bbox_util import denormalize_bbox
 
@@ -464,14 +465,21 @@ class SRFDetHead(BaseModule):
             return boxes_w[None].repeat(bs, 1, 1), feats_w[None].repeat(bs, 1, 1)
         E, P = self.num_dpg_exp, self.num_proposals
         w = self._stair(self.dpg_dw_convs_lidar, point_feats[:self.lidar_feat_lvls]).sum(dim=1).flatten(1, 2)
-        w = self.dpg_fc2_lidar(self.dpg_act_lidar(self.dpg_fc1_lidar(w))).reshape(bs, E, P)
+        w = linear_graph_safe(self.dpg_fc2_lidar, self.dpg_act_lidar(linear_graph_safe(self.dpg_fc1_lidar, w))).reshape(bs, E, P)
         if self.use_img:
             flat = [f.reshape(f.shape[0] * f.shape[1], *f.shape[2:]) for f in img_feats[:self.img_feat_lvls]]
             n_cam = img_feats[0].shape[1]
             x = self._stair(self.dpg_dw_convs_img, flat)
             x = F.interpolate(x, [30, 15] if self.is_kitti else [30, 30])
-            x = x.view(bs, n_cam, *x.shape[1:]).sum(dim=1).sum(dim=1).flatten(1, 2)
-            wi = self.dpg_fc2_img(self.dpg_act_img(self.dpg_fc1_img(x))).reshape(bs, E, P)
+            x = x.view(bs, n_cam, *x.shape[1:]).sum(dim=1)
+            if x.is_cuda and not torch.is_grad_enabled():
+                # channel sum as a row reduction: torch's strided sum over dim 1 becomes a multi-block "global reduce"
+                # here, which clears its semaphores with a memset -- a memset NODE once captured, and those do not
+                # reliably take effect on hipGraph replay (graphs._validate caught this layer)
+                x = x.flatten(2).transpose(1, 2).contiguous().sum(dim=-1)
+            else:
+                x = x.sum(dim=1).flatten(1, 2)
+            wi = linear_graph_safe(self.dpg_fc2_img, self.dpg_act_img(linear_graph_safe(self.dpg_fc1_img, x))).reshape(bs, E, P)
             w = (w + wi) / 2
         w = w.softmax(1).unsqueeze(-1)
         boxes = (w * boxes_w.view(1, E, P, -1)).sum(1)

@@ -179,27 +179,58 @@ def test_lc_frame_eager_graphs_and_overlap_agree(dev):
     torch.manual_seed(2)
     cpu = workloads.build("srfdet_voxel_nusc_LC", 48).eval()
     _randomize_bn(cpu, 2)
+    # random weights give sigmoid scores around 0.5 at best: lower the threshold so that the NMS really has work to do
+    cpu.bbox_head.test_cfg = dict(cpu.bbox_head.test_cfg, score_thr=0.02)
     eager = copy.deepcopy(cpu).to(dev)
     metas = [dict(box_type_3d=LiDARInstance3DBoxes, lidar2img=[m for m in S.camera_rig(f=1266.0 * 256 / 1600, cx=128.0, cy=80.0)])]
     img = torch.from_numpy(S.camera_images(3000, h=160, w=256)).to(dev)
     frames = [torch.from_numpy(S.nuscenes_sweep(2000 + i, 12000)).to(dev) for i in range(2)]
+    def decoded_eager(p, mt):
+        mt = copy.deepcopy(mt)
+        with torch.no_grad():
+            img_feats, pt_feats = eager.extract_feat(img, [p], mt)
+            return eager.bbox_head.decode(*eager.bbox_head(img_feats, pt_feats, mt))
+
+    def decoded_graph(g, p, mt):
+        """runs the frame through the graphs, returns the detections and the pre-NMS tensors the graph produced (the parity
+        contract is on those; which of two nearly tied boxes survives the NMS may flip on the last bits)"""
+        with torch.no_grad():
+            det = g.simple_test(img, [p], copy.deepcopy(mt))[0]["pts_bbox"]
+        e = g._graphed_frame.entry if g._graphed_frame is not None else list(g._graphed_tail.entries.values())[-1]
+        return det, e["scores"].clone(), e["boxes"].clone()
+
+    def close(got_s, got_b, want):
+        torch.testing.assert_close(got_s, want[0], rtol=0, atol=1e-5)
+        torch.testing.assert_close(got_b, want[1], rtol=2e-5, atol=1e-4)
+
     with torch.no_grad():
-        ref = [eager.simple_test(img, [p], copy.deepcopy(metas))[0]["pts_bbox"] for p in frames]
+        ref = [decoded_eager(p, metas) for p in frames]
+        ref_det = [eager.simple_test(img, [p], copy.deepcopy(metas))[0]["pts_bbox"] for p in frames]
+        assert all(r["scores_3d"].numel() > 5 for r in ref_det), "the test needs detections"
         # plain module chain for the image branch (no fused passes): autocast-free fp32, grad mode on disables fusion
         feats_fused = eager.extract_img_feat(img, copy.deepcopy(metas))
     with torch.enable_grad():
         feats_plain = eager.extract_img_feat(img, copy.deepcopy(metas))
     for a, b in zip(feats_fused, feats_plain):
         torch.testing.assert_close(a, b.detach(), rtol=1e-4, atol=1e-4)
+    metas2 = [dict(box_type_3d=LiDARInstance3DBoxes,
+                   lidar2img=[m for m in S.camera_rig(f=1266.0 * 256 / 1600 * 1.3, cx=120.0, cy=70.0, cam_h=1.2)])]
+    ref2 = decoded_eager(frames[0], metas2)
+    assert (ref2[1] - ref[0][1]).abs().max() > 1e-3, "the second calibration must change the result"
     for overlap, whole in ((False, True), (True, True), (False, False)):
         g = copy.deepcopy(cpu).to(dev).enable_hip_graphs(img_overlap=overlap, whole_frame=whole)
-        for rep in range(2):  # second pass replays the captured graphs
-            for p, want in zip(frames, ref):
-                with torch.no_grad():
-                    got = g.simple_test(img, [p], copy.deepcopy(metas))[0]["pts_bbox"]
-                assert torch.equal(got["labels_3d"], want["labels_3d"])
-                torch.testing.assert_close(got["scores_3d"], want["scores_3d"], rtol=0, atol=1e-5)
-                torch.testing.assert_close(got["boxes_3d"].tensor, want["boxes_3d"].tensor, rtol=0, atol=1e-4)
+        with torch.no_grad():
+            g.simple_test(img, [frames[0]], copy.deepcopy(metas))  # first call: eager + capture; replays from here on
+        for rep in range(2):
+            for p, want, want_det in zip(frames, ref, ref_det):
+                det, gs, gb = decoded_graph(g, p, metas)
+                close(gs, gb, want)
+                assert abs(det["scores_3d"].numel() - want_det["scores_3d"].numel()) <= 2
+        # new calibration on a later frame (real data: lidar2img changes every sample): the replay must use it
+        _, gs, gb = decoded_graph(g, frames[0], metas2)
+        close(gs, gb, ref2)
+        _, gs, gb = decoded_graph(g, frames[0], metas)
+        close(gs, gb, ref[0])
 
 
 def test_whole_frame_graph_equals_eager(setup, dev):
@@ -212,10 +243,13 @@ def test_whole_frame_graph_equals_eager(setup, dev):
     metas = [dict(box_type_3d=LiDARInstance3DBoxes)]
 
     def same(a, b):
+        assert b["scores_3d"].numel() > 5, "the test needs detections to compare"
         assert torch.equal(a["labels_3d"], b["labels_3d"])
         torch.testing.assert_close(a["scores_3d"], b["scores_3d"], rtol=0, atol=1e-5)
-        torch.testing.assert_close(a["boxes_3d"].tensor, b["boxes_3d"].tensor, rtol=0, atol=1e-4)
+        torch.testing.assert_close(a["boxes_3d"].tensor, b["boxes_3d"].tensor, rtol=2e-5, atol=1e-4)
 
+    gpu = copy.deepcopy(gpu)
+    gpu.bbox_head.test_cfg = dict(gpu.bbox_head.test_cfg, score_thr=0.02)   # so that the NMS has candidates
     g = copy.deepcopy(gpu).enable_hip_graphs()
     assert g._graphed_frame is not None
     sweeps = [S.nuscenes_sweep(2000, 30000), S.nuscenes_sweep(2001, 30000), S.nuscenes_sweep(2002, 24000),
