@@ -127,6 +127,7 @@ class GraphedTail:
         graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), _graph_safe_convs(), torch.cuda.graph(graph):
             scores, boxes, sel = self._run(static_bev, static_img, sm.metas)
+        # (the NMS selection is not compared: which of two nearly tied candidates comes first may differ on the last bits)
         _validate(graph, [scores, boxes], ref, "tail graph")
         e = dict(graph=graph, bev=static_bev, img=static_img, scores=scores, boxes=boxes, sel=sel, metas=sm)
         self.entries[key] = e
@@ -249,11 +250,11 @@ class GraphedFrame:
                 ref = self._run(static_pts, caps, sm.metas, img_feats)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        ref = [ref[0].clone(), ref[1].clone()]
+        ref = [ref[0].clone(), ref[1].clone(), ref[2][0].clone()]
         graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), _graph_safe_convs(), torch.cuda.graph(graph):
             scores, boxes, counts, sel = self._run(static_pts, caps, sm.metas, img_feats)
-        _validate(graph, [scores, boxes], ref, "whole-frame graph")
+        _validate(graph, [scores, boxes, counts[0]], ref, "whole-frame graph")
         self.stats["captures"] += 1
         self.entry = dict(graph=graph, pts=static_pts, far=far, n_cap=n_cap, nf=pts.shape[1], caps=caps, scores=scores, boxes=boxes,
                           counts=counts[0], limits=counts[1], sel=sel, metas=sm,
