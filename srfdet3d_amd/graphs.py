@@ -20,8 +20,12 @@ def _l2i_host(img_metas):
     return np.ascontiguousarray(m[:, None] if m.ndim == 3 else m)
 
 
-def _graph_safe_convs():
-    """Context for everything that is warmed up for / captured into a hipGraph.
+def _graph_safe_convs(safe=True):
+    """Context for everything that is warmed up for / captured into a hipGraph (safe=False: a no-op context).
+
+    Captures are first tried with MIOpen's normal algorithm choice; if the validation of the graph fails they are repeated
+    under this context (see `_capture_with_fallback`), because deterministic algorithms can be slower for some shapes
+    (Waymo's 192 x 192 BEV maps: -15 % frames/s).
 
     MIOpen's split-K implicit-GEMM kernels (`..._gkgs`) accumulate with atomics into an output that MIOpen first clears
     with hipMemsetAsync.  Captured, that clear becomes a graph MEMSET NODE, and on this ROCm memset nodes do not reliably
@@ -29,7 +33,18 @@ def _graph_safe_convs():
     convolution then keeps adding to the previous replay's output -- correct on the first replay, wrong by a constant
     amount from the second on.  Those kernels are non-deterministic, so asking for deterministic algorithms keeps
     MIOpen away from them inside graphs; eager execution is unaffected."""
+    if not safe:
+        import contextlib
+        return contextlib.nullcontext()
     return torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True)
+
+
+def _capture_with_fallback(capture):
+    """capture(safe) -> entry; normal MIOpen algorithms first, deterministic ones if the replay check fails."""
+    try:
+        return capture(False)
+    except GraphValidationError:
+        return capture(True)
 
 
 class GraphValidationError(RuntimeError):
@@ -102,7 +117,7 @@ class GraphedTail:
         if e is not None and not e["metas"].refresh(img_metas):
             e = None
         if e is None:
-            e = self._capture(key, bev, img_feats, img_metas, img_static)
+            e = _capture_with_fallback(lambda safe: self._capture(key, bev, img_feats, img_metas, img_static, safe))
         e["bev"].copy_(bev)
         if img_feats is not None and not img_static:
             for dst, src in zip(e["img"], img_feats):
@@ -110,7 +125,7 @@ class GraphedTail:
         e["graph"].replay()
         return e["scores"], e["boxes"], e["sel"]
 
-    def _capture(self, key, bev, img_feats, img_metas, img_static=False):
+    def _capture(self, key, bev, img_feats, img_metas, img_static=False, safe=False):
         static_bev = bev.clone()
         static_img = None
         if img_feats is not None:
@@ -118,14 +133,14 @@ class GraphedTail:
         sm = _StaticMetas(img_metas, bev.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad(), _graph_safe_convs():
+        with torch.cuda.stream(side), torch.no_grad(), _graph_safe_convs(safe):
             for _ in range(self.warmup):  # MIOpen / rocBLAS pick their kernels here, outside the capture
                 ref = self._run(static_bev, static_img, sm.metas)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ref = [ref[0].clone(), ref[1].clone()]
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), _graph_safe_convs(), torch.cuda.graph(graph):
+        with torch.no_grad(), _graph_safe_convs(safe), torch.cuda.graph(graph):
             scores, boxes, sel = self._run(static_bev, static_img, sm.metas)
         # (the NMS selection is not compared: which of two nearly tied candidates comes first may differ on the last bits)
         _validate(graph, [scores, boxes], ref, "tail graph")
@@ -153,7 +168,7 @@ class GraphedImageBranch:
         e = self.entries.get(key)
         main = torch.cuda.current_stream()
         if e is None:
-            e = self._capture(key, img, img_metas)
+            e = _capture_with_fallback(lambda safe: self._capture(key, img, img_metas, safe))
         for meta in img_metas:
             meta.update(input_shape=img.shape[-2:])
         run_on = self.stream if self.overlap else main
@@ -164,19 +179,19 @@ class GraphedImageBranch:
             e["done"].record(run_on)
         return e["feats"], e["done"]
 
-    def _capture(self, key, img, img_metas):
+    def _capture(self, key, img, img_metas, safe=False):
         m = self.model
         static_img = img.clone()
         side = self.stream
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad(), _graph_safe_convs():
+        with torch.cuda.stream(side), torch.no_grad(), _graph_safe_convs(safe):
             for _ in range(self.warmup):
                 ref = m.extract_img_feat(static_img, img_metas)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ref = [r.clone() for r in ref]
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), _graph_safe_convs(), torch.cuda.graph(graph, stream=side):
+        with torch.no_grad(), _graph_safe_convs(safe), torch.cuda.graph(graph, stream=side):
             feats = m.extract_img_feat(static_img, img_metas)
         torch.cuda.synchronize()
         _validate(graph, feats, ref, "image-branch graph")
@@ -236,7 +251,7 @@ class GraphedFrame:
     def _round(n):
         return max(4096, (int(n) + 4095) // 4096 * 4096)
 
-    def _capture(self, pts, img_metas, sizes, n_cap, img_feats=None):
+    def _capture(self, pts, img_metas, sizes, n_cap, img_feats=None, safe=False):
         m = self.model
         caps = {k: self._round(v * self.HEADROOM) for k, v in sizes.items()}
         far = torch.full((n_cap, pts.shape[1]), 1.0e6, dtype=pts.dtype, device=pts.device)  # out of every range: dropped
@@ -245,14 +260,14 @@ class GraphedFrame:
         sm = _StaticMetas(img_metas, pts.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad(), _graph_safe_convs():
+        with torch.cuda.stream(side), torch.no_grad(), _graph_safe_convs(safe):
             for _ in range(self.warmup):
                 ref = self._run(static_pts, caps, sm.metas, img_feats)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ref = [ref[0].clone(), ref[1].clone(), ref[2][0].clone()]
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), _graph_safe_convs(), torch.cuda.graph(graph):
+        with torch.no_grad(), _graph_safe_convs(safe), torch.cuda.graph(graph):
             scores, boxes, counts, sel = self._run(static_pts, caps, sm.metas, img_feats)
         _validate(graph, [scores, boxes, counts[0]], ref, "whole-frame graph")
         self.stats["captures"] += 1
@@ -295,7 +310,7 @@ class GraphedFrame:
             if e is not None:  # keep the larger of the old and new requirements
                 sizes = {k: max(v, int(e["caps"][k] / self.HEADROOM)) for k, v in sizes.items()}
             n_cap = self._round(max(pts.shape[0] * 1.1, e["n_cap"] if e is not None else 0))
-            self._capture(pts, img_metas, sizes, n_cap, img_feats)
+            _capture_with_fallback(lambda safe: self._capture(pts, img_metas, sizes, n_cap, img_feats, safe))
             return scores, dec, None
         n = pts.shape[0]
         e["pts"][:n].copy_(pts)
@@ -307,6 +322,6 @@ class GraphedFrame:
         if any(c > lim for c, lim in zip(counts, e["limits"])):
             scores, dec, sizes = self._eager(pts, img_metas, img_feats)
             sizes = {k: max(v, int(e["caps"][k] / self.HEADROOM)) for k, v in sizes.items()}
-            self._capture(pts, img_metas, sizes, e["n_cap"], img_feats)
+            _capture_with_fallback(lambda safe: self._capture(pts, img_metas, sizes, e["n_cap"], img_feats, safe))
             return scores, dec, None
         return e["scores"], e["boxes"], e["sel"]

@@ -458,27 +458,30 @@ class SRFDetHead(BaseModule):
                     x = convs[lvl](x)
         return x
 
+    @staticmethod
+    def _channel_sum(x):
+        """(bs, C, H, W) -> (bs, H*W), summed over channels (srfdet_head.py:537).  On the GPU it is done as a row
+        reduction: torch's strided `sum(dim=1)` can become a multi-block "global reduce" that clears its semaphores with
+        a memset -- a memset NODE once captured, and those do not reliably take effect on hipGraph replay
+        (graphs._validate caught this on the image DPG and on the KITTI / Waymo BEV sizes)."""
+        if x.is_cuda and not torch.is_grad_enabled():
+            return x.flatten(2).transpose(1, 2).contiguous().sum(dim=-1)
+        return x.sum(dim=1).flatten(1, 2)
+
     def _get_init_proposals(self, img_feats, point_feats):
         bs = point_feats[0].shape[0]
         boxes_w, feats_w = self.init_proposal_boxes.weight, self.init_proposal_feats.weight
         if not self.with_dpg:
             return boxes_w[None].repeat(bs, 1, 1), feats_w[None].repeat(bs, 1, 1)
         E, P = self.num_dpg_exp, self.num_proposals
-        w = self._stair(self.dpg_dw_convs_lidar, point_feats[:self.lidar_feat_lvls]).sum(dim=1).flatten(1, 2)
+        w = self._channel_sum(self._stair(self.dpg_dw_convs_lidar, point_feats[:self.lidar_feat_lvls]))
         w = linear_graph_safe(self.dpg_fc2_lidar, self.dpg_act_lidar(linear_graph_safe(self.dpg_fc1_lidar, w))).reshape(bs, E, P)
         if self.use_img:
             flat = [f.reshape(f.shape[0] * f.shape[1], *f.shape[2:]) for f in img_feats[:self.img_feat_lvls]]
             n_cam = img_feats[0].shape[1]
             x = self._stair(self.dpg_dw_convs_img, flat)
             x = F.interpolate(x, [30, 15] if self.is_kitti else [30, 30])
-            x = x.view(bs, n_cam, *x.shape[1:]).sum(dim=1)
-            if x.is_cuda and not torch.is_grad_enabled():
-                # channel sum as a row reduction: torch's strided sum over dim 1 becomes a multi-block "global reduce"
-                # here, which clears its semaphores with a memset -- a memset NODE once captured, and those do not
-                # reliably take effect on hipGraph replay (graphs._validate caught this layer)
-                x = x.flatten(2).transpose(1, 2).contiguous().sum(dim=-1)
-            else:
-                x = x.sum(dim=1).flatten(1, 2)
+            x = self._channel_sum(x.view(bs, n_cam, *x.shape[1:]).sum(dim=1))
             wi = linear_graph_safe(self.dpg_fc2_img, self.dpg_act_img(linear_graph_safe(self.dpg_fc1_img, x))).reshape(bs, E, P)
             w = (w + wi) / 2
         w = w.softmax(1).unsqueeze(-1)
