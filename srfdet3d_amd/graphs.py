@@ -223,18 +223,25 @@ class GraphedFrame:
 
     @staticmethod
     def eligible(model):
-        from .plugin.voxel_encoders import HardSimpleVFE
+        from .plugin.voxel_encoders import DynamicVFECustom, HardSimpleVFE
         vl = getattr(model, "pts_voxel_layer", None)
-        return (vl is not None and vl.max_num_points != -1 and isinstance(model.pts_voxel_encoder, HardSimpleVFE)
-                and vl.fused_mean_features == model.pts_voxel_encoder.num_features
-                and getattr(model.pts_middle_encoder, "spatial_sort", False))
+        if vl is None or not getattr(model.pts_middle_encoder, "spatial_sort", False):
+            return False
+        if vl.max_num_points != -1:
+            return (isinstance(model.pts_voxel_encoder, HardSimpleVFE)
+                    and vl.fused_mean_features == model.pts_voxel_encoder.num_features)
+        return isinstance(model.pts_voxel_encoder, DynamicVFECustom) and not model.pts_voxel_encoder.return_point_feats
 
     # ---- capacities ---------------------------------------------------------------------------------------------
     def _measure(self, pts):
         """One eager pass of the sparse half to learn this sweep's sizes."""
         m = self.model
-        voxels, num, coors = m.voxelize([pts])
-        vf = m.pts_voxel_encoder(voxels, num, coors)
+        if m.pts_voxel_layer.max_num_points != -1:
+            voxels, num, coors = m.voxelize([pts])
+            vf = m.pts_voxel_encoder(voxels, num, coors)
+        else:
+            p, pc = m.voxelize([pts])
+            vf, coors = m.pts_voxel_encoder(p, pc)
         enc = m.pts_middle_encoder
         from .sparse import SparseConvTensor, _SparseConv
         sizes = {}
@@ -245,6 +252,8 @@ class GraphedFrame:
         bev = enc(vf, coors, 1)
         for h in hooks:
             h.remove()
+        if m.pts_voxel_layer.max_num_points == -1:
+            sizes["__voxels__"] = coors.shape[0]
         return bev, sizes
 
     @staticmethod

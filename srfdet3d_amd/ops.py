@@ -93,14 +93,17 @@ def hard_voxelize(points, voxel_size, pc_range, max_points, max_voxels, mean_fea
 class VoxelMap:
     """Sorted unique voxels of a (n,4) coordinate list and the point lists of each voxel."""
 
-    def __init__(self, coors, grid_zyx, batch, known_num_voxels=None):
+    def __init__(self, coors, grid_zyx, batch, known_num_voxels=None, static_rows=None):
+        """static_rows: fixed-shape mode for hipGraph replay -- nothing is read back; `coors` / `reduce` have static_rows
+        rows, those past the real count (device scalar `num_dev`) being padding (coordinates -1, zero features)."""
         coors = _dev(coors, "coors", torch.int32)
         n = coors.shape[0]
         L = _lib.lib()
         dev = coors.device
         self.n = n
         rows = max(n, 1)
-        out_coors = _empty((rows, 4), torch.int32, dev)
+        self.static = static_rows is not None
+        out_coors = torch.full((rows, 4), -1, dtype=torch.int32, device=dev) if self.static else _empty((rows, 4), torch.int32, dev)
         self.point2voxel = _empty((rows,), torch.int32, dev)
         self.counts = _empty((rows,), torch.int32, dev)
         self.offsets = _empty((rows,), torch.int32, dev)
@@ -114,14 +117,20 @@ class VoxelMap:
                                  _ptr(self.counts), _ptr(self.offsets), _ptr(self.order), _ptr(self.num_dev), _ptr(ws),
                                  ws_bytes, _stream()), "voxel_unique")
         # the one device->host read of this op; a caller that knows the count (all rows distinct) skips it
-        self.M = int(self.num_dev.item()) if known_num_voxels is None else int(known_num_voxels)
+        if self.static:
+            self.M = min(int(static_rows), rows)
+        else:
+            self.M = int(self.num_dev.item()) if known_num_voxels is None else int(known_num_voxels)
         self.coors = out_coors[:self.M]
         self.point2voxel = self.point2voxel[:n]
 
     def reduce(self, feats, mode):
         feats = _dev(feats, "feats", torch.float32)
         C = feats.shape[1]
-        out = _empty((max(self.M, 1), C), torch.float32, feats.device)
+        if self.static:
+            out = torch.zeros((max(self.M, 1), C), dtype=torch.float32, device=feats.device)
+        else:
+            out = _empty((max(self.M, 1), C), torch.float32, feats.device)
         check(_lib.lib().srf_scatter_reduce(_ptr(feats), _ptr(self.order), _ptr(self.offsets), _ptr(self.counts),
                                             _ptr(self.num_dev), self.M, C, 0 if mode == "mean" else 1, _ptr(out),
                                             _stream()), "scatter_reduce")

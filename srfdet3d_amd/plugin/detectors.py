@@ -182,22 +182,40 @@ class SRFDet(BaseModule):
         return torch.cat(points, 0), torch.cat(coors, 0)
 
     def extract_bev_static(self, points, static_caps):
-        """One sample, hard voxelization, fixed shapes (see graphs.GraphedFrame): `points` (N_cap, C) with out-of-range
-        filler rows -> (bev, [(name, device count, capacity), ...]); nothing is read back to the host."""
+        """One sample, fixed shapes (see graphs.GraphedFrame): `points` (N_cap, C) with out-of-range filler rows ->
+        (bev, [(name, device count, capacity), ...]); nothing is read back to the host."""
         from .. import ops
         vl = self.pts_voxel_layer
-        max_voxels = vl.max_voxels[0] if self.training else vl.max_voxels[1]
-        if max_voxels == -1:
-            max_voxels = points.shape[0]
-        voxels, coors, num, mean, vnum = ops.hard_voxelize(points, vl.voxel_size, vl.point_cloud_range, vl.max_num_points,
-                                                           max_voxels, vl.fused_mean_features, static=True)
-        if mean is not None:
-            voxels.srf_vfe_mean = mean
-        batch = torch.where(coors[:, :1] < 0, -1, 0).to(coors.dtype)  # padding rows keep b = -1
-        coors = torch.cat([batch, coors], dim=1)
-        voxel_features = self.pts_voxel_encoder(voxels, num, coors)
-        bev, counts = self.pts_middle_encoder(voxel_features, coors, 1, static_caps=dict(static_caps, __rows__=vnum))
-        return bev, [("voxels", vnum, voxels.shape[0])] + counts
+        if vl.max_num_points != -1:  # hard voxelization, mean fused in
+            max_voxels = vl.max_voxels[0] if self.training else vl.max_voxels[1]
+            if max_voxels == -1:
+                max_voxels = points.shape[0]
+            voxels, coors, num, mean, vnum = ops.hard_voxelize(points, vl.voxel_size, vl.point_cloud_range, vl.max_num_points,
+                                                               max_voxels, vl.fused_mean_features, static=True)
+            if mean is not None:
+                voxels.srf_vfe_mean = mean
+            batch = torch.where(coors[:, :1] < 0, -1, 0).to(coors.dtype)  # padding rows keep b = -1
+            coors = torch.cat([batch, coors], dim=1)
+            voxel_features = self.pts_voxel_encoder(voxels, num, coors)
+            rows = voxels.shape[0]
+        else:  # dynamic voxelization + DynamicVFECustom: the scatter maps run at a fixed voxel capacity
+            pc = ops.dynamic_voxelize(points, vl.voxel_size, vl.point_cloud_range)
+            batch = torch.where(pc[:, :1] < 0, -1, 0).to(pc.dtype)
+            pt_coors = torch.cat([batch, pc], dim=1)
+            enc = self.pts_voxel_encoder
+            scatters = [enc.scatter, enc.vfe_scatter, enc.cluster_scatter]
+            rows = int(static_caps["__voxels__"])
+            for sc in scatters:
+                sc.static_rows = rows
+            try:
+                voxel_features, coors = enc(points, pt_coors)
+                vnum = enc.cluster_scatter.last_map_static.num_dev
+            finally:
+                for sc in scatters:
+                    sc.static_rows = None
+        caps = {k: v for k, v in static_caps.items() if k != "__voxels__"}
+        bev, counts = self.pts_middle_encoder(voxel_features, coors, 1, static_caps=dict(caps, __rows__=vnum))
+        return bev, [("voxels", vnum, rows)] + counts
 
     def extract_point_features(self, points):
         x = self.pts_backbone(self.extract_bev(points))

@@ -56,6 +56,7 @@ class DynamicScatter(nn.Module):
         gx, gy, gz = ops.grid_size(self.voxel_size, self.point_cloud_range)
         self.grid_zyx = [gz, gy, gx]
         self.last_map = None
+        self.static_rows = None  # set by a caller that needs fixed shapes (graphs.GraphedFrame): see ops.VoxelMap
 
     def voxel_map(self, coors, batch_size=None):
         cached = getattr(coors, "srf_voxel_map", None)
@@ -63,8 +64,10 @@ class DynamicScatter(nn.Module):
             return cached[1]
         c = coors if coors.dtype == torch.int32 else coors.int()
         if batch_size is None:
-            batch_size = int(c[:, 0].max().item()) + 1 if c.shape[0] else 1
-        vm = ops.VoxelMap(c, self.grid_zyx, max(batch_size, 1))
+            batch_size = 1 if self.static_rows is not None else (int(c[:, 0].max().item()) + 1 if c.shape[0] else 1)
+        vm = ops.VoxelMap(c, self.grid_zyx, max(batch_size, 1), static_rows=self.static_rows)
+        if self.static_rows is not None:
+            self.last_map_static = vm
         coors.srf_voxel_map = (coors._version, vm)
         return vm
 

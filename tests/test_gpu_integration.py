@@ -291,3 +291,35 @@ def test_whole_frame_graph_equals_eager(setup, dev):
                 same(g2.simple_test(None, [big], metas)[0]["pts_bbox"], gpu.simple_test(None, [big], metas)[0]["pts_bbox"])
     finally:
         GraphedFrame.HEADROOM = old
+
+
+@pytest.mark.parametrize("name,sweep,npts,np_", [("srfdet_voxel_kitti_L", "kitti_sweep", 17000, 100),
+                                                 ("srfdet_dvoxel_waymo_L", "waymo_sweep", 60000, 64)])
+def test_whole_frame_graph_dynamic_voxel_configs(name, sweep, npts, np_, dev):
+    """GraphedFrame on the dynamic-voxelization configs (DynamicVFECustom at a fixed voxel capacity): the replayed frame
+    must reproduce the eager pre-NMS tensors on several sweeps, including one with fewer points than the buffer."""
+    import copy
+    torch.manual_seed(3)
+    cpu = workloads.build(name, np_).eval()
+    _randomize_bn(cpu, 3)
+    cpu.bbox_head.test_cfg = dict(cpu.bbox_head.test_cfg, score_thr=0.02)
+    eager = copy.deepcopy(cpu).to(dev)
+    g = copy.deepcopy(cpu).to(dev).enable_hip_graphs()
+    assert g._graphed_frame is not None
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes)]
+    seed = 1000 if "kitti" in name else 5000
+    gen = getattr(S, sweep)
+    sweeps = [gen(seed, npts), gen(seed + 1, npts), gen(seed + 2, int(npts * 0.8)), gen(seed, npts)]
+    for i, sw in enumerate(sweeps):
+        p = torch.from_numpy(sw).to(dev)
+        with torch.no_grad():
+            pf = eager.extract_point_features([p])
+            want_s, want_b = eager.bbox_head.decode(*eager.bbox_head(None, pf, metas))
+            det = g.simple_test(None, [p], metas)
+        if i == 0:
+            continue  # first call: eager pass + capture
+        e = g._graphed_frame.entry
+        torch.testing.assert_close(e["scores"], want_s, rtol=0, atol=1e-5)
+        torch.testing.assert_close(e["boxes"], want_b, rtol=2e-5, atol=1e-4)
+    st = g._graphed_frame.stats
+    assert st["replays"] == 3 and st["captures"] == 1, st
