@@ -46,7 +46,8 @@ int srf_device_count(void);
  * strided conv's output bitmap emits the new active set already sorted (a canonical order: independent of scheduling).
  * cell = ((b*H + y)*W + x)*D + z.  shape = host {D,H,W}.  bitmap: srf_bitmap_words() uint32; prefix: as many ints. */
 size_t srf_bitmap_words(const int *shape, int batch);
-/* ints a pair_counts buffer of the srf_bitmap_* entry points must hold: the K counts come first, the rest is scratch
+/* pair_counts may be NULL (the counts are bookkeeping, no kernel needs them).  ints a pair_counts buffer of the
+ * srf_bitmap_* entry points must hold otherwise: the K counts come first, the rest is scratch
  * (replicated counters: hundreds of workgroups adding to one address would serialise in L2) */
 size_t srf_bitmap_pair_count_ints(void);
 size_t srf_bitmap_workspace_bytes(size_t words);

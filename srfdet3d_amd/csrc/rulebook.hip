@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void srf_bm_subm_k(const int4 *__restrict__ in
         if (v >= A) v = -1;  // only after a capacity overflow upstream (the caller checks the counts and redoes the frame)
         nbr[(size_t)k * A + o] = v;
     }
-    srf_bm_count(v >= 0, k, pair_counts);
+    if (pair_counts) srf_bm_count(v >= 0, k, pair_counts);  // uniform branch
 }
 
 __device__ __forceinline__ bool srf_div_stride(int v, int st, int &q)
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void srf_bm_strided_pairs_k(const int4 *__rest
     } else if (fill_tail && o < nbr_stride) {
         nbr[(size_t)k * nbr_stride + o] = -1;
     }
-    srf_bm_count(v >= 0, k, pair_counts);
+    if (pair_counts) srf_bm_count(v >= 0, k, pair_counts);  // uniform branch
 }
 
 static long long srf_bm_cells(const int *shape, int batch)
@@ -569,16 +569,17 @@ extern "C" int srf_bitmap_rulebook_subm(const int *sorted_indices, int A, const 
                                         const void *bitmap, const int *prefix, int *nbr, int *pair_counts, srf_stream_t stream)
 {
     ConvGeom g;
-    if (A < 0 || !shape || !ksize || !pair_counts || !srf_fill_conv_geom(g, shape, ksize, nullptr, nullptr, batch)) return SRF_EINVAL;
+    if (A < 0 || !shape || !ksize || !srf_fill_conv_geom(g, shape, ksize, nullptr, nullptr, batch)) return SRF_EINVAL;
     for (int d = 0; d < 3; ++d)
         if (!(ksize[d] & 1)) return SRF_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    SRF_HIP_TRY(srf_fill_bytes(pair_counts, 0, sizeof(int) * SRF_MAX_K * (SRF_BM_REPLICAS + 1), st));
+    if (pair_counts) SRF_HIP_TRY(srf_fill_bytes(pair_counts, 0, sizeof(int) * SRF_MAX_K * (SRF_BM_REPLICAS + 1), st));
     if (A == 0) return SRF_OK;
     if (!sorted_indices || !nbr || !bitmap || !prefix) return SRF_EINVAL;
     hipLaunchKernelGGL(srf_bm_subm_k, dim3(srf_ceil_div(A, 256), g.K), dim3(256), 0, st, (const int4 *)sorted_indices, A, g,
-                       (const uint32_t *)bitmap, prefix, nbr, pair_counts + SRF_MAX_K);
-    hipLaunchKernelGGL(srf_bm_fold_counts_k, dim3(1), dim3(64), 0, st, pair_counts + SRF_MAX_K, g.K, pair_counts);
+                       (const uint32_t *)bitmap, prefix, nbr, pair_counts ? pair_counts + SRF_MAX_K : nullptr);
+    if (pair_counts)
+        hipLaunchKernelGGL(srf_bm_fold_counts_k, dim3(1), dim3(64), 0, st, pair_counts + SRF_MAX_K, g.K, pair_counts);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }
@@ -617,17 +618,17 @@ extern "C" int srf_bitmap_strided_pairs(const int *out_indices, const int *num_o
                                         int *pair_counts, srf_stream_t stream)
 {
     ConvGeom g;
-    if (max_out < 0 || nbr_stride < max_out || in_rows < 0 || !shape || !ksize || !stride || !pad || !pair_counts || !num_out)
-        return SRF_EINVAL;
+    if (max_out < 0 || nbr_stride < max_out || in_rows < 0 || !shape || !ksize || !stride || !pad || !num_out) return SRF_EINVAL;
     if (!srf_fill_conv_geom(g, shape, ksize, stride, pad, batch)) return SRF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    SRF_HIP_TRY(srf_fill_bytes(pair_counts, 0, sizeof(int) * SRF_MAX_K * (SRF_BM_REPLICAS + 1), st));
+    if (pair_counts) SRF_HIP_TRY(srf_fill_bytes(pair_counts, 0, sizeof(int) * SRF_MAX_K * (SRF_BM_REPLICAS + 1), st));
     if (max_out == 0) return SRF_OK;
     if (!out_indices || !nbr || !in_bitmap || !in_prefix) return SRF_EINVAL;
     hipLaunchKernelGGL(srf_bm_strided_pairs_k, dim3(srf_ceil_div(max_out, 256), g.K), dim3(256), 0, st, (const int4 *)out_indices,
                        num_out, nbr_stride, in_rows, fill_tail, g, (const uint32_t *)in_bitmap, in_prefix, nbr,
-                       pair_counts + SRF_MAX_K);
-    hipLaunchKernelGGL(srf_bm_fold_counts_k, dim3(1), dim3(64), 0, st, pair_counts + SRF_MAX_K, g.K, pair_counts);
+                       pair_counts ? pair_counts + SRF_MAX_K : nullptr);
+    if (pair_counts)
+        hipLaunchKernelGGL(srf_bm_fold_counts_k, dim3(1), dim3(64), 0, st, pair_counts + SRF_MAX_K, g.K, pair_counts);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

@@ -247,15 +247,15 @@ def bitmap_build(indices, spatial_shape, batch, want_order=True, padded=False):
     return lvl, order[:A], sorted_idx[:A]
 
 
-def rulebook_subm_bitmap(sorted_indices, level, ksize):
+def rulebook_subm_bitmap(sorted_indices, level, ksize, want_counts=True):
     sorted_indices = _dev(sorted_indices, "indices", torch.int32)
     A = sorted_indices.shape[0]
     K = int(np.prod(ksize))
     nbr = _empty((K, max(A, 1)), torch.int32, sorted_indices.device)
-    counts = _empty((_lib.lib().srf_bitmap_pair_count_ints(),), torch.int32, sorted_indices.device)
+    counts = _empty((_lib.lib().srf_bitmap_pair_count_ints(),), torch.int32, sorted_indices.device) if want_counts else None
     check(_lib.lib().srf_bitmap_rulebook_subm(_ptr(sorted_indices), A, hi(level.shape), level.batch, hi(ksize), _ptr(level.bitmap),
                                               _ptr(level.prefix), _ptr(nbr), _ptr(counts), _stream()), "bitmap_rulebook_subm")
-    return nbr[:, :A], counts[:K]
+    return nbr[:, :A], (counts[:K] if want_counts else None)
 
 
 def rulebook_strided_bitmap(indices, level, ksize, stride, pad, out_capacity=None):
@@ -287,12 +287,12 @@ def rulebook_strided_bitmap(indices, level, ksize, stride, pad, out_capacity=Non
     # phase 2 reads the count on the device: it is enqueued before the host learns A_out, so the read-back below
     # overlaps it instead of leaving the GPU idle
     nbr = _empty((K, cap), torch.int32, dev)
-    counts = _empty((L.srf_bitmap_pair_count_ints(),), torch.int32, dev)
+    counts = None if static else _empty((L.srf_bitmap_pair_count_ints(),), torch.int32, dev)  # bookkeeping only
     check(L.srf_bitmap_strided_pairs(_ptr(out_idx), _ptr(num_out), bound, hi(level.shape), level.batch, hi(ksize), hi(stride),
                                      hi(pad), _ptr(level.bitmap), _ptr(level.prefix), A, _ptr(nbr), cap, int(static), _ptr(counts),
                                      _stream()), "bitmap_strided_pairs")
     if static:
-        return out_idx, nbr, counts[:K], out_lvl, oshape, num_out
+        return out_idx, nbr, None, out_lvl, oshape, num_out
     A_out = int(num_out.item())
     return out_idx[:A_out], nbr[:, :A_out], counts[:K], out_lvl, oshape
 

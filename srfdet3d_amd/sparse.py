@@ -78,7 +78,8 @@ class SparseConvTensor:
         if key not in self.indice_dict:
             lvl = self.bitmap_level()
             if lvl is not None:
-                self.indice_dict[key] = ops.rulebook_subm_bitmap(self.indices, lvl, ksize)
+                self.indice_dict[key] = ops.rulebook_subm_bitmap(self.indices, lvl, ksize,
+                                                                 want_counts="static" not in self.indice_dict)
             else:
                 self.indice_dict[key] = ops.rulebook_subm(self.indices, self.spatial_shape, ksize, self.coord_table())
         return self.indice_dict[key]
