@@ -603,11 +603,15 @@ __global__ __launch_bounds__(256) void srf_spconv_direct_k(const float *__restri
         for (int j = 0; j < 16; ++j) acc[rt][j] = 0.0f;
 
     const int kh = lane >> 5;
-    f32x4 ra[NA], bq[2][4];
+    // B fragments are fetched PD chunks ahead into one register slot per chunk position (PD = 2 for the 4-chunk layers:
+    // a weight line that was evicted from L2 by the gathers takes longer than one chunk of MFMAs to arrive)
+    constexpr int PD = NCH >= 4 ? 2 : 1, NS = NCH >= 4 ? NCH : 2;
+    f32x4 ra[NA], bq[NS][4];
     unsigned okmask = 0;
     if (ntap > 0) {
         const int k0 = s_klist[0];
         srf_dir_load_b<NCH>(bq[0], Wd, k0, 0, wc, lane);
+        if (PD == 2) srf_dir_load_b<NCH>(bq[1], Wd, k0, 1, wc, lane);
         srf_dir_gather<TM, NCH, NA>(in, s_nbr + k0 * TM, ra, okmask);
         srf_dir_store<TM, NCH, NA>(s_a[0], ra, okmask);
     }
@@ -621,8 +625,13 @@ __global__ __launch_bounds__(256) void srf_spconv_direct_k(const float *__restri
         for (int c = 0; c < NCH; ++c) {
             // B fragments of the next chunk (of this offset or the first of the next one); NCH is even, so the
             // register pair alternates consistently across offsets
-            if (c + 1 < NCH) srf_dir_load_b<NCH>(bq[(c + 1) & 1], Wd, kc, c + 1, wc, lane);
-            else srf_dir_load_b<NCH>(bq[(c + 1) & 1], Wd, kn, 0, wc, lane);  // harmless re-read on the last offset
+            if (PD == 2) {
+                if (c + 2 < NCH) srf_dir_load_b<NCH>(bq[c + 2], Wd, kc, c + 2, wc, lane);
+                else srf_dir_load_b<NCH>(bq[c + 2 - NCH], Wd, kn, c + 2 - NCH, wc, lane);  // harmless re-read on the last offset
+            } else {
+                if (c + 1 < NCH) srf_dir_load_b<NCH>(bq[(c + 1) & 1], Wd, kc, c + 1, wc, lane);
+                else srf_dir_load_b<NCH>(bq[(c + 1) & 1], Wd, kn, 0, wc, lane);
+            }
             // the gather of the next offset goes out AFTER the last B load this offset still has to wait for: vmcnt
             // retires in order, so an earlier gather (an L2 miss more often than not) would be waited for at every
             // chunk; here it has two chunks of MFMAs to land and only the LDS store below waits for it
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(256) void srf_spconv_direct_k(const float *__restri
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
-                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rt][j >> 2][j & 3], bq[c & 1][j >> 2][j & 3], acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rt][j >> 2][j & 3], bq[PD == 2 ? c : (c & 1)][j >> 2][j & 3], acc[rt], 0, 0, 0);
         }
         if (NBUF == 1) __syncthreads();  // single buffer: every wave is done reading before the rows are replaced
         if (more) srf_dir_store<TM, NCH, NA>(s_a[NBUF == 2 ? (buf ^ 1) : 0], ra, okmask);
