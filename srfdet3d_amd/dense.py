@@ -41,7 +41,7 @@ def bn_act_(y, bn, relu):
 
 def conv_bn_act(conv, bn, relu, x):
     y = conv(x)
-    if _foldable(bn) and fusable(y) and y.is_contiguous():
+    if _foldable(bn) and fusable(y) and y.is_contiguous() and y.shape[0] * y.shape[1] <= 65535:  # grid.y of the kernel
         return bn_act_(y, bn, relu)
     y = bn(y)
     return torch.relu_(y) if relu else y

@@ -49,7 +49,8 @@ class eSEModule(nn.Module):
 
     def forward(self, x, identity=None):
         gate = F.relu6(self.fc(x.mean(dim=(2, 3), keepdim=True)) + 3.0) / 6.0
-        if fusable(x) and x.is_contiguous() and (identity is None or identity.is_contiguous()):
+        if (fusable(x) and x.is_contiguous() and (identity is None or identity.is_contiguous())
+                and x.shape[0] * x.shape[1] <= 65535):
             # gate multiply (+ the OSA identity add) in one in-place pass
             return ops.channel_affine(x, gate.reshape(-1), None, False, out=x, residual=identity)
         out = x * gate
