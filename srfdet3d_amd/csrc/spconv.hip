@@ -195,11 +195,11 @@ __global__ __launch_bounds__(256) void srf_spconv_mfma32_k(const float *__restri
         if (v >= 0) s_any[k] = 1;  // benign race: every writer stores 1
     }
     __syncthreads();
-    if (tid == 0) {
-        int n = 0;
-        for (int k = 0; k < K; ++k)
-            if (s_any[k]) s_klist[n++] = k;
-        s_klist[SRF_KMAX] = n;
+    if (tid < 64) {  // compact the used offsets with one ballot (K <= 27 < 64) instead of a serial loop on one lane
+        const bool used = tid < K && s_any[tid];
+        const unsigned long long m = __ballot(used);
+        if (used) s_klist[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+        if (tid == 0) s_klist[SRF_KMAX] = __popcll(m);
     }
     __syncthreads();
     const int nchunk = (Cin + SRF_KC - 1) / SRF_KC;
@@ -424,11 +424,11 @@ __global__ __launch_bounds__(256) void srf_spconv_packed_k(const float *__restri
         if (v >= 0) s_any[k] = 1;  // benign race: every writer stores 1
     }
     __syncthreads();
-    if (tid == 0) {
-        int n = 0;
-        for (int k = 0; k < K; ++k)
-            if (s_any[k]) s_klist[n++] = k;
-        s_klist[SRF_KMAX] = n;
+    if (tid < 64) {  // compact the used offsets with one ballot (K <= 27 < 64) instead of a serial loop on one lane
+        const bool used = tid < K && s_any[tid];
+        const unsigned long long m = __ballot(used);
+        if (used) s_klist[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+        if (tid == 0) s_klist[SRF_KMAX] = __popcll(m);
     }
     __syncthreads();
     const int nchunk = (Cin + SRF_KC - 1) / SRF_KC;
@@ -587,11 +587,11 @@ __global__ __launch_bounds__(256) void srf_spconv_direct_k(const float *__restri
     const int row0 = srf_xcd_tile(blockIdx.x, n_tiles) * TM;
     const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
     srf_load_nbr_tile<TM>(nbr, nbr_stride, K, row0, A_out, s_nbr, s_any);
-    if (tid == 0) {
-        int n = 0;
-        for (int k = 0; k < K; ++k)
-            if (s_any[k]) s_klist[n++] = k;
-        s_klist[SRF_KMAX] = n;
+    if (tid < 64) {  // compact the used offsets with one ballot (K <= 27 < 64) instead of a serial loop on one lane
+        const bool used = tid < K && s_any[tid];
+        const unsigned long long m = __ballot(used);
+        if (used) s_klist[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+        if (tid == 0) s_klist[SRF_KMAX] = __popcll(m);
     }
     __syncthreads();
     const int ntap = s_klist[SRF_KMAX];
