@@ -45,6 +45,19 @@ def test_host_side_helpers():
     # argument validation happens before any HIP call
     assert L.srf_spconv_fwd(None, 0, 16, None, 27, None, 0, 10, 24, None, None, None, 0, None, None, None) == -1
     assert L.srf_roi_extract(None, 0, 128, None, 0, 7, 2, 56.0, None, 0, 0, 0, 0, None, None) == -1
+    # bitmap-rank rulebooks / dense-side helpers: sizes and argument checks, still no GPU work
+    assert L.srf_bitmap_words(hi([41, 1472, 1472]), 1) == (41 * 1472 * 1472 + 31) // 32
+    assert L.srf_bitmap_words(hi([41, 1472, 1472]), 64) == 0          # cell index must fit 32 bits
+    assert L.srf_bitmap_workspace_bytes(2776000) >= (2776000 // 2048 + 1) * 4
+    assert L.srf_bitmap_pair_count_ints() >= 27
+    assert L.srf_bitmap_build(None, -1, hi([41, 1472, 1472]), 1, None, None, None, None, None, 0, None) == -1
+    assert L.srf_conv1x1_packed_weight_bytes(256, 768) == 256 * 768 * 4
+    assert L.srf_conv1x1_packed_weight_bytes(250, 768) == 0           # Cout and K must be multiples of 32
+    assert L.srf_conv1x1(None, None, 0, 1, 16, None, 128, None, None, 0, None, None) == -1
+    assert L.srf_channel_affine(None, -1, 4, 16, 64, None, None, 0, None, 0, None, 64, None) == -1
+    assert L.srf_nms_rotated_counted(None, 10, None, 0.4, None, None, 0, None) == -1
+    assert L.srf_stage_tail(None, 10, 64, 512, *([None] * 6), 1e-5, 2, None, None, None, None, 3, None, None, None, None,
+                            None, None, 10, None, None, 10, None, None, None, 5.0, None, None, None, None) == -3  # C != 128
 
 
 def test_ops_refuse_cpu_tensors():
