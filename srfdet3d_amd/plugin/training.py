@@ -118,6 +118,67 @@ def bbox_overlaps_3d(boxes1, boxes2):
     return inter3d / (v1 + v2 - inter3d).clamp(min=1e-8)
 
 
+@MATCH_COST.register_module()
+class ClassificationCost:
+    """mmdet's softmax classification cost (the default `cls_cost` of HungarianAssignerSRFDet)."""
+
+    def __init__(self, weight=1.0):
+        self.weight = weight
+
+    def __call__(self, cls_pred, gt_labels):
+        return -cls_pred.softmax(-1)[:, gt_labels] * self.weight
+
+
+@MATCH_COST.register_module()
+class BBoxL1Cost(BBox3DL1Cost):
+    """mmdet's name for the plain L1 cost (default `reg_cost` of HungarianAssignerSRFDet); the box format conversions of
+    the 2-D original do not apply to the normalised 3-D boxes it is given here."""
+
+    def __init__(self, weight=1.0, box_format="xyxy"):
+        super().__init__(weight)
+
+
+class AssignResult:
+    """The four fields of mmdet's AssignResult that callers of the assigner read."""
+
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+
+
+@BBOX_ASSIGNERS.register_module()
+class HungarianAssignerSRFDet:
+    """One-to-one matching of predictions to ground truth on cost = classification + L1 over the first 8 normalised box
+    parameters, solved on the host with scipy (hungarian_assigner_srfdet.py:14-129).  No config of the reference enables
+    it (the lines are commented out in favour of OTAssignerSRFDet); it is here so that those lines resolve."""
+
+    def __init__(self, cls_cost=None, reg_cost=None, pc_range=None):
+        self.cls_cost = MATCH_COST.build(cls_cost if cls_cost is not None else dict(type="ClassificationCost", weight=1.0))
+        self.reg_cost = MATCH_COST.build(reg_cost if reg_cost is not None else dict(type="BBoxL1Cost", weight=1.0))
+        self.pc_range = pc_range
+
+    @torch.no_grad()
+    def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_bboxes_ignore=None, eps=1e-7, kdistillation=False):
+        """-> AssignResult: gt_inds[i] = 0 for background or 1 + index of the matched ground truth; labels[i] = its class
+        or -1."""
+        from scipy.optimize import linear_sum_assignment
+        from .bbox_util import normalize_bbox
+        assert gt_bboxes_ignore is None, "gt_bboxes_ignore is not supported (as in the reference)"
+        n_gt, n_q = gt_bboxes.size(0), bbox_pred.size(0)
+        gt_inds = bbox_pred.new_full((n_q,), 0 if n_gt == 0 else -1, dtype=torch.long)
+        labels = bbox_pred.new_full((n_q,), -1, dtype=torch.long)
+        if n_gt == 0 or n_q == 0:
+            return AssignResult(n_gt, gt_inds, None, labels=labels)
+        target = gt_bboxes if kdistillation else normalize_bbox(gt_bboxes, self.pc_range)
+        cost = self.cls_cost(cls_pred, gt_labels) + self.reg_cost(bbox_pred[:, :8], target[:, :8])
+        rows, cols = linear_sum_assignment(cost.detach().cpu().numpy())
+        rows = torch.from_numpy(rows).to(bbox_pred.device)
+        cols = torch.from_numpy(cols).to(bbox_pred.device)
+        gt_inds[:] = 0
+        gt_inds[rows] = cols + 1
+        labels[rows] = gt_labels[cols]
+        return AssignResult(n_gt, gt_inds, None, labels=labels)
+
+
 @BBOX_ASSIGNERS.register_module()
 class OTAssignerSRFDet(nn.Module):
     """1-to-k dynamic matching of predictions to ground truth (ota_srfdet.py:18-327)."""

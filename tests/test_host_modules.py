@@ -89,3 +89,31 @@ def test_naive_sync_bn_single_process_is_plain_bn():
     torch.testing.assert_close(bn(x), ref(x))
     bn.eval(), ref.eval()
     torch.testing.assert_close(bn(x), ref(x))
+
+
+def test_hungarian_assigner_one_to_one():
+    """HungarianAssignerSRFDet (hungarian_assigner_srfdet.py:14-129): each ground truth gets exactly one prediction, the
+    cheapest overall; everything else is background; empty ground truth -> all background."""
+    from srfdet3d_amd.compat.registry import BBOX_ASSIGNERS
+    from srfdet3d_amd.plugin.bbox_util import normalize_bbox
+    import srfdet3d_amd.plugin.training  # noqa: F401  (registers the assigner)
+    asg = BBOX_ASSIGNERS.build(dict(type="HungarianAssignerSRFDet", cls_cost=dict(type="FocalLossCost", weight=2.0),
+                                    reg_cost=dict(type="BBox3DL1Cost", weight=0.25), pc_range=[-50, -50, -5, 50, 50, 3]))
+    g = torch.Generator().manual_seed(0)
+    gt = torch.cat([torch.rand(4, 3, generator=g) * 40 - 20, torch.rand(4, 3, generator=g) * 3 + 1,
+                    torch.rand(4, 1, generator=g) * 3 - 1.5, torch.zeros(4, 2)], 1)
+    gt_labels = torch.tensor([1, 3, 0, 2])
+    pred = torch.randn(12, 10, generator=g)
+    logits = torch.randn(12, 5, generator=g)
+    want_rows = [7, 2, 9, 4]
+    pred[want_rows] = normalize_bbox(gt) + 0.01 * torch.randn(4, 10, generator=g)
+    logits[want_rows, gt_labels] += 6.0
+    res = asg.assign(pred, logits, gt, gt_labels)
+    assert res.num_gts == 4 and (res.gt_inds > 0).sum() == 4
+    assert res.gt_inds[want_rows].tolist() == [1, 2, 3, 4]
+    assert res.labels[want_rows].tolist() == gt_labels.tolist()
+    assert (res.labels[res.gt_inds == 0] == -1).all()
+    empty = asg.assign(pred, logits, gt[:0], gt_labels[:0])
+    assert (empty.gt_inds == 0).all() and empty.num_gts == 0
+    default = BBOX_ASSIGNERS.build(dict(type="HungarianAssignerSRFDet"))     # mmdet's default cost names resolve too
+    assert (default.assign(pred, logits, gt, gt_labels).gt_inds > 0).sum() == 4
