@@ -6,6 +6,7 @@ libsrfdet3d_hip.so (csrc/, C ABI in include/srfdet3d.h); there is no CPU fallbac
 """
 from .compat import Config, build_model  # noqa: F401
 from .compat import necks as _necks  # noqa: F401  (registers FPN)
+from .compat import resnet as _resnet  # noqa: F401  (registers ResNet for the r50 image-backbone configs)
 from .plugin import training  # noqa: F401  (registers losses, match costs and the OTA assigner before the heads build)
 from .plugin import backbones, detectors, heads, middle_encoders, norm, pillar, voxel_encoders, vovnet  # noqa: F401
 from .roi import RoIAlign, SingleRoIExtractor, bbox2roi  # noqa: F401

@@ -13,7 +13,11 @@ from srfdet3d_amd.compat.config import Config
 REF = "/root/reference"
 NAMES = {"srfdet_voxel_nusc_L": "configs/nus/srfdet_voxel_nusc_L.py", "srfdet_voxel_nusc_LC": "configs/nus/srfdet_voxel_nusc_LC.py",
          "srfdet_voxel_kitti_L": "configs/kitti/srfdet_voxel_kitti_L.py", "srfdet_dvoxel_waymo_L": "configs/waymo/srfdet_dvoxel_waymo_L.py",
-         "srfdet_pillar_nusc_L": "configs/nus/srfdet_pillar_nusc_L.py"}
+         "srfdet_pillar_nusc_L": "configs/nus/srfdet_pillar_nusc_L.py", "srfdet_voxel_kitti_LC": "configs/kitti/srfdet_voxel_kitti_LC.py",
+         "srfdet_pillar_v299_nusc_LC": "configs/nus/srfdet_pillar_v299_nusc_LC.py",
+         "srfdet_pillar_r50_nusc_LC": "configs/nus/srfdet_pillar_r50_nusc_LC.py",
+         "srfdet_voxel_r50_nusc_LC": "configs/nus/srfdet_voxel_r50_nusc_LC.py", "srfdet_dvoxel_nusc_L": "configs/others/srfdet_dvoxel_nusc_L.py",
+         "srfdet_dvoxel_waymo_LC": "configs/others/srfdet_dvoxel_waymo_LC.py"}
 
 
 def _plain(o):
@@ -79,3 +83,32 @@ def test_lc_head_builds_with_fusion_stage():
     assert sum(p.numel() for p in head.head_series_lidar[0].parameters()) == 2177492
     keys = set(head.state_dict())
     assert {"img_convs.3.weight", "dpg_fc2_img.weight", "head_series_lidar.0.output_fused_proj.weight"} <= keys
+
+
+@pytest.mark.parametrize("name", ["srfdet_voxel_r50_nusc_LC", "srfdet_dvoxel_nusc_L"])
+def test_additional_configs_build(name):
+    """every config of the reference except the DCNv2 one builds from its unchanged model dict (the large VoVNet ones are
+    built in the GPU tests)."""
+    m = workloads.build(name, 16)
+    assert sum(p.numel() for p in m.parameters()) > 1e6
+
+
+def test_dcn_config_is_refused_loudly():
+    with pytest.raises(NotImplementedError, match="deformable"):
+        workloads.build("srfdet_dvoxel_waymo_LC", 16)
+
+
+def test_resnet_state_dict_names_follow_mmdet():
+    from srfdet3d_amd.compat.registry import build_backbone
+    import torch
+    r = build_backbone(dict(type="ResNet", depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                            norm_cfg=dict(type="BN", requires_grad=True), norm_eval=True, style="pytorch")).eval()
+    keys = set(r.state_dict())
+    for k in ("conv1.weight", "bn1.running_mean", "layer1.0.downsample.0.weight", "layer1.0.downsample.1.weight",
+              "layer3.5.conv2.weight", "layer4.2.bn3.bias"):
+        assert k in keys
+    assert r.layer2[0].conv2.stride == (2, 2) and r.layer2[0].conv1.stride == (1, 1)      # pytorch style
+    assert not r.conv1.weight.requires_grad and not r.layer1[0].conv1.weight.requires_grad and r.layer2[0].conv1.weight.requires_grad
+    with torch.no_grad():
+        outs = r(torch.zeros(1, 3, 64, 96))
+    assert [o.shape[1] for o in outs] == [256, 512, 1024, 2048] and outs[0].shape[-2:] == (16, 24)

@@ -21,6 +21,12 @@ CONFIGS = {
     "srfdet_voxel_kitti_L": "configs/kitti/srfdet_voxel_kitti_L.py",
     "srfdet_dvoxel_waymo_L": "configs/waymo/srfdet_dvoxel_waymo_L.py",
     "srfdet_pillar_nusc_L": "configs/nus/srfdet_pillar_nusc_L.py",
+    "srfdet_voxel_kitti_LC": "configs/kitti/srfdet_voxel_kitti_LC.py",
+    "srfdet_pillar_v299_nusc_LC": "configs/nus/srfdet_pillar_v299_nusc_LC.py",
+    "srfdet_pillar_r50_nusc_LC": "configs/nus/srfdet_pillar_r50_nusc_LC.py",
+    "srfdet_voxel_r50_nusc_LC": "configs/nus/srfdet_voxel_r50_nusc_LC.py",
+    "srfdet_dvoxel_nusc_L": "configs/others/srfdet_dvoxel_nusc_L.py",
+    "srfdet_dvoxel_waymo_LC": "configs/others/srfdet_dvoxel_waymo_LC.py",
 }
 
 
