@@ -3,8 +3,8 @@
 Same constructor arguments the configs use and the same state_dict names as mmdet's ResNet (`conv1`, `bn1`,
 `layer{1-4}.{i}.conv{1-3}/bn{1-3}`, `layer*.0.downsample.{0,1}`), so `Pretrained` checkpoints load by key.  Plain dense
 convolutions on MIOpen; in inference every conv -> BN -> ReLU goes through dense.conv_bn_act (one fused BN + ReLU pass).
-Deformable convolution (`dcn=dict(type='DCNv2')`, used only by configs/others/srfdet_dvoxel_waymo_LC.py) is an mmcv operator
-that is not available here: asking for it raises.
+Stages with `dcn=dict(type='DCNv2')` (only configs/others/srfdet_dvoxel_waymo_LC.py) use compat/dcn.py for the 3x3
+convolution of their bottlenecks.
 """
 import torch
 from torch import nn
@@ -20,12 +20,16 @@ _ARCH = {18: ("basic", (2, 2, 2, 2)), 34: ("basic", (3, 4, 6, 3)), 50: ("bottlen
 class _Bottleneck(nn.Module):
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride, downsample, style, norm_cfg):
+    def __init__(self, inplanes, planes, stride, downsample, style, norm_cfg, dcn=None):
         super().__init__()
         s1, s2 = (1, stride) if style == "pytorch" else (stride, 1)   # caffe style strides the 1x1, pytorch the 3x3
         self.conv1 = nn.Conv2d(inplanes, planes, 1, s1, bias=False)
         self.bn1 = build_norm_layer(norm_cfg, planes)[1]
-        self.conv2 = nn.Conv2d(planes, planes, 3, s2, 1, bias=False)
+        if dcn is not None:
+            from .dcn import ModulatedDeformConv2dPack
+            self.conv2 = ModulatedDeformConv2dPack(planes, planes, 3, s2, 1, deform_groups=dcn.get("deform_groups", 1), bias=False)
+        else:
+            self.conv2 = nn.Conv2d(planes, planes, 3, s2, 1, bias=False)
         self.bn2 = build_norm_layer(norm_cfg, planes)[1]
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
         self.bn3 = build_norm_layer(norm_cfg, planes * 4)[1]
@@ -42,8 +46,9 @@ class _Bottleneck(nn.Module):
 class _BasicBlock(nn.Module):
     expansion = 1
 
-    def __init__(self, inplanes, planes, stride, downsample, style, norm_cfg):
+    def __init__(self, inplanes, planes, stride, downsample, style, norm_cfg, dcn=None):
         super().__init__()
+        assert dcn is None, "DCN is defined for bottleneck blocks only (as in mmdet)"
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
         self.bn1 = build_norm_layer(norm_cfg, planes)[1]
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
@@ -67,8 +72,10 @@ class ResNet(BaseModule):
         super().__init__(init_cfg)
         if depth not in _ARCH:
             raise KeyError(f"invalid depth {depth} for ResNet")
-        if dcn is not None and any(stage_with_dcn):
-            raise NotImplementedError("ResNet with deformable convolution (mmcv DCNv2) is not available in srfdet3d_amd")
+        if dcn is not None:
+            dcn = dict(dcn)
+            if dcn.pop("type", "DCNv2") != "DCNv2" or dcn.pop("fallback_on_stride", False):
+                raise NotImplementedError("only dcn=dict(type='DCNv2', fallback_on_stride=False) is provided")
         if deep_stem or avg_down or plugins is not None or any(d != 1 for d in dilations):
             raise NotImplementedError("only the plain ResNet variants the SRFDet3D configs use are provided")
         kind, blocks = _ARCH[depth]
@@ -89,7 +96,7 @@ class ResNet(BaseModule):
                 if j == 0 and (stride != 1 or inplanes != planes * block.expansion):
                     down = nn.Sequential(nn.Conv2d(inplanes, planes * block.expansion, 1, stride, bias=False),
                                          build_norm_layer(norm_cfg, planes * block.expansion)[1])
-                layers.append(block(inplanes, planes, stride, down, style, norm_cfg))
+                layers.append(block(inplanes, planes, stride, down, style, norm_cfg, dcn if (dcn is not None and stage_with_dcn[i]) else None))
                 inplanes = planes * block.expansion
             name = f"layer{i + 1}"
             self.add_module(name, nn.Sequential(*layers))

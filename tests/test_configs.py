@@ -93,9 +93,50 @@ def test_additional_configs_build(name):
     assert sum(p.numel() for p in m.parameters()) > 1e6
 
 
-def test_dcn_config_is_refused_loudly():
-    with pytest.raises(NotImplementedError, match="deformable"):
-        workloads.build("srfdet_dvoxel_waymo_LC", 16)
+def test_dcnv2_definition():
+    """compat/dcn.py against the definition: zero offsets + unit mask = plain convolution; integer offsets = a shifted
+    tap; fractional offsets = bilinear interpolation with zero padding (checked against an explicit loop)."""
+    import torch
+    import torch.nn.functional as F
+    from srfdet3d_amd.compat.dcn import ModulatedDeformConv2dPack, modulated_deform_conv2d
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 6, 9, 11, generator=g)
+    w = torch.randn(4, 6, 3, 3, generator=g)
+    Ho, Wo = 5, 6     # stride 2, pad 1
+    off0 = torch.zeros(2, 18, Ho, Wo)
+    one = torch.ones(2, 9, Ho, Wo)
+    torch.testing.assert_close(modulated_deform_conv2d(x, off0, one, w, None, 2, 1), F.conv2d(x, w, None, 2, 1), rtol=1e-5, atol=1e-5)
+    off = torch.randn(2, 18, Ho, Wo, generator=g) * 1.5
+    m = torch.rand(2, 9, Ho, Wo, generator=g)
+    got = modulated_deform_conv2d(x, off, m, w, None, 2, 1)
+    want = torch.zeros(2, 4, Ho, Wo)
+    H, W = 9, 11
+    for n in range(2):
+        for ho in range(Ho):
+            for wo in range(Wo):
+                for t in range(9):
+                    i, j = divmod(t, 3)
+                    py = ho * 2 - 1 + i + float(off[n, 2 * t, ho, wo])
+                    px = wo * 2 - 1 + j + float(off[n, 2 * t + 1, ho, wo])
+                    y0, x0 = int(torch.floor(torch.tensor(py))), int(torch.floor(torch.tensor(px)))
+                    v = torch.zeros(6)
+                    for yy, xx, wt in ((y0, x0, (1 - (py - y0)) * (1 - (px - x0))), (y0, x0 + 1, (1 - (py - y0)) * (px - x0)),
+                                       (y0 + 1, x0, (py - y0) * (1 - (px - x0))), (y0 + 1, x0 + 1, (py - y0) * (px - x0))):
+                        if 0 <= yy < H and 0 <= xx < W:
+                            v = v + wt * x[n, :, yy, xx]
+                    want[n, :, ho, wo] += (w[:, :, i, j] @ v) * m[n, t, ho, wo]
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+    pack = ModulatedDeformConv2dPack(6, 4, 3, 2, 1, bias=False)
+    assert set(pack.state_dict()) == {"weight", "conv_offset.weight", "conv_offset.bias"}
+    torch.testing.assert_close(pack(x), 0.5 * F.conv2d(x, pack.weight, None, 2, 1), rtol=1e-5, atol=1e-5)  # sigmoid(0) = 0.5
+
+
+def test_waymo_lc_config_builds_with_dcn():
+    m = workloads.build("srfdet_dvoxel_waymo_LC", 16)
+    from srfdet3d_amd.compat.dcn import ModulatedDeformConv2dPack
+    bb = m.img_backbone
+    assert isinstance(bb.layer3[0].conv2, ModulatedDeformConv2dPack) and not isinstance(bb.layer2[0].conv2, ModulatedDeformConv2dPack)
+    assert bb.layer3[0].conv1.stride == (2, 2)   # caffe style: the stride sits on the 1x1
 
 
 def test_resnet_state_dict_names_follow_mmdet():

@@ -329,10 +329,12 @@ def test_whole_frame_graph_dynamic_voxel_configs(name, sweep, npts, np_, dev):
                                                    ("srfdet_pillar_v299_nusc_LC", 6, "nuscenes_sweep", 20000),
                                                    ("srfdet_voxel_r50_nusc_LC", 6, "nuscenes_sweep", 20000),
                                                    ("srfdet_pillar_r50_nusc_LC", 6, "nuscenes_sweep", 20000),
-                                                   ("srfdet_voxel_kitti_LC", 1, "kitti_sweep", 17000)])
+                                                   ("srfdet_voxel_kitti_LC", 1, "kitti_sweep", 17000),
+                                                   ("srfdet_dvoxel_waymo_LC", 5, "waymo_sweep", 40000)])
 def test_remaining_reference_configs_run_and_graphs_agree(name, n_cam, sweep, npts, dev):
     """The other configs of the reference (dynamic-voxel nuScenes, pillar + VoVNet, ResNet-50 image backbones, KITTI with its
-    single camera): one frame end to end, eager and through the hipGraphs, same pre-NMS tensors."""
+    single camera, Waymo LC with its DCNv2 ResNet-101): one frame end to end, eager and through the hipGraphs, same pre-NMS
+    tensors."""
     import copy
     torch.manual_seed(4)
     cpu = workloads.build(name, 32).eval()
