@@ -166,11 +166,14 @@ def main():
             # HBM traffic cannot be read from inside the process: it comes from the separate rocprofv3 --pmc passes
             # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied) recorded under profiles/
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_pmc_spconv128_traffic.json")
-            if os.path.exists(tpath):
+            direct = os.environ.get("SRF_SPCONV_DIRECT", "") == "1"  # developer switch of the C library: previous kernel
+            tpath = os.path.join(ROOT, "profiles", "r01_pmc_spconv128_traffic.json" if direct
+                                 else "r01_pmc_spconv128_gs_traffic.json")
+            if os.path.exists(tpath) and args.workload in ("nusc_L", "nusc_LC"):  # counted on a nuScenes-shaped sweep
                 with open(tpath) as fh:
                     traffic = json.load(fh).get("traffic_bytes_per_launch")
-            roofline = dict(kernel="srf_spconv_direct_k<32,4,2> (SubM 3x3x3, 128->128, 5x184x184 level)", bound="mfma",
+            kname = "srf_spconv_direct_k<32,4,2>" if direct else "srf_spconv_gs_k<4>"
+            roofline = dict(kernel=kname + " (SubM 3x3x3, 128->128, last level of the sparse encoder)", bound="mfma",
                             achieved=round(achieved, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                             launches=len(dom), avg_us=round(ms * 1e3, 2), measured=roofline_source,

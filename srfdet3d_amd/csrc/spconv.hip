@@ -15,6 +15,7 @@
 // LDS per workgroup (COUT = 128): nbr tile 27*64*4 = 6.9 KB, A chunk 64*33*4 = 8.4 KB, W chunk 32*128*4 = 16 KB
 // -> 5 workgroups per CU; latency is hidden by occupancy rather than by an explicit pipeline.
 #include "common.hpp"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -284,6 +285,9 @@ __global__ __launch_bounds__(256) void srf_spconv_mfma32_k(const float *__restri
 // =====================================================================================================================
 // direct (LDS-free B operand) layout of the COUT = 128 kernel, see srf_spconv_direct_k below
 static bool srf_direct_layout(int Cin, int Cout) { return Cout == 128 && (Cin == 64 || Cin == 128); }
+// compacted-offset layout of the same shapes (srf_spconv_gs_k below), the default
+static bool srf_gs_layout(int Cin, int Cout);
+__global__ void srf_pack_weights_gs_k(const float *__restrict__ W, int K, int Cin, int Cout, int nchunk, float *__restrict__ P);
 
 __global__ __launch_bounds__(256) void srf_pack_weights_direct_k(const float *__restrict__ W, int K, int Cin, int Cout,
                                                                int nchunk, float *__restrict__ P)
@@ -327,7 +331,10 @@ extern "C" int srf_spconv_pack_weights(const float *W, int K, int Cin, int Cout,
     if (!W || !packed || K <= 0 || K > SRF_KMAX || Cin <= 0 || Cout <= 0) return SRF_EINVAL;
     const int nchunk = (Cin + 31) / 32;
     const long long total = (long long)K * nchunk * Cout * 32;
-    if (srf_direct_layout(Cin, Cout))
+    if (srf_gs_layout(Cin, Cout))
+        hipLaunchKernelGGL(srf_pack_weights_gs_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, W, K, Cin,
+                           Cout, nchunk, packed);
+    else if (srf_direct_layout(Cin, Cout))
         hipLaunchKernelGGL(srf_pack_weights_direct_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, W, K,
                            Cin, Cout, nchunk, packed);
     else
@@ -674,9 +681,464 @@ __global__ __launch_bounds__(256) void srf_spconv_direct_k(const float *__restri
         }
 }
 
+// =====================================================================================================================
+// COUT = 128, Cin in {64, 128}, compacted offsets ("gs": gather rows, scatter into an LDS-resident output tile).
+// In the output-stationary kernels above a 32-row tile spends one full MFMA pass on every kernel offset any of its rows
+// uses, although only 16-20 of the 27 neighbours of a row exist: 40 % of the issued MFMAs multiply zeros (59 % useful at
+// the 128-channel level of a nuScenes sweep, 73 % on a Waymo sweep).  Here a workgroup owns up to 88 output rows whose
+// accumulators live in LDS.  For every offset k the rows that HAVE a neighbour at k are compacted (one ballot per 64 rows)
+// and processed in groups of 16 on v_mfma_f32_16x16x4_f32: the group's accumulators are read from the output tile (row =
+// the group's output slot), run through the channel-ascending MFMA chain and written back, so every output element still
+// sees exactly the chain (offset ascending, channel ascending) of the oracle -- minus the terms that were exact zeros:
+// results stay bit-identical.  86 % of the issued MFMAs are useful on the nuScenes sweep (90 % Waymo); the kernel issues
+// 70 % of the MFMA cycles of srf_spconv_direct_k (profiles/r01_pmc_spconv128_gs_traffic.json).
+// B operands go global(L2) -> registers in MFMA order as in the direct kernel, once per offset and tile (not once per
+// group), one offset ahead in a second register set; the gathered rows of the next group are fetched during the MFMAs of
+// the current one (double-buffered LDS).  A wave owns 32 output channels of the tile, so no other wave touches its
+// accumulators: one barrier per group (the A hand-over) suffices.
+//   gs layout: Wg[k][chunk][wc = col/32][g][lane][i], idx = 4g + i, = W[k][chunk*32 + 4*(idx&7) + (lane>>4)]
+//                                                                      [wc*32 + 16*(idx>>3) + (lane&15)]
+// LDS: output tile 88 x 132 x 4 = 46.5 KB, A 2 x (NCH x 2 KB), row lists 27 x 96 x 5 B = 13 KB -> 76 KB, two workgroups
+// per CU (224 VGPRs).  Which rows a workgroup owns: srf_spconv_tiles_build below (ranges of equal cost), or equal-height
+// tiles when the caller passes no ranges.
+// Measured (MI355X, nuScenes level 4, 35k rows, 556k pairs): 277 us vs 342 us for srf_spconv_direct_k; 558 vs 582 us on a
+// 66k-row level with 19.5 pairs per row.  A workgroup spends ~45 % of a group's time issuing MFMAs and the two
+// workgroups of a CU do not interleave perfectly (MFMA pipe busy 58 %): the remaining distance to the MFMA roofline.
+// =====================================================================================================================
+#define SRF_GS_TMAX 88   /* most output rows of a tile: 2 workgroups per CU still fit in LDS */
+#define SRF_GS_LS 96     /* stride of the per-offset row lists (TMAX rounded up to whole groups) */
+#define SRF_GS_OS 132    /* output-tile row stride in floats: rows 4 apart land 16 banks apart */
+#define SRF_GS_CHS (16 * 32 + 8) /* chunk stride of the A image: the four chunks of a row start 8 banks apart */
+#ifndef SRF_GS_PRIO
+#define SRF_GS_PRIO 1
+#endif
+#define SRF_GS_SLOTS 512 /* co-resident workgroups: 256 CUs x 2 */
+
+// Tile height.  A tile is ~80 groups of MFMAs (~200 us): with a fixed height the last partial round of tiles would leave
+// most of the chip idle for that long (547 tiles of 64 rows on 512 slots: 35 tiles run alone in a second round).  The
+// height is therefore chosen from the live row count so that the tiles fill a whole number of rounds of 512: 1 round up
+// to 45k rows, 2 rounds up to 90k, ...  Evaluated identically on the host (grid size from the capacity) and in the
+// kernel (from the device row count of a static-shape level).
+__host__ __device__ static inline int srf_gs_rounds(int A) { return A <= 0 ? 1 : (A + SRF_GS_SLOTS * SRF_GS_TMAX - 1) / (SRF_GS_SLOTS * SRF_GS_TMAX); }
+__host__ __device__ static inline int srf_gs_tile_rows(int A)
+{
+    const int per = SRF_GS_SLOTS * srf_gs_rounds(A);
+    int tm = ((A + per - 1) / per + 7) & ~7;
+    return tm < 16 ? 16 : tm;
+}
+
+static bool srf_gs_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("SRF_SPCONV_DIRECT");  // developer switch: keep the previous (direct) kernel for A/B timing
+        return !(e && e[0] == '1');
+    }();
+    return on;
+}
+static bool srf_gs_layout(int Cin, int Cout) { return srf_gs_enabled() && Cout == 128 && (Cin == 64 || Cin == 128); }
+
+__global__ __launch_bounds__(256) void srf_pack_weights_gs_k(const float *__restrict__ W, int K, int Cin, int Cout, int nchunk,
+                                                           float *__restrict__ P)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)K * nchunk * Cout * 32;
+    if (t >= total) return;
+    const int i = (int)(t & 3), lane = (int)((t >> 2) & 63), g = (int)((t >> 8) & 3), wc = (int)((t >> 10) & 3);
+    const long long rest = t >> 12;
+    const int chunk = (int)(rest % nchunk), k = (int)(rest / nchunk);
+    const int idx = 4 * g + i;
+    const int col = wc * 32 + 16 * (idx >> 3) + (lane & 15);
+    const int c = chunk * 32 + 4 * (idx & 7) + (lane >> 4);
+    P[t] = c < Cin ? W[((size_t)k * Cin + c) * Cout + col] : 0.0f;
+}
+
+// rows of one group, global -> registers.  Padding entries of a last group (-1) read row 0: their MFMA rows are never
+// written back, so any finite-or-not value will do and no zero fill is needed
+template <int NCH, int NA>
+__device__ __forceinline__ void srf_gs_gather(const float *__restrict__ in, const int *s_rows, f32x4 (&ra)[NA])
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int e = tid + j * 256;
+        const int r = e / (8 * NCH), q = e % (8 * NCH);
+        const int i = s_rows[r];
+        ra[j] = *reinterpret_cast<const f32x4 *>(in + (size_t)(i >= 0 ? i : 0) * (32 * NCH) + q * 4);
+    }
+}
+
+// A image of one group: [chunk][row 0..15][32], channel 4q + j of a chunk at position j*8 + q (lane (row, j) of the
+// 16x16x4 MFMA reads its eight steps as two b128), 16-byte units XOR-swizzled by (row >> 1) & 7
+template <int NCH, int NA>
+__device__ __forceinline__ void srf_gs_store(float *s_a, const f32x4 (&ra)[NA])
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int e = tid + j * 256;
+        const int r = e / (8 * NCH), qq = e % (8 * NCH);
+        const int ch = qq >> 3, q = qq & 7;
+        const int swz = (r >> 1) & 7;
+        float *img = s_a + ch * SRF_GS_CHS + r * 32 + (q & 3);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) img[((jj * 2 + (q >> 2)) ^ swz) << 2] = ra[j][jj];
+    }
+}
+
+template <int NCH, int NA>
+__device__ __forceinline__ void srf_gs_offset(const float *__restrict__ in, const float *__restrict__ Wg, int kc, int kn, bool more_k,
+                                              const int *s_in, const unsigned char *s_slot, const int *s_cnt, float *s_out,
+                                              float *s_a, int &buf, f32x4 (&bc)[NCH][4], f32x4 (&bn)[NCH][4], f32x4 (&ra)[NA])
+{
+    const int lane = threadIdx.x & 63, wc = threadIdx.x >> 6;
+    const int n = s_cnt[kc];
+    const int ng = (n + 15) >> 4;
+    const int ar = lane & 15, aj = lane >> 4;
+    const int a_swz = (ar >> 1) & 7;
+    for (int g = 0; g < ng; ++g) {
+        const bool last = g + 1 == ng;
+        const bool has_next = !last || more_k;
+        if (last && more_k) {  // B of the next offset, one whole group of MFMAs ahead, into the other register set
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) srf_dir_load_b<NCH>(bn[c], Wg, kn, c, wc, lane);
+        }
+        if (has_next) srf_gs_gather<NCH, NA>(in, last ? s_in + kn * SRF_GS_LS : s_in + kc * SRF_GS_LS + (g + 1) * 16, ra);
+        // all A fragments of the group first (8 ds_read_b128 in flight together, one exposed LDS latency per group instead of
+        // one per chunk), then the accumulators of this group out of the output tile
+        const float *abase = s_a + buf * (NCH * SRF_GS_CHS) + ar * 32;
+        f32x4 af[NCH][2];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            af[c][0] = *reinterpret_cast<const f32x4 *>(abase + c * SRF_GS_CHS + (((aj << 1) ^ a_swz) << 2));
+            af[c][1] = *reinterpret_cast<const f32x4 *>(abase + c * SRF_GS_CHS + ((((aj << 1) + 1) ^ a_swz) << 2));
+        }
+        const int nrows = n - g * 16;  // >= 1; rows beyond it are padding of the last group
+        const unsigned sl4 = *reinterpret_cast<const unsigned *>(s_slot + kc * SRF_GS_LS + g * 16 + aj * 4);
+        f32x4 acc[2];
+        int oaddr[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const bool valid = aj * 4 + jj < nrows;
+            const int slot = valid ? (int)((sl4 >> (8 * jj)) & 255u) : 0;
+            oaddr[jj] = valid ? slot * SRF_GS_OS + wc * 32 + ar : -1;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[cb][jj] = valid ? s_out[oaddr[jj] + cb * 16] : 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMA block
+        if (SRF_GS_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float a = af[c][s >> 2][s & 3];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[c][s >> 2][s & 3], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[c][2 + (s >> 2)][s & 3], acc[1], 0, 0, 0);
+            }
+        }
+        if (SRF_GS_PRIO) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            if (oaddr[jj] >= 0) {
+                s_out[oaddr[jj]] = acc[0][jj];
+                s_out[oaddr[jj] + 16] = acc[1][jj];
+            }
+        // every load issued in this group has landed before the next one starts.  Stated explicitly (s_waitcnt vmcnt(0)):
+        // the compiler cannot tie "B was prefetched" to "the gather was waited for" across the two branches and would
+        // otherwise guard the next group's MFMAs with vmcnt waits that also catch that group's own fresh loads
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (has_next) srf_gs_store<NCH, NA>(s_a + (buf ^ 1) * (NCH * SRF_GS_CHS), ra);
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+// ---- work-balanced row ranges ------------------------------------------------------------------------------------------
+// One round of co-resident workgroups finishes when its heaviest tile does, and the pairs per 72 rows of a sweep vary by
+// 1.5x around their mean (dense clusters vs. isolated returns).  srf_spconv_tiles_build therefore cuts the rows of a
+// rulebook into T ranges of (almost) equal PAIR count -- range t = the rows whose exclusive pair prefix lies in
+// [t*P/T, (t+1)*P/T) -- once per rulebook (the four SubM layers of a level share it).  A workgroup walks its range in
+// sub-tiles of at most SRF_GS_TMAX rows.
+#define SRF_TB_ROWS 1024
+#define SRF_GS_ROW_COST 12 /* cost of a row = its pairs + 12: the constant carries the row's share of the per-offset and
+                              per-sub-tile work (fit of the measured workgroup times: 2.0 us per group, 0.34 us per offset,
+                              15 us per sub-tile); with it the slowest range of a nuScenes / Waymo sweep is 9 % / 4 % above
+                              the mean instead of 24 % / 12 % */
+__host__ __device__ static inline int srf_gs_ranges(int A_cap)
+{
+    const int t = A_cap / 32;
+    return t < 1 ? 1 : (t > SRF_GS_SLOTS ? SRF_GS_SLOTS : t);
+}
+
+__device__ __forceinline__ int srf_block_scan_excl(int v, int *s_scan /* 256 + 4 */, int &total)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_scan[wave] = x;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) base += s_scan[w];
+    }
+    total = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    __syncthreads();
+    return base + x - v;
+}
+
+// pairs per row, exclusive prefix inside blocks of 1024 rows (row order), block totals
+__global__ __launch_bounds__(256) void srf_gs_rowpairs_k(const int *__restrict__ nbr, int nbr_stride, int K, int A,
+                                                       const int *__restrict__ rows_dev, int *__restrict__ local,
+                                                       int *__restrict__ blocksum)
+{
+    __shared__ int s_scan[4];
+    if (rows_dev) {
+        const int live = *rows_dev;
+        A = A < live ? A : live;
+    }
+    const int r0 = blockIdx.x * SRF_TB_ROWS;
+    int carry = 0;
+    for (int j = 0; j < SRF_TB_ROWS / 256; ++j) {  // block-uniform trip count: the barriers inside the scan are safe
+        const int r = r0 + j * 256 + threadIdx.x;
+        int c = 0;
+        if (r < A)
+        {
+            for (int k = 0; k < K; ++k) c += nbr[(size_t)k * nbr_stride + r] >= 0 ? 1 : 0;
+            c += SRF_GS_ROW_COST;
+        }
+        int total;
+        const int ex = srf_block_scan_excl(c, s_scan, total);
+        if (r < A) local[r] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = carry;
+}
+
+// exclusive scan of the block totals (one workgroup; nb <= a few hundred), total pair count at [nb]
+__global__ __launch_bounds__(256) void srf_gs_blockscan_k(const int *__restrict__ blocksum, int nb, int *__restrict__ blockoff)
+{
+    __shared__ int s_scan[4];
+    int carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += 256) {
+        const int b = b0 + threadIdx.x;
+        const int v = b < nb ? blocksum[b] : 0;
+        int total;
+        const int ex = srf_block_scan_excl(v, s_scan, total);
+        if (b < nb) blockoff[b] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) blockoff[nb] = carry;
+}
+
+// tiles[t] = first row whose exclusive pair prefix reaches t*P/T (binary search over blocks, then inside the block)
+__global__ __launch_bounds__(256) void srf_gs_cut_k(const int *__restrict__ local, const int *__restrict__ blockoff, int nb, int A,
+                                                  const int *__restrict__ rows_dev, int T, int *__restrict__ tiles)
+{
+    if (rows_dev) {
+        const int live = *rows_dev;
+        A = A < live ? A : live;
+    }
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t > T) return;
+    const int nbl = (A + SRF_TB_ROWS - 1) / SRF_TB_ROWS;  // live blocks (<= nb)
+    if (t == T || A == 0) {
+        tiles[t] = A;
+        return;
+    }
+    const long long P = blockoff[nbl];
+    const long long target = (P * t + T - 1) / T;
+    // last block whose offset is <= target
+    int lo = 0, hi = nbl - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (blockoff[mid] <= target) lo = mid;
+        else hi = mid - 1;
+    }
+    const long long boff = blockoff[lo];
+    const int r0 = lo * SRF_TB_ROWS;
+    const int r1 = r0 + SRF_TB_ROWS < A ? r0 + SRF_TB_ROWS : A;
+    // first row in [r0, r1) with boff + local[r] >= target, else r1
+    int a = r0, b = r1;
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (boff + local[mid] >= target) b = mid;
+        else a = mid + 1;
+    }
+    tiles[t] = a;
+}
+
+extern "C" int srf_spconv_tiles_count(int A_out) { return A_out <= 0 ? 1 : srf_gs_ranges(A_out); }
+
+extern "C" size_t srf_spconv_tiles_workspace_bytes(int A_out)
+{
+    if (A_out < 0) return 0;
+    const size_t nb = (size_t)(A_out + SRF_TB_ROWS - 1) / SRF_TB_ROWS;
+    return ((size_t)A_out + 2 * nb + 8) * sizeof(int);
+}
+
+extern "C" int srf_spconv_tiles_build(const int *nbr, int nbr_stride, int K, int A_out, const int *rows_dev, void *workspace,
+                                      int *tiles, srf_stream_t stream)
+{
+    if (A_out < 0 || K <= 0 || K > SRF_KMAX || nbr_stride < A_out || !tiles) return SRF_EINVAL;
+    if (A_out > 0 && (!nbr || !workspace)) return SRF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int T = srf_spconv_tiles_count(A_out);
+    const int nb = (A_out + SRF_TB_ROWS - 1) / SRF_TB_ROWS;
+    int *local = (int *)workspace, *blocksum = local + A_out, *blockoff = blocksum + nb + 1;
+    if (nb > 0) {
+        hipLaunchKernelGGL(srf_gs_rowpairs_k, dim3(nb), dim3(256), 0, st, nbr, nbr_stride, K, A_out, rows_dev, local, blocksum);
+        hipLaunchKernelGGL(srf_gs_blockscan_k, dim3(1), dim3(256), 0, st, blocksum, nb, blockoff);
+    }
+    hipLaunchKernelGGL(srf_gs_cut_k, dim3(srf_ceil_div(T + 1, 256)), dim3(256), 0, st, local, blockoff, nb, A_out, rows_dev, T, tiles);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restrict__ in, const float *__restrict__ Wg, int K,
+                                                        const int *__restrict__ nbr, int nbr_stride, int A_out,
+                                                        const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                        const float *__restrict__ residual, int relu,
+                                                        float *__restrict__ out, const int *__restrict__ rows_dev,
+                                                        const int *__restrict__ tiles)
+{
+    constexpr int COUT = 128, NA = 16 * 8 * NCH / 256, LS = SRF_GS_LS, NKW = (SRF_KMAX + 3) / 4;
+    static_assert(NA >= 1, "a group is at least one f32x4 per thread");
+    __shared__ int s_in[SRF_KMAX * LS];                 // per offset: input rows of the outputs that have this neighbour
+    __shared__ __attribute__((aligned(4))) unsigned char s_slot[SRF_KMAX * LS];  // ... and their slot in the output tile
+    __shared__ int s_cnt[SRF_KMAX];
+    __shared__ int s_klist[SRF_KMAX + 1];
+    __shared__ __attribute__((aligned(16))) float s_out[SRF_GS_TMAX * SRF_GS_OS];
+    __shared__ __attribute__((aligned(16))) float s_a[2 * NCH * SRF_GS_CHS];
+
+    const int A_cap = A_out;
+    if (rows_dev) {  // static-shape levels: rows >= *rows_dev are padding; their tiles do nothing
+        const int live = *rows_dev;
+        A_out = A_out < live ? A_out : live;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // this workgroup's rows: a work-balanced range of the rulebook (walked in equal sub-tiles), or one equal-height tile
+    int range0, range1;
+    if (tiles) {
+        const int T = srf_gs_ranges(A_cap);
+        if ((int)blockIdx.x >= T) return;
+        const int t = srf_xcd_tile(blockIdx.x, T);
+        range0 = tiles[t];
+        range1 = tiles[t + 1];
+        range1 = range1 < A_out ? range1 : A_out;
+    } else {
+        const int tm = srf_gs_tile_rows(A_out);
+        const int n_tiles = (A_out + tm - 1) / tm;
+        if ((int)blockIdx.x >= n_tiles) return;
+        range0 = srf_xcd_tile(blockIdx.x, n_tiles) * tm;
+        range1 = range0 + tm < A_out ? range0 + tm : A_out;
+    }
+    if (range1 <= range0) return;
+    const int nsub = (range1 - range0 + SRF_GS_TMAX - 1) / SRF_GS_TMAX;
+    const int TM = (((range1 - range0 + nsub - 1) / nsub) + 7) & ~7;  // <= SRF_GS_TMAX (a multiple of 8)
+    for (int row0 = range0; row0 < range1; row0 += TM) {
+    const int row_end = row0 + TM < range1 ? row0 + TM : range1;  // rows of this sub-tile: [row0, row_end)
+    for (int e = tid; e < TM * SRF_GS_OS / 4; e += 256) reinterpret_cast<f32x4 *>(s_out)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // compaction: the wave's offsets (wave, wave + 4, ...), rows in two segments of 64; all loads in flight together
+    int nv[NKW][2];
+#pragma unroll
+    for (int i = 0; i < NKW; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = wave + 4 * i, r = h * 64 + lane;
+            nv[i][h] = (k < K && row0 + r < row_end) ? nbr[(size_t)k * nbr_stride + row0 + r] : -1;
+        }
+#pragma unroll
+    for (int i = 0; i < NKW; ++i) {
+        const int k = wave + 4 * i;
+        if (k >= SRF_KMAX) break;
+        int *lin = s_in + k * LS;
+        unsigned char *lsl = s_slot + k * LS;
+        lin[lane] = -1;  // padding of the last group (same wave: ordered before the compacted stores)
+        if (lane < LS - 64) lin[64 + lane] = -1;
+        int base = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int v = nv[i][h];
+            const unsigned long long m = __ballot(v >= 0);
+            if (v >= 0) {
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                lin[pos] = v;
+                lsl[pos] = (unsigned char)(h * 64 + lane);
+            }
+            base += __popcll(m);
+        }
+        if (lane == 0) s_cnt[k] = base;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const bool used = tid < K && s_cnt[tid] > 0;
+        const unsigned long long m = __ballot(used);
+        if (used) s_klist[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+        if (tid == 0) s_klist[SRF_KMAX] = __popcll(m);
+    }
+    __syncthreads();
+    const int ntap = s_klist[SRF_KMAX];
+
+    f32x4 b0[NCH][4], b1[NCH][4], ra[NA];
+    int buf = 0;
+    if (ntap > 0) {
+        const int k0 = s_klist[0];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) srf_dir_load_b<NCH>(b0[c], Wg, k0, c, wave, lane);
+        srf_gs_gather<NCH, NA>(in, s_in + k0 * LS, ra);
+        srf_gs_store<NCH, NA>(s_a, ra);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing is in flight when the first group starts (see srf_gs_offset)
+    __syncthreads();
+    for (int tk = 0; tk < ntap; tk += 2) {  // two offsets per trip: the B register sets swap roles without moves
+        {
+            const bool more = tk + 1 < ntap;
+            const int kc = s_klist[tk], kn = more ? s_klist[tk + 1] : kc;
+            srf_gs_offset<NCH, NA>(in, Wg, kc, kn, more, s_in, s_slot, s_cnt, s_out, s_a, buf, b0, b1, ra);
+        }
+        if (tk + 1 < ntap) {
+            const bool more = tk + 2 < ntap;
+            const int kc = s_klist[tk + 1], kn = more ? s_klist[tk + 2] : kc;
+            srf_gs_offset<NCH, NA>(in, Wg, kc, kn, more, s_in, s_slot, s_cnt, s_out, s_a, buf, b1, b0, ra);
+        }
+    }
+
+    // epilogue: every output row once, BN / residual / ReLU in registers, 512 B per row and store
+    const int c4 = (tid & 31) * 4;
+    f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+    if (alpha) {
+        al = *reinterpret_cast<const f32x4 *>(alpha + c4);
+        be = *reinterpret_cast<const f32x4 *>(beta + c4);
+    }
+    for (int r = tid >> 5; r < TM; r += 8) {
+        const int row = row0 + r;
+        if (row >= row_end) break;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(s_out + r * SRF_GS_OS + c4);
+        f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+        if (residual) rs = *reinterpret_cast<const f32x4 *>(residual + (size_t)row * COUT + c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = v[j];
+            if (alpha) x = __fmaf_rn(x, al[j], be[j]);
+            if (residual) x = __fadd_rn(x, rs[j]);
+            if (relu) x = x > 0.0f ? x : 0.0f;
+            v[j] = x;
+        }
+        *reinterpret_cast<f32x4 *>(out + (size_t)row * COUT + c4) = v;
+    }
+    __syncthreads();  // the output tile and the row lists are rebuilt by the next sub-tile
+    }
+}
+
 extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const float *W_packed, int K, const int *nbr,
                                      int nbr_stride, int A_out, int Cout, const float *alpha, const float *beta,
-                                     const float *residual, int relu, float *out, const int *rows_dev, srf_stream_t stream)
+                                     const float *residual, int relu, float *out, const int *rows_dev, const int *tiles,
+                                     srf_stream_t stream)
 {
     if (A_in < 0 || A_out < 0 || Cin <= 0 || Cin > 512 || K <= 0 || K > SRF_KMAX || nbr_stride < A_out) return SRF_EINVAL;
     if ((alpha == nullptr) != (beta == nullptr)) return SRF_EINVAL;
@@ -695,6 +1157,17 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
                            st, SRF_ARGS);
         break;
     case 128: {
+        if (srf_gs_layout(Cin, Cout)) {
+            // >= the tiles of any live row count <= A_out / the ranges srf_spconv_tiles_build cut for this capacity
+            const dim3 grid(tiles ? srf_gs_ranges(A_out) : SRF_GS_SLOTS * srf_gs_rounds(A_out));
+            if (Cin == 128)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gs_k<4>), grid, dim3(256), 0, st, in, W_packed, K, nbr, nbr_stride,
+                                   A_out, alpha, beta, residual, relu, out, rows_dev, tiles);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gs_k<2>), grid, dim3(256), 0, st, in, W_packed, K, nbr, nbr_stride,
+                                   A_out, alpha, beta, residual, relu, out, rows_dev, tiles);
+            break;
+        }
         if (srf_direct_layout(Cin, Cout)) {
 #define SRF_DARGS in, W_packed, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev
             if (Cin == 128)

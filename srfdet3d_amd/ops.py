@@ -312,10 +312,30 @@ def pack_spconv_weights(weight):
     return packed
 
 
+def spconv_tiles_wanted(Cin, Cout):
+    """True for the layer shapes whose packed kernel takes work-balanced row ranges (`tiles=` of spconv_fwd)."""
+    return Cout == 128 and Cin in (64, 128)
+
+
+def spconv_tiles(nbr, rows_dev=None):
+    """Row ranges of equal pair count for the rulebook nbr (K, A_out): int32 (srf_spconv_tiles_count(A_out) + 1,).
+    Built once per rulebook and passed to every spconv_fwd(..., packed=, tiles=) that uses it."""
+    if not nbr.is_cuda or nbr.dtype != torch.int32 or nbr.stride(1) != 1:
+        raise RuntimeError("srfdet3d_amd: `nbr` must be a GPU int32 tensor with unit inner stride")
+    K, A_out = nbr.shape
+    L = _lib.lib()
+    tiles = _empty((L.srf_spconv_tiles_count(A_out) + 1,), torch.int32, nbr.device)
+    ws = _empty((max(L.srf_spconv_tiles_workspace_bytes(A_out), 4),), torch.uint8, nbr.device)
+    check(L.srf_spconv_tiles_build(_ptr(nbr), nbr.stride(0) if A_out > 0 else 0, K, A_out, _ptr(rows_dev), _ptr(ws), _ptr(tiles),
+                                   _stream()), "spconv_tiles_build")
+    return tiles
+
+
 def spconv_fwd(feats, weight, nbr, alpha=None, beta=None, residual=None, relu=False, pair_counts=None, packed=None,
-               rows_dev=None):
+               rows_dev=None, tiles=None):
     """feats (A_in,Cin); weight (K,Cin,Cout); nbr (K,A_out) (row stride nbr.stride(0)) -> (A_out,Cout).
-    `packed` = pack_spconv_weights(weight) selects the packed-weight kernel (Cout >= 32, Cin % 4 == 0)."""
+    `packed` = pack_spconv_weights(weight) selects the packed-weight kernel (Cout >= 32, Cin % 4 == 0);
+    `tiles` = spconv_tiles(nbr) lets its 128-channel variant balance the workgroups by pair count."""
     feats = _dev(feats, "feats", torch.float32)
     weight = _dev(weight, "weight", torch.float32)
     if not nbr.is_cuda or nbr.dtype != torch.int32 or nbr.stride(1) != 1:
@@ -334,7 +354,8 @@ def spconv_fwd(feats, weight, nbr, alpha=None, beta=None, residual=None, relu=Fa
     if packed is not None and Cout >= 32 and Cin % 4 == 0 and feats.shape[0] > 0:
         check(_lib.lib().srf_spconv_fwd_packed(_ptr(feats), feats.shape[0], Cin, _ptr(packed), K, _ptr(nbr),
                                                nbr.stride(0) if A_out > 0 else 0, A_out, Cout, _ptr(alpha), _ptr(beta),
-                                               _ptr(residual), int(bool(relu)), _ptr(out), _ptr(rows_dev), _stream()),
+                                               _ptr(residual), int(bool(relu)), _ptr(out), _ptr(rows_dev),
+                                               _ptr(tiles) if spconv_tiles_wanted(Cin, Cout) else None, _stream()),
               "spconv_fwd_packed")
     else:
         check(_lib.lib().srf_spconv_fwd(_ptr(feats), feats.shape[0], Cin, _ptr(weight), K, _ptr(nbr),

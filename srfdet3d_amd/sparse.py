@@ -191,8 +191,14 @@ class _SparseConv(SparseModule):
                     cache = (vers, ops.pack_spconv_weights(w.detach()))
                 self._srf_packed = cache
             packed = cache[1]
+        tiles = None
+        if packed is not None and ops.spconv_tiles_wanted(self.in_channels, self.out_channels) and nbr.shape[1] > 0:
+            tkey = ("tiles", nbr.data_ptr(), nbr.shape[1])  # one set of balanced row ranges per rulebook
+            tiles = x.indice_dict.get(tkey)
+            if tiles is None:
+                tiles = x.indice_dict[tkey] = ops.spconv_tiles(nbr, rows_dev)
         feats = ops.spconv_fwd(x.features, w, nbr, alpha, beta, residual, relu, pair_counts=counts, packed=packed,
-                               rows_dev=rows_dev)
+                               rows_dev=rows_dev, tiles=tiles)
         return SparseConvTensor(feats, out_idx, oshape, x.batch_size, x.indice_dict, rows_dev)
 
 

@@ -45,6 +45,10 @@ def test_host_side_helpers():
     # argument validation happens before any HIP call
     assert L.srf_spconv_fwd(None, 0, 16, None, 27, None, 0, 10, 24, None, None, None, 0, None, None, None) == -1
     assert L.srf_roi_extract(None, 0, 128, None, 0, 7, 2, 56.0, None, 0, 0, 0, 0, None, None) == -1
+    assert L.srf_spconv_fwd_packed(None, 0, 128, None, 27, None, 0, 10, 128, None, None, None, 0, None, None, None, None) == -1
+    assert L.srf_spconv_tiles_count(35000) == 512 and L.srf_spconv_tiles_count(100) == 3 and L.srf_spconv_tiles_count(0) == 1
+    assert L.srf_spconv_tiles_workspace_bytes(35000) >= 35000 * 4
+    assert L.srf_spconv_tiles_build(None, 0, 27, 10, None, None, None, None) == -1
     # bitmap-rank rulebooks / dense-side helpers: sizes and argument checks, still no GPU work
     assert L.srf_bitmap_words(hi([41, 1472, 1472]), 1) == (41 * 1472 * 1472 + 31) // 32
     assert L.srf_bitmap_words(hi([41, 1472, 1472]), 64) == 0          # cell index must fit 32 bits

@@ -108,6 +108,59 @@ def test_spconv_fwd_exact(dev, cin, cout, K):
             got = ops.spconv_fwd(tt(feats), tt(W), tt(nbr), tt(alpha) if use_bn else None, tt(beta) if use_bn else None,
                                  tt(res) if use_res else None, relu, packed=ops.pack_spconv_weights(tt(W))).cpu().numpy()
             assert np.array_equal(got, ref), f"packed: max abs diff {np.abs(got - ref).max()}"
+            if ops.spconv_tiles_wanted(cin, cout):  # the same kernel walking work-balanced row ranges
+                tiles = ops.spconv_tiles(tt(nbr))
+                got = ops.spconv_fwd(tt(feats), tt(W), tt(nbr), tt(alpha) if use_bn else None, tt(beta) if use_bn else None,
+                                     tt(res) if use_res else None, relu, packed=ops.pack_spconv_weights(tt(W)),
+                                     tiles=tiles).cpu().numpy()
+                assert np.array_equal(got, ref), f"packed+tiles: max abs diff {np.abs(got - ref).max()}"
+
+
+@pytest.mark.parametrize("n,live", [(6000, None), (6000, 4100), (40, None), (3000, 0)])
+def test_spconv_tiles_cut_rows_by_pair_count(dev, n, live):
+    """tiles[t] = first row whose exclusive cost prefix reaches ceil(t * P / T), cost of a row = its pairs + 12 (include/
+    srfdet3d.h): checked against that definition in numpy; with a device row count (static-shape levels) only the live rows
+    are cut."""
+    idx = _level1(n=n)
+    nbr, _ = O.rulebook_subm(idx, SHAPE1, [3, 3, 3])
+    A = nbr.shape[1]
+    t_nbr = torch.from_numpy(nbr).to(dev)
+    rows_dev = None if live is None else torch.tensor([live], dtype=torch.int32, device=dev)
+    tiles = ops.spconv_tiles(t_nbr, rows_dev).cpu().numpy()
+    a_live = A if live is None else min(live, A)
+    T = len(tiles) - 1
+    pairs = (nbr[:, :a_live] >= 0).sum(0).astype(np.int64) + 12
+    prefix = np.concatenate([[0], np.cumsum(pairs)])  # prefix[r] = cost of rows < r
+    P = int(prefix[-1])
+    want = np.empty(T + 1, np.int64)
+    for t in range(T):
+        want[t] = np.searchsorted(prefix[:a_live], -(-P * t // T), side="left") if a_live else 0
+    want[T] = a_live
+    np.testing.assert_array_equal(tiles, want)
+    assert tiles[0] == 0 and np.all(np.diff(tiles) >= 0)
+    if a_live >= 2000:  # every range carries P/T cost to within one row's worth
+        per = np.diff(prefix[tiles])
+        assert per.max() - per.min() <= 2 * (27 + 12)
+
+
+def test_spconv_tiles_with_padded_rows(dev):
+    """static-shape level: capacity-sized rulebook whose tail rows are padding (-1), device row count -> same rows out."""
+    rng = np.random.default_rng(5)
+    idx = _level1(n=5000)
+    nbr, _ = O.rulebook_subm(idx, SHAPE1, [3, 3, 3])
+    A = nbr.shape[1]
+    cap = A + 700
+    nbr_pad = np.full((27, cap), -1, np.int32)
+    nbr_pad[:, :A] = nbr
+    feats = rng.standard_normal((A, 128)).astype(np.float32)
+    W = (rng.standard_normal((27, 128, 128)) / 20).astype(np.float32)
+    ref = O.spconv_fwd(feats, W, nbr)
+    tt = lambda x: torch.from_numpy(x).to(dev)
+    rows_dev = torch.tensor([A], dtype=torch.int32, device=dev)
+    t_nbr = tt(nbr_pad)
+    tiles = ops.spconv_tiles(t_nbr, rows_dev)
+    got = ops.spconv_fwd(tt(feats), tt(W), t_nbr, packed=ops.pack_spconv_weights(tt(W)), rows_dev=rows_dev, tiles=tiles)
+    assert np.array_equal(got[:A].cpu().numpy(), ref)
 
 
 def test_spconv_vs_dense_torch_conv3d(dev):

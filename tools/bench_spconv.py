@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--points", type=int, default=30000)
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--unpacked", action="store_true")
+    ap.add_argument("--no-tiles", action="store_true", help="equal-height tiles instead of work-balanced row ranges")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     pts = torch.from_numpy(synthetic.nuscenes_sweep(2000, a.points)).to(dev)
@@ -39,13 +40,14 @@ def main():
             W = (torch.randn(27, C, C, generator=g) * 0.05).to(dev)
             al, be = torch.rand(C, generator=g).to(dev) + 0.5, torch.randn(C, generator=g).to(dev)
             pk = ops.pack_spconv_weights(W) if (C >= 32 and not a.unpacked) else None
+            tiles = ops.spconv_tiles(nbr) if (pk is not None and ops.spconv_tiles_wanted(C, C) and not a.no_tiles) else None
             for _ in range(3):
-                ops.spconv_fwd(f, W, nbr, al, be, f, True, packed=pk)
+                ops.spconv_fwd(f, W, nbr, al, be, f, True, packed=pk, tiles=tiles)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             e0.record()
             for _ in range(a.reps):
-                ops.spconv_fwd(f, W, nbr, al, be, f, True, packed=pk)
+                ops.spconv_fwd(f, W, nbr, al, be, f, True, packed=pk, tiles=tiles)
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / a.reps
