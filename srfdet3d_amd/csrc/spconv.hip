@@ -709,9 +709,6 @@ __global__ __launch_bounds__(256) void srf_spconv_direct_k(const float *__restri
 #define SRF_GS_LS 96     /* stride of the per-offset row lists (TMAX rounded up to whole groups) */
 #define SRF_GS_OS 132    /* output-tile row stride in floats: rows 4 apart land 16 banks apart */
 #define SRF_GS_CHS (16 * 32 + 8) /* chunk stride of the A image: the four chunks of a row start 8 banks apart */
-#ifndef SRF_GS_PRIO
-#define SRF_GS_PRIO 1
-#endif
 #define SRF_GS_SLOTS 512 /* co-resident workgroups: 256 CUs x 2 */
 
 // Tile height.  A tile is ~80 groups of MFMAs (~200 us): with a fixed height the last partial round of tiles would leave
@@ -825,7 +822,6 @@ __device__ __forceinline__ void srf_gs_offset(const float *__restrict__ in, cons
             for (int cb = 0; cb < 2; ++cb) acc[cb][jj] = valid ? s_out[oaddr[jj] + cb * 16] : 0.0f;
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMA block
-        if (SRF_GS_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
 #pragma unroll
@@ -835,7 +831,6 @@ __device__ __forceinline__ void srf_gs_offset(const float *__restrict__ in, cons
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[c][2 + (s >> 2)][s & 3], acc[1], 0, 0, 0);
             }
         }
-        if (SRF_GS_PRIO) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
             if (oaddr[jj] >= 0) {
@@ -858,7 +853,7 @@ __device__ __forceinline__ void srf_gs_offset(const float *__restrict__ in, cons
 // rulebook into T ranges of (almost) equal PAIR count -- range t = the rows whose exclusive pair prefix lies in
 // [t*P/T, (t+1)*P/T) -- once per rulebook (the four SubM layers of a level share it).  A workgroup walks its range in
 // sub-tiles of at most SRF_GS_TMAX rows.
-#define SRF_TB_ROWS 1024
+#define SRF_TB_ROWS 256
 #define SRF_GS_ROW_COST 12 /* cost of a row = its pairs + 12: the constant carries the row's share of the per-offset and
                               per-sub-tile work (fit of the measured workgroup times: 2.0 us per group, 0.34 us per offset,
                               15 us per sub-tile); with it the slowest range of a nuScenes / Waymo sweep is 9 % / 4 % above
@@ -890,7 +885,7 @@ __device__ __forceinline__ int srf_block_scan_excl(int v, int *s_scan /* 256 + 4
     return base + x - v;
 }
 
-// pairs per row, exclusive prefix inside blocks of 1024 rows (row order), block totals
+// cost per row, exclusive prefix inside blocks of SRF_TB_ROWS rows (row order), block totals
 __global__ __launch_bounds__(256) void srf_gs_rowpairs_k(const int *__restrict__ nbr, int nbr_stride, int K, int A,
                                                        const int *__restrict__ rows_dev, int *__restrict__ local,
                                                        int *__restrict__ blocksum)

@@ -192,8 +192,11 @@ class _SparseConv(SparseModule):
                 self._srf_packed = cache
             packed = cache[1]
         tiles = None
-        if packed is not None and ops.spconv_tiles_wanted(self.in_channels, self.out_channels) and nbr.shape[1] > 0:
-            tkey = ("tiles", nbr.data_ptr(), nbr.shape[1])  # one set of balanced row ranges per rulebook
+        if self.subm and packed is not None and ops.spconv_tiles_wanted(self.in_channels, self.out_channels) and \
+                nbr.shape[1] > 0:
+            # balanced row ranges, one set per rulebook: worth their ~20 us only where several layers share the rulebook
+            # (the SubM layers of a level); a strided conv or conv_out runs on equal-height tiles
+            tkey = ("tiles", nbr.data_ptr(), nbr.shape[1])
             tiles = x.indice_dict.get(tkey)
             if tiles is None:
                 tiles = x.indice_dict[tkey] = ops.spconv_tiles(nbr, rows_dev)
