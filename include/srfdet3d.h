@@ -74,6 +74,30 @@ int srf_bitmap_strided_pairs(const int *out_indices, const int *num_out, int max
                              int in_rows, int *nbr, int nbr_stride, int fill_tail, int *pair_counts, srf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * f-4  the step before the path: the CPU transforms of the reference's test pipeline between the decoded
+ * sensor data and SRFDet.forward (configs/nus/srfdet_voxel_nusc_LC.py:253-283), on the device.
+ *
+ * srf_points_filter: PointsRangeFilter (mmdet3d points.in_range_3d: x > x_min && y > y_min && z > z_min &&
+ * x < x_max && y < y_max && z < z_max) and, when close_radius > 0, the remove_close of
+ * LoadPointsFromMultiSweeps (points with |x| < r && |y| < r dropped).  pc_range: host[6] or NULL (no range
+ * test).  The kept points are copied in their original order to out_points (room for n rows); out_index
+ * (may be NULL) receives their source rows; *num_out (device int) their count.
+ * workspace: srf_points_filter_workspace_bytes(n).
+ *
+ * srf_image_prepare: V decoded views (V, H, W, 3) uint8 -> (V, 3, Hp, Wp) float32 = NormalizeMultiviewImage
+ * ((x - mean) * (1 / std) per channel in float32, after a BGR<->RGB swap when to_rgb != 0) + PadMultiViewImage
+ * (zeros below / right of the image; Hp >= H, Wp >= W, Wp % 4 == 0; the caller rounds up to size_divisor) of
+ * mmdet3d_plugin/datasets/pipelines/transform_3d.py:7-93 + the HWC -> CHW transpose and stack of
+ * DefaultFormatBundle3D.  mean / std: host[3].
+ * ------------------------------------------------------------------------------------------------------- */
+size_t srf_points_filter_workspace_bytes(int n);
+int srf_points_filter(const float *points, int n, int nf, const float *pc_range /*host[6] or NULL*/,
+                      float close_radius, float *out_points, int *out_index, int *num_out, void *workspace,
+                      srf_stream_t stream);
+int srf_image_prepare(const unsigned char *images, int V, int H, int W, const float *mean /*host[3]*/,
+                      const float *std /*host[3]*/, int to_rgb, int Hp, int Wp, float *out, srf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * K2  dynamic voxelization.
  * Replaces mmcv.ops.Voxelization(max_num_points=-1).forward as called from SRFDet.voxelize,
  * mmdet3d_plugin/models/detectors/srfdet.py:233-247.

@@ -203,3 +203,44 @@ def bn_fold(gamma, beta, mean, var, eps):
     gamma, beta, mean, var = (np.asarray(t, np.float32) for t in (gamma, beta, mean, var))
     alpha = (gamma / np.sqrt(var + np.float32(eps))).astype(np.float32)
     return alpha, (beta - mean * alpha).astype(np.float32)
+
+
+# ---- the step before the path: CPU transforms of the reference's test pipeline (configs/nus/srfdet_voxel_nusc_LC.py:253-283) ----
+
+def points_filter(points, pc_range=None, close_radius=0.0):
+    """PointsRangeFilter = mmdet3d 1.0.0rc6 `BasePoints.in_range_3d` (strict: x > x_min & y > y_min & z > z_min & x < x_max &
+    y < y_max & z < z_max; third party, parity unpinned) and, for close_radius > 0, `LoadPointsFromMultiSweeps._remove_close`
+    (not (|x| < r and |y| < r)).  Order preserved.  -> (kept points, their source rows)."""
+    p = np.asarray(points, np.float32)
+    keep = np.ones(len(p), bool)
+    if pc_range is not None:
+        r = np.asarray(pc_range, np.float32)
+        keep &= (p[:, 0] > r[0]) & (p[:, 1] > r[1]) & (p[:, 2] > r[2]) & (p[:, 0] < r[3]) & (p[:, 1] < r[4]) & (p[:, 2] < r[5])
+    if close_radius > 0:
+        rr = np.float32(close_radius)
+        keep &= ~((np.abs(p[:, 0]) < rr) & (np.abs(p[:, 1]) < rr))
+    idx = np.nonzero(keep)[0].astype(np.int32)
+    return p[idx], idx
+
+
+def image_prepare(images_u8, mean, std, to_rgb=False, size_divisor=32, size=None):
+    """NormalizeMultiviewImage + PadMultiViewImage (mmdet3d_plugin/datasets/pipelines/transform_3d.py:7-93) + the HWC -> CHW
+    transpose / stack of DefaultFormatBundle3D: float32 pixels, (x - mean) * (1 / float64(std) as float32) per channel after an
+    optional BGR -> RGB swap (mmcv.imnormalize; third party, parity unpinned), zeros appended below / right up to a multiple
+    of size_divisor.  (V, H, W, 3) uint8 -> (V, 3, Hp, Wp) float32."""
+    img = np.asarray(images_u8)
+    assert img.dtype == np.uint8 and img.ndim == 4 and img.shape[3] == 3
+    V, H, W, _ = img.shape
+    x = img.astype(np.float32)
+    if to_rgb:
+        x = x[..., ::-1]
+    m = np.asarray(mean, np.float32).reshape(1, 1, 1, 3)
+    inv = (1.0 / np.asarray(std, np.float32).astype(np.float64)).astype(np.float32).reshape(1, 1, 1, 3)
+    y = ((x - m).astype(np.float32) * inv).astype(np.float32)
+    if size is not None:
+        Hp, Wp = int(size[0]), int(size[1])
+    else:
+        Hp, Wp = -(-H // size_divisor) * size_divisor, -(-W // size_divisor) * size_divisor
+    out = np.zeros((V, 3, Hp, Wp), np.float32)
+    out[:, :, :H, :W] = y.transpose(0, 3, 1, 2)
+    return out

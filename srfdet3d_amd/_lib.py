@@ -28,6 +28,9 @@ SIGNATURES = {
     "srf_abi_version": (c_int, []),
     "srf_error_string": (c_char_p, [c_int]),
     "srf_device_count": (c_int, []),
+    "srf_points_filter_workspace_bytes": (c_size_t, [c_int]),
+    "srf_points_filter": (c_int, [_P, c_int, c_int, _HF, c_float, _P, _P, _P, _P, _P]),
+    "srf_image_prepare": (c_int, [_P, c_int, c_int, c_int, _HF, _HF, c_int, c_int, c_int, _P, _P]),
     "srf_dynamic_voxelize": (c_int, [_P, c_int, c_int, _HF, _HF, _HI, _P, _P]),
     "srf_hard_voxelize_workspace_bytes": (c_size_t, [c_int, c_int]),
     "srf_hard_voxelize": (c_int, [_P, c_int, c_int, _HF, _HF, _HI, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P,

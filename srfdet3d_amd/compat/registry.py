@@ -58,6 +58,7 @@ MATCH_COST = Registry("match_cost")
 NORM_LAYERS = Registry("norm_layer")
 CONV_LAYERS = Registry("conv_layer")
 ACTIVATION_LAYERS = Registry("activation_layer")
+PIPELINES = Registry("pipeline")
 
 
 def build_voxel_encoder(cfg):

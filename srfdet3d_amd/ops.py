@@ -58,6 +58,47 @@ def dynamic_voxelize(points, voxel_size, pc_range):
     return coors
 
 
+def points_filter(points, pc_range=None, close_radius=0.0, static=False, with_index=False):
+    """PointsRangeFilter (strict inequalities on x, y, z against pc_range) and / or the multi-sweep `remove_close`
+    (|x| < r and |y| < r dropped) as one order-preserving compaction -> kept points (M, nf) [, their source rows].
+    One D2H sync for M; static=True returns all n rows (rows >= M undefined) and the device scalar M instead."""
+    points = _dev(points, "points", torch.float32)
+    n, nf = points.shape
+    L = _lib.lib()
+    dev = points.device
+    out = _empty((max(n, 1), nf), torch.float32, dev)
+    index = _empty((max(n, 1),), torch.int32, dev) if with_index else None
+    num = _empty((1,), torch.int32, dev)
+    ws = _empty((max(L.srf_points_filter_workspace_bytes(n), 4),), torch.uint8, dev)
+    check(L.srf_points_filter(_ptr(points), n, nf, hf(pc_range) if pc_range is not None else None, float(close_radius),
+                              _ptr(out), _ptr(index), _ptr(num), _ptr(ws), _stream()), "points_filter")
+    if static:
+        return (out[:n], index[:n], num) if with_index else (out[:n], num)
+    M = int(num.item())
+    return (out[:M], index[:M]) if with_index else out[:M]
+
+
+def image_prepare(images_u8, mean, std, to_rgb=False, size_divisor=32, size=None):
+    """(V, H, W, 3) uint8 decoded views -> (V, 3, Hp, Wp) float32: NormalizeMultiviewImage + PadMultiViewImage + the
+    HWC -> CHW transpose of the format bundle in one pass.  Padding to `size` (Hp, Wp) or up to a multiple of
+    `size_divisor`."""
+    if not isinstance(images_u8, torch.Tensor) or not images_u8.is_cuda or images_u8.dtype != torch.uint8:
+        raise RuntimeError("srfdet3d_amd: `images_u8` must be a GPU uint8 tensor (no CPU fallback exists)")
+    images_u8 = images_u8.contiguous()
+    V, H, W, C = images_u8.shape
+    if C != 3:
+        raise RuntimeError("srfdet3d_amd: image_prepare expects 3-channel views")
+    if size is not None:
+        Hp, Wp = int(size[0]), int(size[1])
+    else:
+        d = int(size_divisor)
+        Hp, Wp = -(-H // d) * d, -(-W // d) * d
+    out = _empty((V, 3, Hp, Wp), torch.float32, images_u8.device)
+    check(_lib.lib().srf_image_prepare(_ptr(images_u8), V, H, W, hf(mean), hf(std), int(bool(to_rgb)), Hp, Wp, _ptr(out),
+                                       _stream()), "image_prepare")
+    return out
+
+
 def hard_voxelize(points, voxel_size, pc_range, max_points, max_voxels, mean_features=0, static=False):
     """-> voxels (M,max_points,nf), coors (M,3) zyx, num (M,), mean (M,mean_features) or None.  One D2H sync for M.
     static=True: no sync; all min(n, max_voxels) rows are returned, rows >= M being padding (coors -1, num 0, zeros),

@@ -49,6 +49,10 @@ def test_host_side_helpers():
     assert L.srf_spconv_tiles_count(35000) == 512 and L.srf_spconv_tiles_count(100) == 3 and L.srf_spconv_tiles_count(0) == 1
     assert L.srf_spconv_tiles_workspace_bytes(35000) >= 35000 * 4
     assert L.srf_spconv_tiles_build(None, 0, 27, 10, None, None, None, None) == -1
+    assert L.srf_points_filter_workspace_bytes(30000) >= 8 and L.srf_points_filter_workspace_bytes(-1) == 0
+    assert L.srf_points_filter(None, 10, 2, None, 0.0, None, None, None, None, None) == -1      # nf < 3 / no counter
+    assert L.srf_image_prepare(None, 6, 900, 1600, _lib.hf([0, 0, 0]), _lib.hf([1, 1, 1]), 0, 928, 1602, None, None) == -1  # Wp % 4
+    assert L.srf_image_prepare(None, 6, 900, 1600, _lib.hf([0, 0, 0]), _lib.hf([1, 0, 1]), 0, 928, 1600, None, None) == -1  # std 0
     # bitmap-rank rulebooks / dense-side helpers: sizes and argument checks, still no GPU work
     assert L.srf_bitmap_words(hi([41, 1472, 1472]), 1) == (41 * 1472 * 1472 + 31) // 32
     assert L.srf_bitmap_words(hi([41, 1472, 1472]), 64) == 0          # cell index must fit 32 bits
