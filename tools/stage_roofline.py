@@ -112,6 +112,7 @@ def install():
             byts += 4 * out.shape[0] * Cout
         return byts, 2.0 * P * Cin * Cout, f"{Cin}->{Cout}, K={K}"
     _wrap("spconv_fwd", "mfma", w_spconv)
+    _wrap("spconv_tiles", "hbm", lambda a, k, o: (n4(a[0]) + 4 * a[0].shape[1] * 2, 0, None))
     _wrap("densify", "hbm", lambda a, k, o: (n4(a[0]) + n4(o), 0, None))
     _wrap("box_rois", "latency", lambda a, k, o: (n4(a[0]) * 2, 0, None))
 
