@@ -368,4 +368,8 @@ def test_remaining_reference_configs_run_and_graphs_agree(name, n_cam, sweep, np
             # five free-running random-weight stages amplify the last-bit differences between MIOpen's eager and captured
             # algorithm choices; a broken graph is off by 1e-2 and more
             torch.testing.assert_close(e["scores"], want[i][0], rtol=0, atol=2e-4)
-            torch.testing.assert_close(e["boxes"], want[i][1], rtol=3e-3, atol=2e-3)
+            # boxes: all but a stray element within 1e-3 (one size entry -- exp() of a free-running delta -- of the Waymo LC
+            # config moves by 1e-3..3e-3 from run to run), every element within 1e-2
+            tight = torch.isclose(e["boxes"], want[i][1], rtol=1e-3, atol=2e-3)
+            assert tight.float().mean().item() >= 0.99, f"{(~tight).sum().item()} of {tight.numel()} box entries differ"
+            torch.testing.assert_close(e["boxes"], want[i][1], rtol=1e-2, atol=2e-3)
