@@ -60,8 +60,8 @@ def main():
     ap.add_argument("--eager", action="store_true", help="do not replay the static tail as a hipGraph")
     ap.add_argument("--whole-frame", default="auto", choices=["auto", "on", "off"],
                     help="replay voxelization + sparse encoder + tail as ONE hipGraph (capacity-padded static shapes). auto = on "
-                         "for the LiDAR-only workloads; off for LC, where it is worth 0.5 %% and would take the per-launch HIP "
-                         "events of `roofline` out of the timed region")
+                         "for the LiDAR-only workloads; off for LC, where it is worth 1.2 %% (12.63 instead of 12.48 frames/s) and "
+                         "would take the per-launch HIP events of `roofline` out of the timed region")
     ap.add_argument("--img-overlap", action="store_true",
                     help="LC only: replay the image-branch graph on a side stream beside the LiDAR half (about 2.5 %% "
                          "more frames/s, but the sparse-conv kernels then share the chip and their per-launch times "
