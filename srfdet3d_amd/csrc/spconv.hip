@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256) void srf_spconv_direct_k(const float *__restri
 // accumulators: one barrier per group (the A hand-over) suffices.
 //   gs layout: Wg[k][chunk][wc = col/32][g][lane][i], idx = 4g + i, = W[k][chunk*32 + 4*(idx&7) + (lane>>4)]
 //                                                                      [wc*32 + 16*(idx>>3) + (lane&15)]
-// LDS: output tile 88 x 132 x 4 = 46.5 KB, A 2 x (NCH x 2 KB), row lists 27 x 96 x 5 B = 13 KB -> 76 KB, two workgroups
+// LDS: output tile (88 + 1 spare row for the padding slots of last groups) x 132 x 4 = 47 KB, A 2 x (NCH x 2 KB), row lists 27 x 96 x 5 B = 13 KB -> 76 KB, two workgroups
 // per CU (224 VGPRs).  Which rows a workgroup owns: srf_spconv_tiles_build below (ranges of equal cost), or equal-height
 // tiles when the caller passes no ranges.
 // Measured (MI355X, nuScenes level 4, 35k rows, 556k pairs): 277 us vs 342 us for srf_spconv_direct_k; 558 vs 582 us on a
@@ -749,8 +749,8 @@ __global__ __launch_bounds__(256) void srf_pack_weights_gs_k(const float *__rest
     P[t] = c < Cin ? W[((size_t)k * Cin + c) * Cout + col] : 0.0f;
 }
 
-// rows of one group, global -> registers.  Padding entries of a last group (-1) read row 0: their MFMA rows are never
-// written back, so any finite-or-not value will do and no zero fill is needed
+// rows of one group, global -> registers.  Padding entries of a last group read row 0 and accumulate into a spare row of
+// the output tile that is never stored: any finite-or-not value will do, no zero fill and no predicates are needed
 template <int NCH, int NA>
 __device__ __forceinline__ void srf_gs_gather(const float *__restrict__ in, const int *s_rows, f32x4 (&ra)[NA])
 {
@@ -759,8 +759,8 @@ __device__ __forceinline__ void srf_gs_gather(const float *__restrict__ in, cons
     for (int j = 0; j < NA; ++j) {
         const int e = tid + j * 256;
         const int r = e / (8 * NCH), q = e % (8 * NCH);
-        const int i = s_rows[r];
-        ra[j] = *reinterpret_cast<const f32x4 *>(in + (size_t)(i >= 0 ? i : 0) * (32 * NCH) + q * 4);
+        const int i = s_rows[r];  // padding entries of a last group name row 0
+        ra[j] = *reinterpret_cast<const f32x4 *>(in + (size_t)i * (32 * NCH) + q * 4);
     }
 }
 
@@ -809,17 +809,15 @@ __device__ __forceinline__ void srf_gs_offset(const float *__restrict__ in, cons
             af[c][0] = *reinterpret_cast<const f32x4 *>(abase + c * SRF_GS_CHS + (((aj << 1) ^ a_swz) << 2));
             af[c][1] = *reinterpret_cast<const f32x4 *>(abase + c * SRF_GS_CHS + ((((aj << 1) + 1) ^ a_swz) << 2));
         }
-        const int nrows = n - g * 16;  // >= 1; rows beyond it are padding of the last group
+        // output slots of the group's 16 rows; padding rows of a last group name the spare row SRF_GS_TMAX
         const unsigned sl4 = *reinterpret_cast<const unsigned *>(s_slot + kc * SRF_GS_LS + g * 16 + aj * 4);
         f32x4 acc[2];
         int oaddr[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const bool valid = aj * 4 + jj < nrows;
-            const int slot = valid ? (int)((sl4 >> (8 * jj)) & 255u) : 0;
-            oaddr[jj] = valid ? slot * SRF_GS_OS + wc * 32 + ar : -1;
+            oaddr[jj] = (int)((sl4 >> (8 * jj)) & 255u) * SRF_GS_OS + wc * 32 + ar;
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[cb][jj] = valid ? s_out[oaddr[jj] + cb * 16] : 0.0f;
+            for (int cb = 0; cb < 2; ++cb) acc[cb][jj] = s_out[oaddr[jj] + cb * 16];
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMA block
 #pragma unroll
@@ -832,11 +830,10 @@ __device__ __forceinline__ void srf_gs_offset(const float *__restrict__ in, cons
             }
         }
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-            if (oaddr[jj] >= 0) {
-                s_out[oaddr[jj]] = acc[0][jj];
-                s_out[oaddr[jj] + 16] = acc[1][jj];
-            }
+        for (int jj = 0; jj < 4; ++jj) {
+            s_out[oaddr[jj]] = acc[0][jj];
+            s_out[oaddr[jj] + 16] = acc[1][jj];
+        }
         // every load issued in this group has landed before the next one starts.  Stated explicitly (s_waitcnt vmcnt(0)):
         // the compiler cannot tie "B was prefetched" to "the gather was waited for" across the two branches and would
         // otherwise guard the next group's MFMAs with vmcnt waits that also catch that group's own fresh loads
@@ -1007,7 +1004,7 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
     __shared__ __attribute__((aligned(4))) unsigned char s_slot[SRF_KMAX * LS];  // ... and their slot in the output tile
     __shared__ int s_cnt[SRF_KMAX];
     __shared__ int s_klist[SRF_KMAX + 1];
-    __shared__ __attribute__((aligned(16))) float s_out[SRF_GS_TMAX * SRF_GS_OS];
+    __shared__ __attribute__((aligned(16))) float s_out[(SRF_GS_TMAX + 1) * SRF_GS_OS];  // + the spare row of padding slots
     __shared__ __attribute__((aligned(16))) float s_a[2 * NCH * SRF_GS_CHS];
 
     const int A_cap = A_out;
@@ -1053,8 +1050,12 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
         if (k >= SRF_KMAX) break;
         int *lin = s_in + k * LS;
         unsigned char *lsl = s_slot + k * LS;
-        lin[lane] = -1;  // padding of the last group (same wave: ordered before the compacted stores)
-        if (lane < LS - 64) lin[64 + lane] = -1;
+        lin[lane] = 0;  // padding of the last group: input row 0 into the spare output row (same wave: ordered before the
+        lsl[lane] = (unsigned char)SRF_GS_TMAX;  // compacted stores below)
+        if (lane < LS - 64) {
+            lin[64 + lane] = 0;
+            lsl[64 + lane] = (unsigned char)SRF_GS_TMAX;
+        }
         int base = 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
