@@ -1034,6 +1034,11 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
     const int TM = (((range1 - range0 + nsub - 1) / nsub) + 7) & ~7;  // <= SRF_GS_TMAX (a multiple of 8)
     for (int row0 = range0; row0 < range1; row0 += TM) {
     const int row_end = row0 + TM < range1 ? row0 + TM : range1;  // rows of this sub-tile: [row0, row_end)
+    // An opaque zero: the address arithmetic of the prologue / epilogue below is invariant across sub-tiles, and hoisted
+    // above this loop it stays live through the main loop, where every register is taken -- the compiler then spills it
+    // (11 MB of scratch write-back per launch).  Tied to this value it is recomputed per sub-tile instead.
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
     for (int e = tid; e < TM * SRF_GS_OS / 4; e += 256) reinterpret_cast<f32x4 *>(s_out)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
     // compaction: the wave's offsets (wave, wave + 4, ...), rows in two segments of 64; all loads in flight together
     int nv[NKW][2];
@@ -1042,14 +1047,14 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = wave + 4 * i, r = h * 64 + lane;
-            nv[i][h] = (k < K && row0 + r < row_end) ? nbr[(size_t)k * nbr_stride + row0 + r] : -1;
+            nv[i][h] = (k < K && row0 + r < row_end) ? nbr[(size_t)(k + zero) * nbr_stride + row0 + r] : -1;
         }
 #pragma unroll
     for (int i = 0; i < NKW; ++i) {
         const int k = wave + 4 * i;
         if (k >= SRF_KMAX) break;
-        int *lin = s_in + k * LS;
-        unsigned char *lsl = s_slot + k * LS;
+        int *lin = s_in + (k + zero) * LS;
+        unsigned char *lsl = s_slot + (k + zero) * LS;
         lin[lane] = 0;  // padding of the last group: input row 0 into the spare output row (same wave: ordered before the
         lsl[lane] = (unsigned char)SRF_GS_TMAX;  // compacted stores below)
         if (lane < LS - 64) {
@@ -1105,7 +1110,7 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
     }
 
     // epilogue: every output row once, BN / residual / ReLU in registers, 512 B per row and store
-    const int c4 = (tid & 31) * 4;
+    const int c4 = ((tid & 31) + zero) * 4;
     f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
     if (alpha) {
         al = *reinterpret_cast<const f32x4 *>(alpha + c4);
