@@ -701,9 +701,9 @@ __global__ __launch_bounds__(256) void srf_spconv_direct_k(const float *__restri
 // LDS: output tile (88 + 1 spare row for the padding slots of last groups) x 132 x 4 = 47 KB, A 2 x (NCH x 2 KB), row lists 27 x 96 x 5 B = 13 KB -> 76 KB, two workgroups
 // per CU (224 VGPRs).  Which rows a workgroup owns: srf_spconv_tiles_build below (ranges of equal cost), or equal-height
 // tiles when the caller passes no ranges.
-// Measured (MI355X, nuScenes level 4, 35k rows, 556k pairs): 264 us vs 342 us for srf_spconv_direct_k; 541 vs 582 us on a
+// Measured (MI355X, nuScenes level 4, 35k rows, 556k pairs): 257 us vs 342 us for srf_spconv_direct_k; 514 vs 582 us on a
 // 66k-row level with 19.5 pairs per row.  A workgroup spends ~45 % of a group's time issuing MFMAs and the two
-// workgroups of a CU do not interleave perfectly (MFMA pipe busy 62 %): the remaining distance to the MFMA roofline.
+// workgroups of a CU do not interleave perfectly (MFMA pipe busy 64 %): the remaining distance to the MFMA roofline.
 // =====================================================================================================================
 #define SRF_GS_TMAX 88   /* most output rows of a tile: 2 workgroups per CU still fit in LDS */
 #define SRF_GS_LS 96     /* stride of the per-offset row lists (TMAX rounded up to whole groups) */
