@@ -72,3 +72,40 @@ def test_sync_bn_and_sharding_two_ranks():
     for rank, *_rest in res:
         torch.testing.assert_close(res[rank][4], xf.grad[rank::world], rtol=1e-4, atol=1e-5)
     assert sorted(res[0][5] + res[1][5]) == list(range(10))
+
+
+def _gather_worker(rank, world, port, q, n_frames):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from srfdet3d_amd.sharding import frame_indices, gather_detections
+    mine = frame_indices(n_frames, rank, world)
+    part = [dict(frame=i, boxes=np.full((2, 9), float(i), np.float32), scores=np.array([0.5, 0.25], np.float32)) for i in mine]
+    out = gather_detections(part, n_frames)
+    q.put((rank, mine, None if out is None else [(d["frame"], float(d["boxes"][0, 0])) for d in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_sharding_and_end_of_run_gather_two_ranks():
+    """frames i -> rank i mod W (DistributedSampler(shuffle=False), tools/test.py:195-200), no collective on
+    the data path, one gather of the detections at the end that restores dataset order and cuts the padding."""
+    from srfdet3d_amd.sharding import frame_indices
+    assert frame_indices(7, 0, 1) == list(range(7))
+    assert frame_indices(7, 0, 2) == [0, 2, 4, 6] and frame_indices(7, 1, 2) == [1, 3, 5, 0]      # padded with the head
+    assert frame_indices(2, 3, 4) == [1] and frame_indices(1, 2, 4) == [0]
+    assert sorted(sum((frame_indices(10, r, 4) for r in range(4)), []))[:10] != []               # every rank has ceil(n/W)
+    assert all(len(frame_indices(10, r, 4)) == 3 for r in range(4))
+    world, n = 2, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q, n)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5, 0]
+    assert res[1][2] is None
+    assert res[0][2] == [(i, float(i)) for i in range(n)]
