@@ -424,6 +424,11 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * 32;
     const int C = TAIL_C, F = tw.F;
+    // gridDim.y == 2: the two towers of a row tile run in two workgroups (both compute the FFN, which is cheaper than
+    // waiting: 7 row tiles leave the chip idle, and the chain drops from 15 to 12 dependent weight blocks); y == 0 also owns
+    // obj_out.  gridDim.y == 1: one workgroup runs both towers.
+    const int first_tower = gridDim.y == 2 ? (int)blockIdx.y : 0;
+    const int last_tower = gridDim.y == 2 ? (int)blockIdx.y : 1;
     float *p_b1 = s_par, *p_b2 = p_b1 + 4 * LIN_TN, *p_n3g = p_b2 + C, *p_n3b = p_n3g + C;
     float *p_tw = p_n3b + C;                                 // towers: [cls g, b] x 4, [reg g, b] x 4
     float *p_bl = p_tw + 4 * TAIL_MAX_TOWER * C, *p_bd = p_bl + 32;
@@ -477,8 +482,13 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
         srf_tail_commit(blk, s_w);                 // W2 k-block (all waves are past the MFMAs that read s_w)
         __syncthreads();
         if (n0 + LIN_TN < F) srf_tail_load(blk, tw.w1, C, n0 + LIN_TN, F, 0);
-        else if (tw.n_cls > 0) srf_tail_load(blk, tw.cls_w[0], C, 0, C, 0);
-        else srf_tail_load(blk, tw.wl, C, 0, tw.ncls, 0);
+        else if (first_tower == 0) {
+            if (tw.n_cls > 0) srf_tail_load(blk, tw.cls_w[0], C, 0, C, 0);
+            else srf_tail_load(blk, tw.wl, C, 0, tw.ncls, 0);
+        } else {
+            if (tw.n_reg > 0) srf_tail_load(blk, tw.reg_w[0], C, 0, C, 0);
+            else srf_tail_load(blk, tw.wd, C, 0, tw.Dd, 0);
+        }
         srf_tail_mma(img_h, s_w, acc2);
         __syncthreads();
     }
@@ -492,8 +502,10 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
             float v[2] = {s_out[r][lane], s_out[r][lane + 64]};
             if (row < R) {
                 srf_row_epilogue<2>(v, C, lane, row, ep);
-                obj_out[(size_t)row * C + lane] = v[0];
-                obj_out[(size_t)row * C + lane + 64] = v[1];
+                if (first_tower == 0) {
+                    obj_out[(size_t)row * C + lane] = v[0];
+                    obj_out[(size_t)row * C + lane + 64] = v[1];
+                }
             } else {
                 v[0] = v[1] = 0.f;
             }
@@ -504,7 +516,7 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
     __syncthreads();
     srf_tail_to_image(s_out, img_obj);  // img_obj now holds obj2, the input of both towers
     // ---- towers ---------------------------------------------------------------------------------------------------------
-    for (int tower = 0; tower < 2; ++tower) {
+    for (int tower = first_tower; tower <= last_tower; ++tower) {
         const int nl = tower == 0 ? tw.n_cls : tw.n_reg;
         const int N = tower == 0 ? tw.ncls : tw.Dd;
         const float *src = img_obj;
@@ -514,7 +526,7 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
             // next block: the next layer of this tower, its head, or the first block of the other tower
             if (l + 1 < nl) srf_tail_load(blk, tower == 0 ? tw.cls_w[l + 1] : tw.reg_w[l + 1], C, 0, C, 0);
             else if (l + 1 == nl) srf_tail_load(blk, tower == 0 ? tw.wl : tw.wd, C, 0, N, 0);
-            else if (tower == 0) {
+            else if (tower == 0 && last_tower == 1) {
                 if (tw.n_reg > 0) srf_tail_load(blk, tw.reg_w[0], C, 0, C, 0);
                 else srf_tail_load(blk, tw.wd, C, 0, tw.Dd, 0);
             }
@@ -872,7 +884,7 @@ extern "C" int srf_stage_tail(const float *obj_in, int R, int C, int F, const fl
         SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_stage_tail_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         attr_set = true;
     }
-    hipLaunchKernelGGL(srf_stage_tail_k, dim3(srf_ceil_div(R, 32)), dim3(256), sh, (hipStream_t)stream, obj_in, R, tw, boxes_m, g,
+    hipLaunchKernelGGL(srf_stage_tail_k, dim3(srf_ceil_div(R, 32), 2), dim3(256), sh, (hipStream_t)stream, obj_in, R, tw, boxes_m, g,
                        obj_out, logits, pred);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
