@@ -86,6 +86,77 @@ __device__ __forceinline__ void srf_row_epilogue(float (&v)[NV], int N, int lane
         for (int i = 0; i < NV; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
 }
 
+// The same epilogue for a wave that walks several rows: the column vectors (bias, LayerNorm gains / offsets) are loaded once
+// per wave and the residual rows are fetched before the loop -- read inside it, every row pays its own L2 round trips
+// (bias -> ln1 -> residual -> ln2: 16 of the 20 us of a 128 -> 128 projection at 200 rows).
+template <int NV>
+struct RowVecs {
+    float bias[NV], g1[NV], b1[NV], g2[NV], b2[NV];
+};
+
+template <int NV>
+__device__ __forceinline__ void srf_row_vecs_load(RowVecs<NV> &pv, int N, int lane, const RowEpilogue &ep)
+{
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        const bool in = c < N;
+        pv.bias[i] = (ep.bias && in) ? ep.bias[c] : 0.f;
+        pv.g1[i] = (ep.ln1_g && in) ? ep.ln1_g[c] : 0.f;
+        pv.b1[i] = (ep.ln1_g && in) ? ep.ln1_b[c] : 0.f;
+        pv.g2[i] = (ep.ln2_g && in) ? ep.ln2_g[c] : 0.f;
+        pv.b2[i] = (ep.ln2_g && in) ? ep.ln2_b[c] : 0.f;
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void srf_wave_layernorm_regs(float (&v)[NV], int N, int lane, const float (&g)[NV], const float (&b)[NV],
+                                                        float eps)
+{
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + i * 64 < N) s += v[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    const float mean = s / (float)N;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + i * 64 < N) {
+            const float t = v[i] - mean;
+            q += t * t;
+        }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) q += __shfl_xor(q, d, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)N + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + i * 64 < N) v[i] = (v[i] - mean) * rstd * g[i] + b[i];
+}
+
+template <int NV>
+__device__ __forceinline__ void srf_row_epilogue_regs(float (&v)[NV], int N, int lane, const float (&res)[NV], const RowEpilogue &ep,
+                                                      const RowVecs<NV> &pv)
+{
+    if (ep.bias)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + i * 64 < N) v[i] += pv.bias[i];
+    if (ep.ln1_g) srf_wave_layernorm_regs<NV>(v, N, lane, pv.g1, pv.b1, ep.eps1);
+    if (ep.relu1)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+    if (ep.residual)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + i * 64 < N) v[i] += res[i];
+    if (ep.ln2_g) srf_wave_layernorm_regs<NV>(v, N, lane, pv.g2, pv.b2, ep.eps2);
+    if (ep.relu2)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // srf_linear
 // ---------------------------------------------------------------------------------------------------------------------
@@ -214,35 +285,64 @@ __global__ __launch_bounds__(256) void srf_linear_k(const float *__restrict__ X,
 #pragma unroll
     for (int j = 0; j < 16; ++j) s_out[(j & 3) + 8 * (j >> 2) + 4 * kh][wave * 32 + (lane & 31)] = acc[j];
     __syncthreads();
-    for (int r = wave * 8; r < wave * 8 + 8; ++r) {
-        const int row = row0 + r;
-        if (row >= M) break;
-        float v[2] = {lane < N ? s_out[r][lane] : 0.f, lane + 64 < N ? s_out[r][lane + 64] : 0.f};
-        srf_row_epilogue<2>(v, N, lane, row, ep);
-        if (lane < N) Y[(size_t)row * ldy + lane] = v[0];
-        if (lane + 64 < N) Y[(size_t)row * ldy + lane + 64] = v[1];
+    RowVecs<2> pv;
+    srf_row_vecs_load<2>(pv, N, lane, ep);
+    float res[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = row0 + wave * 8 + i;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            res[i][h] = (ep.residual && row < M && lane + h * 64 < N) ? ep.residual[(size_t)row * ep.ldr + lane + h * 64] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = wave * 8 + i, row = row0 + r;
+        if (row < M) {
+            float v[2] = {lane < N ? s_out[r][lane] : 0.f, lane + 64 < N ? s_out[r][lane + 64] : 0.f};
+            srf_row_epilogue_regs<2>(v, N, lane, res[i], ep, pv);
+            if (lane < N) Y[(size_t)row * ldy + lane] = v[0];
+            if (lane + 64 < N) Y[(size_t)row * ldy + lane + 64] = v[1];
+        }
     }
 }
 
 // one wave per row: sum the split-K partial slabs (or read a finished product), then the epilogue chain.  N <= 1024.
+template <int NV>  // columns per lane: 2 for N <= 128 (everything the epilogue reads is fetched up front), 16 up to N = 1024
 __global__ __launch_bounds__(256) void srf_rows_epilogue_k(const float *__restrict__ partial, int nsplit, int M, int N,
                                                          float *__restrict__ Y, int ldy, RowEpilogue ep)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    float v[16];
+    RowVecs<NV> pv;
+    float res[NV];
+    if (NV <= 2) {  // issued before the slab sums below, which they overlap
+        srf_row_vecs_load<NV>(pv, N, lane, ep);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NV; ++i)
+            res[i] = (ep.residual && lane + i * 64 < N) ? ep.residual[(size_t)row * ep.ldr + lane + i * 64] : 0.f;
+    }
+    float v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         float s = 0.f;
         if (c < N)
-            for (int p = 0; p < nsplit; ++p) s += partial[((size_t)p * M + row) * N + c];
+            for (int p0 = 0; p0 < nsplit; p0 += 8) {  // eight slab loads in flight, summed in slab order
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = p0 + u < nsplit ? partial[((size_t)(p0 + u) * M + row) * N + c] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (p0 + u < nsplit) s += t[u];
+            }
         v[i] = s;
     }
-    srf_row_epilogue<16>(v, N, lane, row, ep);
+    if (NV <= 2) srf_row_epilogue_regs<NV>(v, N, lane, res, ep, pv);
+    else srf_row_epilogue<NV>(v, N, lane, row, ep);
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < NV; ++i)
         if (lane + i * 64 < N) Y[(size_t)row * ldy + lane + i * 64] = v[i];
 }
 
@@ -273,6 +373,44 @@ extern "C" size_t srf_linear_workspace_bytes(int M, int N, int K)
     return (size_t)nsplit * (size_t)(M > 0 ? M : 1) * N * sizeof(float);
 }
 
+// M <= 8 without a row epilogue (the two Linear layers of the proposal generator at batch size 1..8, srfdet_head.py:541-548):
+// a GEMV.  On the MFMA kernel above 31 of the 32 tile rows would be padding and 4-8 workgroups would stream the 2-3 MB of
+// weights alone (33 + 21 us per frame); here one wave owns one output column, reads its weight row with coalesced float4
+// loads and reduces over the lanes (5 us each).
+__global__ __launch_bounds__(256) void srf_linear_gemv_k(const float *__restrict__ X, int M, int K, int ldx, const float *__restrict__ W,
+                                                       int N, int ldw, const float *__restrict__ bias, int relu, float *__restrict__ Y, int ldy)
+{
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = 0.f;
+    const float *w = W + (size_t)n * ldw;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + k);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (m < M) {
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(X + (size_t)m * ldx + k);
+                acc[m] = __fmaf_rn(xv[3], wv[3], __fmaf_rn(xv[2], wv[2], __fmaf_rn(xv[1], wv[1], __fmaf_rn(xv[0], wv[0], acc[m]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        if (m < M) {
+            float v = acc[m];
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane == 0) {
+                v += bias ? bias[n] : 0.f;
+                if (relu) v = v > 0.f ? v : 0.f;
+                Y[(size_t)m * ldy + n] = v;
+            }
+        }
+    }
+}
+
 extern "C" int srf_linear(const float *X, int M, int K, int ldx, const float *W, int N, int ldw, const float *bias,
                           const float *ln1_g, const float *ln1_b, float eps1, int relu1, const float *residual, int ldr,
                           const float *ln2_g, const float *ln2_b, float eps2, int relu2, float *Y, int ldy,
@@ -291,14 +429,23 @@ extern "C" int srf_linear(const float *X, int M, int K, int ldx, const float *W,
         kps = 256;
         nsplit = (K + kps - 1) / kps;
     }
+    if (!rows && M <= 8) {
+        hipLaunchKernelGGL(srf_linear_gemv_k, dim3(srf_ceil_div(N, 4)), dim3(256), 0, st, X, M, K, ldx, W, N, ldw, bias, relu1, Y, ldy);
+        SRF_LAUNCH_CHECK();
+        return SRF_OK;
+    }
     const bool two_pass = nsplit > 1 || (rows && N > LIN_TN);
     if (two_pass) {
         if (!workspace || workspace_bytes < (size_t)nsplit * M * N * sizeof(float)) return SRF_EWORKSPACE;
         RowEpilogue none = srf_make_epilogue(nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0, nullptr, nullptr, 0.f, 0);
         hipLaunchKernelGGL(srf_linear_k, dim3(srf_ceil_div(N, LIN_TN), srf_ceil_div(M, LIN_TM), nsplit), dim3(256), 0, st, X, M, K,
                            ldx, W, N, ldw, Y, ldy, kps, (float *)workspace, none, 0);
-        hipLaunchKernelGGL(srf_rows_epilogue_k, dim3(srf_ceil_div(M, 4)), dim3(256), 0, st, (const float *)workspace, nsplit, M,
-                           N, Y, ldy, ep);
+        if (N <= 128)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_rows_epilogue_k<2>), dim3(srf_ceil_div(M, 4)), dim3(256), 0, st,
+                               (const float *)workspace, nsplit, M, N, Y, ldy, ep);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_rows_epilogue_k<16>), dim3(srf_ceil_div(M, 4)), dim3(256), 0, st,
+                               (const float *)workspace, nsplit, M, N, Y, ldy, ep);
     } else {
         hipLaunchKernelGGL(srf_linear_k, dim3(srf_ceil_div(N, LIN_TN), srf_ceil_div(M, LIN_TM), 1), dim3(256), 0, st, X, M, K, ldx,
                            W, N, ldw, Y, ldy, K, (float *)nullptr, ep, rows ? 1 : 0);
