@@ -331,6 +331,20 @@ int srf_nms_rotated(const float *boxes, int n, float iou_threshold, int *keep, v
 int srf_nms_rotated_counted(const float *boxes_xywhr, int n, const int *n_dev, float iou_threshold, int *keep,
                             void *workspace, size_t workspace_bytes, srf_stream_t stream);
 
+/* The fixed-shape multi-class selection around srf_nms_rotated_counted: the static form of mmdet3d box3d_multiclass_nms as
+ * called at srfdet_head.py:1276-1293, without a host read-back (hipGraph replay).
+ * srf_nms_select: boxes (n, D >= 7) [x, y, z, w, l, h, yaw, ...], scores (n, C) -> the L best (box, class) pairs above
+ * score_thr in descending score: cand (L, D), top_s (L), cls (L, int64), bev (L, 5) = [x + class * span, y, w, l, yaw]
+ * (classes pushed apart by span = (max|x,y| + max|w,l|) * 4 + 1 so that one NMS pass is the reference's per-class NMS),
+ * *m (device int) = number of pairs above the threshold -- if it exceeds L the caller redoes the frame on the dynamic
+ * path.  n * C <= 16384, L <= n * C.
+ * srf_nms_finish: keep (L) from srf_nms_rotated_counted -> survivors first, class-major, descending score inside a class
+ * (the order of the reference's per-class loop): out_boxes (L, D), out_scores (L), out_labels (L, int64), *kept. */
+int srf_nms_select(const float *boxes, const float *scores, int n, int C, int D, float score_thr, int L, float *cand,
+                   float *top_s, long long *cls, float *bev, int *m, srf_stream_t stream);
+int srf_nms_finish(const float *cand, const float *top_s, const long long *cls, const int *keep, int L, int D,
+                   float *out_boxes, float *out_scores, long long *out_labels, int *kept, srf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

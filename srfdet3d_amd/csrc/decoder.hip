@@ -640,15 +640,26 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
         __syncthreads();
     }
     // ---- obj2 = LN3(obj + ffn + b2) ----------------------------------------------------------------------------------
+    float res[8][2];  // the residual rows of this wave, all in flight before the spill below (not one L2 round trip per row)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = row0 + wave * 8 + i;
+        res[i][0] = row < R ? obj_in[(size_t)row * C + lane] : 0.f;
+        res[i][1] = row < R ? obj_in[(size_t)row * C + lane + 64] : 0.f;
+    }
     srf_tail_spill(acc2, s_out);
     __syncthreads();
     {
         RowEpilogue ep = {p_b2, nullptr, nullptr, obj_in, p_n3g, p_n3b, C, 0, 0, 0.f, tw.eps_n3};
-        for (int r = wave * 8; r < wave * 8 + 8; ++r) {
+        RowVecs<2> pv;
+        srf_row_vecs_load<2>(pv, C, lane, ep);  // from LDS (s_par)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 8 + i;
             const int row = row0 + r;
             float v[2] = {s_out[r][lane], s_out[r][lane + 64]};
             if (row < R) {
-                srf_row_epilogue<2>(v, C, lane, row, ep);
+                srf_row_epilogue_regs<2>(v, C, lane, res[i], ep, pv);
                 if (first_tower == 0) {
                     obj_out[(size_t)row * C + lane] = v[0];
                     obj_out[(size_t)row * C + lane + 64] = v[1];

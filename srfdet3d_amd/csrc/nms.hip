@@ -197,3 +197,204 @@ static int srf_nms_launch(const float *boxes, int n, const int *n_dev, float iou
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }
+
+// =====================================================================================================================
+// The fixed-shape multi-class selection around the NMS (the static form of mmdet3d's box3d_multiclass_nms as called at
+// srfdet_head.py:1276-1293), in two single-workgroup launches instead of ~25 torch launches of 4-40 us each (threshold,
+// topk, index arithmetic, gathers, stack, a second sort ...): at a few thousand (box, class) scores the whole job is a
+// bitonic sort in LDS.
+//   srf_nms_select:  scores (n, C) -> the L = capacity best (box, class) pairs above score_thr in descending score
+//                    (ties: lower flat index first): their boxes `cand` (L, D), scores `top_s` (L), classes `cls` (L),
+//                    BEV boxes for the NMS `bev` (L, 5) = [x + class * span, y, w, l, yaw] with span = (max|x,y| +
+//                    max|w,l|) * 4 + 1 (classes pushed apart so that ONE rotated-NMS pass is the per-class NMS of the
+//                    reference), and *m = number of pairs above the threshold (may exceed L: the caller then falls back).
+//                    Rows >= min(*m, L) hold score -1 and an arbitrary valid box.
+//   srf_nms_finish:  survivors (keep != 0) first, class-major, descending score inside a class (the order of the
+//                    reference's per-class loop), stable; *kept = their number.
+// =====================================================================================================================
+#define SRF_SEL_THREADS 1024
+
+__device__ __forceinline__ bool srf_sel_before(float ka, int ia, float kb, int ib, bool descending)
+{
+    if (ka != kb) return descending ? ka > kb : ka < kb;
+    return ia < ib;
+}
+
+// bitonic sort of P = 2^p (key, index) pairs in LDS into the order srf_sel_before defines (a strict total order)
+__device__ void srf_sel_sort(float *key, int *idx, int P, bool descending)
+{
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < P; t += SRF_SEL_THREADS) {
+                const int o = t ^ j;
+                if (o > t) {
+                    const bool up = (t & k) == 0;  // this pair ends in "before" order when up
+                    const float ka = key[t], kb = key[o];
+                    const int ia = idx[t], ib = idx[o];
+                    const bool a_first = srf_sel_before(ka, ia, kb, ib, descending);
+                    if (a_first != up) {
+                        key[t] = kb;
+                        key[o] = ka;
+                        idx[t] = ib;
+                        idx[o] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(SRF_SEL_THREADS) void srf_nms_select_k(const float *__restrict__ boxes, const float *__restrict__ scores,
+                                                                  int n, int C, int D, float score_thr, int L, int P,
+                                                                  float *__restrict__ cand, float *__restrict__ top_s,
+                                                                  long long *__restrict__ cls, float *__restrict__ bev,
+                                                                  int *__restrict__ m_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sel_lds[];
+    float *key = reinterpret_cast<float *>(sel_lds);
+    int *idx = reinterpret_cast<int *>(key + P);
+    __shared__ float s_red[2][SRF_SEL_THREADS / 64];
+    __shared__ int s_cnt[SRF_SEL_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = n * C;
+    int cnt = 0;
+    for (int t = tid; t < P; t += SRF_SEL_THREADS) {
+        float k = -2.0f;  // padding of the power-of-two array: behind every real entry
+        if (t < total) {
+            const float s = scores[t];
+            const bool valid = s > score_thr;
+            k = valid ? s : -1.0f;
+            cnt += valid ? 1 : 0;
+        }
+        key[t] = k;
+        idx[t] = t;
+    }
+    // span = (max |x|,|y| + max |w|,|l|) * 4 + 1 over all boxes
+    float mxy = 0.f, mwl = 0.f;
+    for (int b = tid; b < n; b += SRF_SEL_THREADS) {
+        const float *p = boxes + (size_t)b * D;
+        mxy = fmaxf(mxy, fmaxf(fabsf(p[0]), fabsf(p[1])));
+        mwl = fmaxf(mwl, fmaxf(fabsf(p[3]), fabsf(p[4])));
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        mxy = fmaxf(mxy, __shfl_xor(mxy, d, 64));
+        mwl = fmaxf(mwl, __shfl_xor(mwl, d, 64));
+        cnt += __shfl_xor(cnt, d, 64);
+    }
+    if (lane == 0) {
+        s_red[0][wave] = mxy;
+        s_red[1][wave] = mwl;
+        s_cnt[wave] = cnt;
+    }
+    __syncthreads();
+    mxy = 0.f;
+    mwl = 0.f;
+    cnt = 0;
+    for (int w = 0; w < SRF_SEL_THREADS / 64; ++w) {
+        mxy = fmaxf(mxy, s_red[0][w]);
+        mwl = fmaxf(mwl, s_red[1][w]);
+        cnt += s_cnt[w];
+    }
+    const float span = __fadd_rn(__fmul_rn(__fadd_rn(mxy, mwl), 4.0f), 1.0f);
+    if (tid == 0) *m_out = cnt;
+    srf_sel_sort(key, idx, P, true);
+    for (int j = tid; j < L; j += SRF_SEL_THREADS) {
+        const int flat = idx[j];
+        const int bi = flat / C, ci = flat - bi * C;
+        const float *p = boxes + (size_t)bi * D;
+        for (int c = 0; c < D; ++c) cand[(size_t)j * D + c] = p[c];
+        top_s[j] = key[j];
+        cls[j] = ci;
+        float *o = bev + (size_t)j * 5;
+        o[0] = __fadd_rn(p[0], __fmul_rn((float)ci, span));
+        o[1] = p[1];
+        o[2] = p[3];
+        o[3] = p[4];
+        o[4] = p[6];
+    }
+}
+
+__global__ __launch_bounds__(SRF_SEL_THREADS) void srf_nms_finish_k(const float *__restrict__ cand, const float *__restrict__ top_s,
+                                                                  const long long *__restrict__ cls, const int *__restrict__ keep,
+                                                                  int L, int D, int P, float *__restrict__ out_boxes,
+                                                                  float *__restrict__ out_scores, long long *__restrict__ out_labels,
+                                                                  int *__restrict__ kept_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sel_lds[];
+    float *key = reinterpret_cast<float *>(sel_lds);
+    int *idx = reinterpret_cast<int *>(key + P);
+    __shared__ int s_cnt[SRF_SEL_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int cnt = 0;
+    for (int t = tid; t < P; t += SRF_SEL_THREADS) {
+        float k = 2.0e9f;  // padding: behind everything
+        if (t < L) {
+            const bool kp = keep[t] != 0;
+            float s = top_s[t];
+            s = s < 0.f ? 0.f : (s > 1.f ? 1.f : s);
+            k = kp ? __fsub_rn(__fmul_rn((float)cls[t], 4.0f), __fmul_rn(s, 2.0f)) : 1.0e9f;
+            cnt += kp ? 1 : 0;
+        }
+        key[t] = k;
+        idx[t] = t;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int c = 0;
+        for (int w = 0; w < SRF_SEL_THREADS / 64; ++w) c += s_cnt[w];
+        *kept_out = c;
+    }
+    srf_sel_sort(key, idx, P, false);
+    for (int j = tid; j < L; j += SRF_SEL_THREADS) {
+        const int src = idx[j];
+        for (int c = 0; c < D; ++c) out_boxes[(size_t)j * D + c] = cand[(size_t)src * D + c];
+        out_scores[j] = top_s[src];
+        out_labels[j] = cls[src];
+    }
+}
+
+static int srf_sel_pow2(int v)
+{
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+extern "C" int srf_nms_select(const float *boxes, const float *scores, int n, int C, int D, float score_thr, int L, float *cand,
+                              float *top_s, long long *cls, float *bev, int *m_out, srf_stream_t stream)
+{
+    if (n <= 0 || C <= 0 || D < 7 || L <= 0 || L > n * C) return SRF_EINVAL;
+    if ((long long)n * C > 16384) return SRF_EUNSUPPORTED;  // one workgroup sorts everything in LDS (128 KB at 16384 pairs)
+    if (!boxes || !scores || !cand || !top_s || !cls || !bev || !m_out) return SRF_EINVAL;
+    const int P = srf_sel_pow2(n * C);
+    const size_t sh = (size_t)P * 8;
+    if (sh > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_nms_select_k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(srf_nms_select_k, dim3(1), dim3(SRF_SEL_THREADS), sh, (hipStream_t)stream, boxes, scores, n, C, D, score_thr, L, P,
+                       cand, top_s, cls, bev, m_out);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+extern "C" int srf_nms_finish(const float *cand, const float *top_s, const long long *cls, const int *keep, int L, int D,
+                              float *out_boxes, float *out_scores, long long *out_labels, int *kept_out, srf_stream_t stream)
+{
+    if (L <= 0 || D <= 0) return SRF_EINVAL;
+    if (L > 4096) return SRF_EUNSUPPORTED;  // the rotated NMS in between takes up to 4096 boxes
+    if (!cand || !top_s || !cls || !keep || !out_boxes || !out_scores || !out_labels || !kept_out) return SRF_EINVAL;
+    const int P = srf_sel_pow2(L);
+    hipLaunchKernelGGL(srf_nms_finish_k, dim3(1), dim3(SRF_SEL_THREADS), (size_t)P * 8, (hipStream_t)stream, cand, top_s, cls, keep, L, D, P,
+                       out_boxes, out_scores, out_labels, kept_out);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}

@@ -515,6 +515,35 @@ def nms_rotated_counted(sorted_boxes_xywhr, n_live, iou_threshold):
     return keep
 
 
+def nms_select(boxes, scores, score_thr, capacity):
+    """(n, D) boxes, (n, C) scores -> the L = min(n*C, capacity) best (box, class) pairs above score_thr in descending score:
+    cand (L, D), top_s (L,), cls (L,) int64, bev (L, 5) for the rotated NMS, m (1,) int32 = pairs above the threshold.
+    One single-workgroup launch (LDS bitonic sort), nothing read back: graph-capturable.  n*C <= 16384."""
+    boxes = _dev(boxes, "boxes", torch.float32).contiguous()
+    scores = _dev(scores, "scores", torch.float32).contiguous()
+    n, D = boxes.shape
+    C = scores.shape[1]
+    L = min(n * C, int(capacity))
+    dev = boxes.device
+    cand, top_s = _empty((L, D), torch.float32, dev), _empty((L,), torch.float32, dev)
+    cls, bev, m = _empty((L,), torch.int64, dev), _empty((L, 5), torch.float32, dev), _empty((1,), torch.int32, dev)
+    check(_lib.lib().srf_nms_select(_ptr(boxes), _ptr(scores), n, C, D, float(score_thr), L, _ptr(cand), _ptr(top_s), _ptr(cls),
+                                    _ptr(bev), _ptr(m), _stream()), "nms_select")
+    return cand, top_s, cls, bev, m
+
+
+def nms_finish(cand, top_s, cls, keep):
+    """keep flags of the NMS over nms_select's candidates -> (boxes (L, D), scores (L,), labels (L,) int64, kept (1,) int32):
+    survivors first, class-major, descending score inside a class."""
+    L, D = cand.shape
+    dev = cand.device
+    ob, os_, ol, kept = (_empty((L, D), torch.float32, dev), _empty((L,), torch.float32, dev), _empty((L,), torch.int64, dev),
+                         _empty((1,), torch.int32, dev))
+    check(_lib.lib().srf_nms_finish(_ptr(cand), _ptr(top_s), _ptr(cls), _ptr(_dev(keep, "keep", torch.int32)), L, D, _ptr(ob),
+                                    _ptr(os_), _ptr(ol), _ptr(kept), _stream()), "nms_finish")
+    return ob, os_, ol, kept
+
+
 # ---------------------------------------------------------------------------------------------- decoder stage
 def _ln(ln):
     """nn.LayerNorm or (gamma, beta, eps) or None -> (ptr_g, ptr_b, eps)."""

@@ -48,9 +48,22 @@ def box3d_multiclass_nms_static(boxes, scores, score_thr, nms_thr, capacity=STAT
     descending score inside a class); `candidates` (device int32) is the number of (box, class) pairs above the score
     threshold -- if it exceeds L the caller must redo the frame with `box3d_multiclass_nms`."""
     n, C = scores.shape
+    L = min(n * C, int(capacity))
+    if 0 < n * C <= 16384 and L <= 4096 and boxes.shape[1] >= 7:
+        # two single-workgroup launches around the NMS (LDS bitonic sorts) instead of the ~25 small torch launches below
+        cand, top_s, ci, bev, m = ops.nms_select(boxes, scores, score_thr, capacity)
+        keep = ops.nms_rotated_counted(bev, torch.clamp(m, max=L), nms_thr)
+        out_b, out_s, out_l, kept = ops.nms_finish(cand, top_s, ci, keep)
+        return out_b, out_s, out_l, kept, m
+    return _static_torch(boxes, scores, score_thr, nms_thr, L)
+
+
+def _static_torch(boxes, scores, score_thr, nms_thr, L):
+    """the same selection on torch ops (shapes beyond the fused kernels' limits; the definition the fused path is tested
+    against)"""
+    n, C = scores.shape
     flat = scores.reshape(-1)
     valid = flat > score_thr
-    L = min(n * C, int(capacity))
     key = torch.where(valid, flat, torch.full_like(flat, -1.0))
     top_s, top_i = torch.topk(key, L, sorted=True)           # descending score, candidates first
     m = valid.sum().to(torch.int32).view(1)
