@@ -343,7 +343,9 @@ int srf_nms_rotated_counted(const float *boxes_xywhr, int n, const int *n_dev, f
 int srf_nms_select(const float *boxes, const float *scores, int n, int C, int D, float score_thr, int L, float *cand,
                    float *top_s, long long *cls, float *bev, int *m, srf_stream_t stream);
 int srf_nms_finish(const float *cand, const float *top_s, const long long *cls, const int *keep, int L, int D,
-                   float *out_boxes, float *out_scores, long long *out_labels, int *kept, srf_stream_t stream);
+                   float *out_boxes, float *out_scores, long long *out_labels, int *kept,
+                   float *packed /* (L, D+2) rows [box, score, label] for one D2H copy, or NULL */,
+                   const int *m /* srf_nms_select's count */, int *counts /* [kept, m] or NULL */, srf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -320,7 +320,8 @@ __global__ __launch_bounds__(SRF_SEL_THREADS) void srf_nms_finish_k(const float 
                                                                   const long long *__restrict__ cls, const int *__restrict__ keep,
                                                                   int L, int D, int P, float *__restrict__ out_boxes,
                                                                   float *__restrict__ out_scores, long long *__restrict__ out_labels,
-                                                                  int *__restrict__ kept_out)
+                                                                  int *__restrict__ kept_out, float *__restrict__ packed,
+                                                                  const int *__restrict__ m_in, int *__restrict__ counts)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sel_lds[];
     float *key = reinterpret_cast<float *>(sel_lds);
@@ -348,6 +349,10 @@ __global__ __launch_bounds__(SRF_SEL_THREADS) void srf_nms_finish_k(const float 
         int c = 0;
         for (int w = 0; w < SRF_SEL_THREADS / 64; ++w) c += s_cnt[w];
         *kept_out = c;
+        if (counts) {
+            counts[0] = c;
+            counts[1] = *m_in;
+        }
     }
     srf_sel_sort(key, idx, P, false);
     for (int j = tid; j < L; j += SRF_SEL_THREADS) {
@@ -355,6 +360,12 @@ __global__ __launch_bounds__(SRF_SEL_THREADS) void srf_nms_finish_k(const float 
         for (int c = 0; c < D; ++c) out_boxes[(size_t)j * D + c] = cand[(size_t)src * D + c];
         out_scores[j] = top_s[src];
         out_labels[j] = cls[src];
+        if (packed) {
+            float *row = packed + (size_t)j * (D + 2);
+            for (int c = 0; c < D; ++c) row[c] = cand[(size_t)src * D + c];
+            row[D] = top_s[src];
+            row[D + 1] = (float)cls[src];
+        }
     }
 }
 
@@ -387,14 +398,16 @@ extern "C" int srf_nms_select(const float *boxes, const float *scores, int n, in
 }
 
 extern "C" int srf_nms_finish(const float *cand, const float *top_s, const long long *cls, const int *keep, int L, int D,
-                              float *out_boxes, float *out_scores, long long *out_labels, int *kept_out, srf_stream_t stream)
+                              float *out_boxes, float *out_scores, long long *out_labels, int *kept_out, float *packed,
+                              const int *m, int *counts, srf_stream_t stream)
 {
+    if (counts && !m) return SRF_EINVAL;
     if (L <= 0 || D <= 0) return SRF_EINVAL;
     if (L > 4096) return SRF_EUNSUPPORTED;  // the rotated NMS in between takes up to 4096 boxes
     if (!cand || !top_s || !cls || !keep || !out_boxes || !out_scores || !out_labels || !kept_out) return SRF_EINVAL;
     const int P = srf_sel_pow2(L);
     hipLaunchKernelGGL(srf_nms_finish_k, dim3(1), dim3(SRF_SEL_THREADS), (size_t)P * 8, (hipStream_t)stream, cand, top_s, cls, keep, L, D, P,
-                       out_boxes, out_scores, out_labels, kept_out);
+                       out_boxes, out_scores, out_labels, kept_out, packed, m, counts);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

@@ -532,15 +532,20 @@ def nms_select(boxes, scores, score_thr, capacity):
     return cand, top_s, cls, bev, m
 
 
-def nms_finish(cand, top_s, cls, keep):
+def nms_finish(cand, top_s, cls, keep, m=None):
     """keep flags of the NMS over nms_select's candidates -> (boxes (L, D), scores (L,), labels (L,) int64, kept (1,) int32):
-    survivors first, class-major, descending score inside a class."""
+    survivors first, class-major, descending score inside a class.  With m (nms_select's count) also the packed form of the
+    same rows, (L, D+2) [box, score, label], and counts (2,) int32 [kept, m]: one D2H copy per frame."""
     L, D = cand.shape
     dev = cand.device
     ob, os_, ol, kept = (_empty((L, D), torch.float32, dev), _empty((L,), torch.float32, dev), _empty((L,), torch.int64, dev),
                          _empty((1,), torch.int32, dev))
+    packed = _empty((L, D + 2), torch.float32, dev) if m is not None else None
+    counts = _empty((2,), torch.int32, dev) if m is not None else None
     check(_lib.lib().srf_nms_finish(_ptr(cand), _ptr(top_s), _ptr(cls), _ptr(_dev(keep, "keep", torch.int32)), L, D, _ptr(ob),
-                                    _ptr(os_), _ptr(ol), _ptr(kept), _stream()), "nms_finish")
+                                    _ptr(os_), _ptr(ol), _ptr(kept), _ptr(packed), _ptr(m), _ptr(counts), _stream()), "nms_finish")
+    if m is not None:
+        return ob, os_, ol, kept, packed, counts
     return ob, os_, ol, kept
 
 

@@ -606,9 +606,11 @@ class SRFDetHead(BaseModule):
         cfg = self.test_cfg
         packed, counts = [], []
         for i in range(scores.shape[0]):
-            b, s, l, kept, cand = box3d_multiclass_nms_static(boxes[i], scores[i], cfg["score_thr"], cfg["nms_thr"])
-            packed.append(torch.cat([b, s.unsqueeze(1), l.to(b.dtype).unsqueeze(1)], dim=1))
-            counts.append(torch.cat([kept, cand]))
+            p, c = box3d_multiclass_nms_static(boxes[i], scores[i], cfg["score_thr"], cfg["nms_thr"], want_packed=True)
+            packed.append(p)
+            counts.append(c)
+        if len(packed) == 1:
+            return packed[0].unsqueeze(0), counts[0].unsqueeze(0)
         return torch.stack(packed), torch.stack(counts)
 
     def results_from_static(self, packed, counts, img_metas):

@@ -40,7 +40,7 @@ def box3d_multiclass_nms(boxes, scores, score_thr, max_num, nms_thr):
 STATIC_CANDIDATES = 2048  # capacity of the fixed-shape NMS (the kernel takes up to 4096)
 
 
-def box3d_multiclass_nms_static(boxes, scores, score_thr, nms_thr, capacity=STATIC_CANDIDATES):
+def box3d_multiclass_nms_static(boxes, scores, score_thr, nms_thr, capacity=STATIC_CANDIDATES, want_packed=False):
     """The same selection with FIXED shapes and no host read-back, so that it can live inside a hipGraph.
 
     boxes (n, D), scores (n, C) -> (out_boxes (L, D), out_scores (L,), out_labels (L,), kept, candidates) with
@@ -52,10 +52,16 @@ def box3d_multiclass_nms_static(boxes, scores, score_thr, nms_thr, capacity=STAT
     if 0 < n * C <= 16384 and L <= 4096 and boxes.shape[1] >= 7:
         # two single-workgroup launches around the NMS (LDS bitonic sorts) instead of the ~25 small torch launches below
         cand, top_s, ci, bev, m = ops.nms_select(boxes, scores, score_thr, capacity)
-        keep = ops.nms_rotated_counted(bev, torch.clamp(m, max=L), nms_thr)
-        out_b, out_s, out_l, kept = ops.nms_finish(cand, top_s, ci, keep)
+        keep = ops.nms_rotated_counted(bev, m, nms_thr)  # the kernels take min(*m, L) themselves
+        out_b, out_s, out_l, kept, packed, counts = ops.nms_finish(cand, top_s, ci, keep, m)
+        if want_packed:
+            return packed, counts
         return out_b, out_s, out_l, kept, m
-    return _static_torch(boxes, scores, score_thr, nms_thr, L)
+    out = _static_torch(boxes, scores, score_thr, nms_thr, L)
+    if want_packed:  # (L, D+2) rows [box, score, label] and [kept, candidates]: what select_static ships to the host
+        b, s_, l, kept, m = out
+        return torch.cat([b, s_.unsqueeze(1), l.to(b.dtype).unsqueeze(1)], dim=1), torch.cat([kept, m])
+    return out
 
 
 def _static_torch(boxes, scores, score_thr, nms_thr, L):
