@@ -19,7 +19,8 @@ def _ln(n, dev, g):
 
 @pytest.mark.parametrize("M,K,N", [(200, 128, 384), (200, 128, 8192), (200, 6272, 128), (200, 128, 512), (200, 512, 128),
                                    (200, 128, 10), (900, 128, 128), (9800, 256, 128), (37, 128, 128), (100, 256, 256),
-                                   (100, 12544, 256)])
+                                   (100, 12544, 256),
+                                   (1, 532, 1024), (1, 1024, 800), (2, 1060, 3600), (8, 132, 64), (5, 4, 3)])   # M <= 8: the GEMV path
 def test_linear_variants(dev, M, K, N):
     g = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K, generator=g).to(dev)
