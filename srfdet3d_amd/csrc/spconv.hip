@@ -284,7 +284,18 @@ __global__ __launch_bounds__(256) void srf_spconv_mfma32_k(const float *__restri
 // bit-identical to srf_spconv_fwd and to the oracle.
 // =====================================================================================================================
 // direct (LDS-free B operand) layout of the COUT = 128 kernel, see srf_spconv_direct_k below
-static bool srf_direct_layout(int Cin, int Cout) { return Cout == 128 && (Cin == 64 || Cin == 128); }
+static bool srf_direct64_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("SRF_SPCONV_PACKED64");  // developer switch: the LDS-staged kernel for 64 -> 64, for A/B timing
+        return !(e && e[0] == '1');
+    }();
+    return on;
+}
+static bool srf_direct_layout(int Cin, int Cout)
+{
+    return (Cout == 128 && (Cin == 64 || Cin == 128)) || (Cout == 64 && Cin == 64 && srf_direct64_enabled());
+}
 // compacted-offset layout of the same shapes (srf_spconv_gs_k below), the default
 static bool srf_gs_layout(int Cin, int Cout);
 __global__ void srf_pack_weights_gs_k(const float *__restrict__ W, int K, int Cin, int Cout, int nchunk, float *__restrict__ P);
@@ -295,8 +306,11 @@ __global__ __launch_bounds__(256) void srf_pack_weights_direct_k(const float *__
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)K * nchunk * Cout * 32;
     if (t >= total) return;
-    const int i = (int)(t & 3), lane = (int)((t >> 2) & 63), g = (int)((t >> 8) & 3), wc = (int)((t >> 10) & 3);
-    const long long rest = t >> 12;
+    const int nwc = Cout / 32;  // 32-column slices: 4 (COUT = 128) or 2 (COUT = 64)
+    const int i = (int)(t & 3), lane = (int)((t >> 2) & 63), g = (int)((t >> 8) & 3);
+    long long rest = t >> 10;
+    const int wc = (int)(rest % nwc);
+    rest /= nwc;
     const int chunk = (int)(rest % nchunk), k = (int)(rest / nchunk);
     const int col = wc * 32 + (lane & 31);
     const int c = chunk * 32 + 2 * (4 * g + i) + (lane >> 5);
@@ -525,12 +539,12 @@ __global__ __launch_bounds__(256) void srf_spconv_packed_k(const float *__restri
 // other kernel here (offset ascending, channel ascending): bit-identical results.
 //   direct layout: Wd[k][chunk][wc = col/32][g][lane][i] = W[k][chunk*32 + 2*(4g+i) + (lane>>5)][wc*32 + (lane&31)]
 // =====================================================================================================================
-template <int NCH>
+template <int NCH, int NWC = 4>
 __device__ __forceinline__ void srf_dir_load_b(f32x4 (&b)[4], const float *__restrict__ Wd, int k, int chunk, int wc, int lane)
 {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-        b[g] = *reinterpret_cast<const f32x4 *>(Wd + (((((size_t)k * NCH + chunk) * 4 + wc) * 4 + g) * 64 + lane) * 4);
+        b[g] = *reinterpret_cast<const f32x4 *>(Wd + (((((size_t)k * NCH + chunk) * NWC + wc) * 4 + g) * 64 + lane) * 4);
 }
 
 template <int TM, int NCH, int NA>
@@ -679,6 +693,97 @@ __global__ __launch_bounds__(256) void srf_spconv_direct_k(const float *__restri
                 out[(size_t)row * COUT + col] = v;
             }
         }
+}
+
+// COUT = 64, Cin = 64 with the same LDS-free B operand: 64-row tiles, waves = 2 row halves x 2 column halves, each a
+// 32 x 32 accumulator.  Against srf_spconv_packed_k<64, 64, 2, 2> (weight slab through LDS, a barrier per 32-channel chunk =
+// per 16 MFMAs) there is one barrier per kernel offset (32 MFMAs per wave) and half the LDS traffic.
+template <int NCH>
+__global__ __launch_bounds__(256) void srf_spconv_direct64_k(const float *__restrict__ in, const float *__restrict__ Wd, int K,
+                                                           const int *__restrict__ nbr, int nbr_stride, int A_out,
+                                                           const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                           const float *__restrict__ residual, int relu,
+                                                           float *__restrict__ out, const int *__restrict__ rows_dev)
+{
+    constexpr int COUT = 64, TM = 64, NA = TM * 8 * NCH / 256;
+    static_assert(NCH == 2, "register slots below alternate over two chunks");
+    __shared__ int s_nbr[SRF_KMAX * TM];
+    __shared__ int s_any[SRF_KMAX];
+    __shared__ int s_klist[SRF_KMAX + 1];
+    __shared__ __attribute__((aligned(16))) float s_a[2][NCH * TM * 32];
+
+    if (rows_dev) {  // static-shape levels: rows >= *rows_dev are padding; their tiles do nothing
+        const int live = *rows_dev;
+        A_out = A_out < live ? A_out : live;
+    }
+    const int n_tiles = (A_out + TM - 1) / TM;
+    if ((int)blockIdx.x >= n_tiles) return;
+    const int row0 = srf_xcd_tile(blockIdx.x, n_tiles) * TM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave & 1, wr = wave >> 1;
+    srf_load_nbr_tile<TM>(nbr, nbr_stride, K, row0, A_out, s_nbr, s_any);
+    if (tid < 64) {
+        const bool used = tid < K && s_any[tid];
+        const unsigned long long m = __ballot(used);
+        if (used) s_klist[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+        if (tid == 0) s_klist[SRF_KMAX] = __popcll(m);
+    }
+    __syncthreads();
+    const int ntap = s_klist[SRF_KMAX];
+
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    const int kh = lane >> 5;
+    f32x4 ra[NA], bq[2][4];
+    unsigned okmask = 0;
+    if (ntap > 0) {
+        const int k0 = s_klist[0];
+        srf_dir_load_b<NCH, 2>(bq[0], Wd, k0, 0, wc, lane);
+        srf_dir_gather<TM, NCH, NA>(in, s_nbr + k0 * TM, ra, okmask);
+        srf_dir_store<TM, NCH, NA>(s_a[0], ra, okmask);
+    }
+    __syncthreads();
+    const int arow = wr * 32 + (lane & 31);
+    const int a_swz = (arow >> 1) & 7;
+    for (int tk = 0; tk < ntap; ++tk) {
+        const int buf = tk & 1;
+        const int kc = s_klist[tk];
+        const bool more = tk + 1 < ntap;
+        const int kn = more ? s_klist[tk + 1] : kc;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            // B fragments of the next chunk (of this offset, or the first of the next one) into the other register slot
+            if (c + 1 < NCH) srf_dir_load_b<NCH, 2>(bq[(c + 1) & 1], Wd, kc, c + 1, wc, lane);
+            else srf_dir_load_b<NCH, 2>(bq[(c + 1) & 1], Wd, kn, 0, wc, lane);  // harmless re-read on the last offset
+            // the gather of the next offset goes out after the B load this chunk still waits for (vmcnt retires in order)
+            if (c == NCH - 2 && more) srf_dir_gather<TM, NCH, NA>(in, s_nbr + kn * TM, ra, okmask);
+            f32x4 af[4];
+            const float *pa = s_a[buf] + c * (TM * 32) + arow * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) af[g] = *reinterpret_cast<const f32x4 *>(pa + (((kh << 2) + g) ^ a_swz) * 4);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j >> 2][j & 3], bq[c & 1][j >> 2][j & 3], acc, 0, 0, 0);
+        }
+        if (more) srf_dir_store<TM, NCH, NA>(s_a[buf ^ 1], ra, okmask);
+        __syncthreads();
+    }
+
+    const int col = wc * 32 + (lane & 31);
+    const float al = alpha ? alpha[col] : 1.0f;
+    const float be = alpha ? beta[col] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int row = row0 + wr * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+        if (row < A_out) {
+            float v = acc[j];
+            if (alpha) v = __fmaf_rn(v, al, be);
+            if (residual) v = __fadd_rn(v, residual[(size_t)row * COUT + col]);
+            if (relu) v = v > 0.0f ? v : 0.0f;
+            out[(size_t)row * COUT + col] = v;
+        }
+    }
 }
 
 // =====================================================================================================================
@@ -1154,6 +1259,11 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
                            0, st, SRF_ARGS);
         break;
     case 64:
+        if (srf_direct_layout(Cin, Cout)) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_direct64_k<2>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0, st, in, W_packed,
+                               K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev);
+            break;
+        }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_packed_k<64, 64, 2, 2>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0,
                            st, SRF_ARGS);
         break;
