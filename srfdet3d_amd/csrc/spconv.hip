@@ -1497,15 +1497,39 @@ extern "C" int srf_spconv_fwd(const float *in, int A_in, int Cin, const float *W
 // K6 densify: (A, C) rows at (b, z, y, x) -> (B, C, D, H, W).  One thread per (row, channel): the read is coalesced,
 // the write scatters one dword per channel plane.
 // ---------------------------------------------------------------------------------------------------------------------
+// 64 rows x 64 channels per workgroup through LDS: the features are read along the channels (coalesced), the dense
+// (B, C, D, H, W) tensor is written with the ROW index fastest -- consecutive rows of the sorted active set are neighbours
+// in x (and z), so a channel's 64 values land in a few cache lines instead of one line per value (3.1 M scattered 4-byte
+// stores took 31 us for 12 MB).
 __global__ __launch_bounds__(256) void srf_densify_k(const float *__restrict__ feats, const int4 *__restrict__ indices,
                                                    int A, int C, int D, int H, int W, float *__restrict__ out)
 {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long long)A * C) return;
-    const int a = (int)(t / C), c = (int)(t % C);
-    const int4 p = indices[a];
-    if (p.x < 0) return;  // padding row of a capacity-sized active set
-    out[((((size_t)p.x * C + c) * D + p.y) * H + p.z) * W + p.w] = feats[t];
+    __shared__ float s_f[64][65];
+    __shared__ long long s_off[64];
+    const int row0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
+    const size_t plane = (size_t)D * H * W;
+    if (tid < 64) {
+        const int a = row0 + tid;
+        long long off = -1;
+        if (a < A) {
+            const int4 p = indices[a];
+            if (p.x >= 0) off = (long long)((size_t)p.x * C * plane + ((size_t)p.y * H + p.z) * W + p.w);  // padding rows: b < 0
+        }
+        s_off[tid] = off;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + i * 256, r = e >> 6, c = e & 63;
+        const int a = row0 + r;
+        s_f[r][c] = (a < A && c0 + c < C) ? feats[(size_t)a * C + c0 + c] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + i * 256, c = e >> 6, r = e & 63;
+        const long long off = s_off[r];
+        if (off >= 0 && c0 + c < C) out[(size_t)off + (size_t)(c0 + c) * plane] = s_f[r][c];
+    }
 }
 
 extern "C" int srf_densify(const float *feats, const int *indices, int A, int C, int B, int D, int H, int W, float *out,
@@ -1516,7 +1540,7 @@ extern "C" int srf_densify(const float *feats, const int *indices, int A, int C,
     if (zero_fill) SRF_HIP_TRY(srf_fill_bytes(out, 0, sizeof(float) * (size_t)B * C * D * H * W, st));
     if (A == 0) return SRF_OK;
     if (!feats || !indices) return SRF_EINVAL;
-    hipLaunchKernelGGL(srf_densify_k, dim3(srf_ceil_div((long long)A * C, 256)), dim3(256), 0, st, feats,
+    hipLaunchKernelGGL(srf_densify_k, dim3(srf_ceil_div(A, 64), srf_ceil_div(C, 64)), dim3(256), 0, st, feats,
                        (const int4 *)indices, A, C, D, H, W, out);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
