@@ -63,7 +63,7 @@ def main():
                          "for the LiDAR-only workloads; off for LC, where it is worth 1.2 %% (12.63 instead of 12.48 frames/s) and "
                          "would take the per-launch HIP events of `roofline` out of the timed region")
     ap.add_argument("--img-overlap", action="store_true",
-                    help="LC only: replay the image-branch graph on a side stream beside the LiDAR half (about 2.5 %% "
+                    help="LC only: replay the image-branch graph on a side stream beside the LiDAR half (about 3.8 %% "
                          "more frames/s, but the sparse-conv kernels then share the chip and their per-launch times "
                          "no longer describe the kernel; off by default so that `roofline` stays a kernel figure)")
     ap.add_argument("--img-dtype", default="fp32", choices=["fp32", "fp16", "bf16"],
