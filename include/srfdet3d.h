@@ -289,6 +289,13 @@ int srf_channel_affine(const float *x, int N, int C, int HW, long long x_batch_s
                        const float *shift, int per_sample, const float *residual, int relu, float *y,
                        long long y_batch_stride, srf_stream_t stream);
 
+/* srf_upsample_add: out = lateral + nearest_upsample(top), the top-down step of mmdet's FPN (`laterals[i-1] +=
+ * F.interpolate(laterals[i], size=laterals[i-1].shape[2:], mode='nearest')`; the necks of configs/nus/srfdet_voxel_nusc_LC.py)
+ * in one pass.  lateral, out: (NC, H, W) f32 contiguous (out == lateral allowed), top: (NC, Ht, Wt); source index
+ * floor(dst * Ht / H) as F.interpolate.  W % 4 == 0, else SRF_EUNSUPPORTED. */
+int srf_upsample_add(const float *lateral, const float *top, int NC, int H, int W, int Ht, int Wt, float *out,
+                     srf_stream_t stream);
+
 /* srf_conv1x1: 1x1 convolution over the channel concatenation of n_src (<= 8) NCHW f32 tensors of the same N and
  * H*W, followed by y = y * scale[co] + shift[co] (scale may be NULL: bias only; both NULL: none) and an optional ReLU --
  * the `concat` layer of VoVNet's OSA blocks (vovnet.py:182-216: torch.cat + conv1x1 + BN + ReLU) without the

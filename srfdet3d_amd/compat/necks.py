@@ -3,6 +3,7 @@ SURVEY.md Appendix B.6): laterals 1x1, top-down nearest upsample-add, 3x3 outs, 
 import torch.nn.functional as F
 from torch import nn
 
+from .. import ops
 from .cnn import BaseModule, ConvModule
 from .registry import NECKS
 
@@ -45,6 +46,9 @@ class FPN(BaseModule):
         for i in range(n - 1, 0, -1):
             if "scale_factor" in self.upsample_cfg:
                 lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], **self.upsample_cfg)
+            elif self.upsample_cfg.get("mode", "nearest") == "nearest" and len(self.upsample_cfg) == 1 and \
+                    ops.upsample_add_supported(lat[i - 1], lat[i]):
+                lat[i - 1] = ops.upsample_add(lat[i - 1], lat[i])  # one pass instead of upsample-to-temporary + add
             else:
                 lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], **self.upsample_cfg)
         outs = [self.fpn_convs[i](lat[i]) for i in range(n)]

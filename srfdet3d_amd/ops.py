@@ -616,6 +616,23 @@ def apply_deltas(deltas, boxes, weights6, pc_range, scale_clamp):
     return out
 
 
+def upsample_add_supported(lateral, top):
+    return (lateral.is_cuda and lateral.dtype == torch.float32 and top.dtype == torch.float32 and lateral.dim() == 4
+            and lateral.shape[:2] == top.shape[:2] and lateral.shape[3] % 4 == 0 and lateral.is_contiguous() and top.is_contiguous()
+            and not (torch.is_grad_enabled() and (lateral.requires_grad or top.requires_grad)))
+
+
+def upsample_add(lateral, top):
+    """lateral + F.interpolate(top, size=lateral.shape[2:], mode='nearest') in one pass (the FPN top-down step)."""
+    lateral = _dev(lateral, "lateral", torch.float32)
+    top = _dev(top, "top", torch.float32)
+    N, C, H, W = lateral.shape
+    out = _empty((N, C, H, W), torch.float32, lateral.device)
+    check(_lib.lib().srf_upsample_add(_ptr(lateral), _ptr(top), N * C, H, W, top.shape[2], top.shape[3], _ptr(out), _stream()),
+          "upsample_add")
+    return out
+
+
 def channel_affine(x, scale, shift, relu, out=None, residual=None):
     """y = x * scale + shift (+ residual) (+ ReLU) on a contiguous NCHW tensor; scale / shift hold C values (per
     channel) or N*C values (per sample and channel); shift may be None.  `out` may be x itself or a channel slice of a

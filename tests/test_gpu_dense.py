@@ -105,3 +105,16 @@ def test_conv1x1_falls_back_on_unsupported_shapes(dev):
         want = bn(conv(torch.cat(xs, 1))).relu()
         got = dense.conv1x1_cat_bn_act(conv, bn, True, xs)
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,H,W,Ht,Wt", [(6, 256, 116, 200, 58, 100), (1, 128, 184, 184, 92, 92), (2, 8, 23, 24, 12, 12), (1, 4, 15, 20, 8, 10)])
+def test_upsample_add_equals_interpolate_plus_add(N, C, H, W, Ht, Wt):
+    """the FPN top-down step in one pass: bit-identical to lateral + F.interpolate(top, size=..., mode='nearest')"""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H * W)
+    lat = torch.randn(N, C, H, W, generator=g).to(dev)
+    top = torch.randn(N, C, Ht, Wt, generator=g).to(dev)
+    assert ops.upsample_add_supported(lat, top)
+    want = lat + torch.nn.functional.interpolate(top, size=(H, W), mode="nearest")
+    assert torch.equal(ops.upsample_add(lat, top), want)
