@@ -296,6 +296,11 @@ int srf_channel_affine(const float *x, int N, int C, int HW, long long x_batch_s
 int srf_upsample_add(const float *lateral, const float *top, int NC, int H, int W, int Ht, int Wt, float *out,
                      srf_stream_t stream);
 
+/* srf_maxpool3s2_ceil: nn.MaxPool2d(kernel_size=3, stride=2, ceil_mode=True) on (NC, H, W) f32 -> (NC, Ho, Wo),
+ * Ho = ceil((H - 3) / 2) + 1 (the last window must start inside the input), likewise Wo: the stage pooling of the
+ * VoVNet image backbone (mmdet3d_plugin/models/backbones/vovnet.py, `_make_layer` of every stage but the first). */
+int srf_maxpool3s2_ceil(const float *x, int NC, int H, int W, float *y, srf_stream_t stream);
+
 /* srf_conv1x1: 1x1 convolution over the channel concatenation of n_src (<= 8) NCHW f32 tensors of the same N and
  * H*W, followed by y = y * scale[co] + shift[co] (scale may be NULL: bias only; both NULL: none) and an optional ReLU --
  * the `concat` layer of VoVNet's OSA blocks (vovnet.py:182-216: torch.cat + conv1x1 + BN + ReLU) without the

@@ -331,3 +331,66 @@ extern "C" int srf_upsample_add(const float *lateral, const float *top, int NC, 
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }
+
+// =====================================================================================================================
+// MaxPool2d(kernel 3, stride 2, ceil_mode=True, no padding) on NCHW f32: the stage pooling of VoVNet (vovnet.py:91 of this
+// package = the reference's vovnet.py stage builder).  Windows that reach past the bottom / right edge are clipped (ceil
+// mode).  One thread = 4 consecutive outputs of a row: nine input columns of three rows, read as two float4 + one float per
+// row.  torch's max_pool2d_with_indices reads at 2.4 TB/s here (it also tracks indices); max is exact, so results are equal.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void srf_maxpool3s2_k(const float *__restrict__ x, int NC, int H, int W, int Ho, int Wo,
+                                                      float *__restrict__ y)
+{
+    const int wq = (Wo + 3) >> 2;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)NC * Ho * wq;
+    if (t >= total) return;
+    const int xq = (int)(t % wq);
+    const long long rest = t / wq;
+    const int yo = (int)(rest % Ho);
+    const long long nc = rest / Ho;
+    const int xi0 = xq * 8, yi0 = yo * 2;
+    const float NEG = -__builtin_inff();
+    float m[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) m[j] = NEG;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yi = yi0 + dy;
+        if (yi < H) {
+            const float *row = x + ((size_t)nc * H + yi) * W + xi0;
+            float v[9];
+            if (xi0 + 8 < W && (W & 3) == 0) {  // the common case: two aligned float4 and one more value
+                const float4 a = *reinterpret_cast<const float4 *>(row), b = *reinterpret_cast<const float4 *>(row + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                v[8] = row[8];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) v[j] = xi0 + j < W ? row[j] : NEG;
+            }
+#pragma unroll
+            for (int j = 0; j < 9; ++j) m[j] = fmaxf(m[j], v[j]);
+        }
+    }
+    float *o = y + ((size_t)nc * Ho + yo) * Wo + xq * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (xq * 4 + j < Wo) o[j] = fmaxf(fmaxf(m[2 * j], m[2 * j + 1]), m[2 * j + 2]);
+}
+
+extern "C" int srf_maxpool3s2_ceil(const float *x, int NC, int H, int W, float *y, srf_stream_t stream)
+{
+    if (NC < 0 || H < 1 || W < 1) return SRF_EINVAL;
+    if (NC == 0) return SRF_OK;
+    if (!x || !y) return SRF_EINVAL;
+    // ceil_mode output size of torch: ceil((H - 3) / 2) + 1, and the last window must start inside the input
+    int Ho = (H - 3 + 1) / 2 + 1, Wo = (W - 3 + 1) / 2 + 1;
+    if (H < 3) Ho = 1;
+    if (W < 3) Wo = 1;
+    if ((Ho - 1) * 2 >= H) --Ho;
+    if ((Wo - 1) * 2 >= W) --Wo;
+    const long long total = (long long)NC * Ho * ((Wo + 3) >> 2);
+    hipLaunchKernelGGL(srf_maxpool3s2_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, NC, H, W, Ho, Wo, y);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}

@@ -633,6 +633,19 @@ def upsample_add(lateral, top):
     return out
 
 
+def maxpool3s2_ceil(x):
+    """nn.MaxPool2d(3, stride=2, ceil_mode=True) on a contiguous NCHW f32 tensor."""
+    x = _dev(x, "x", torch.float32).contiguous()
+    N, C, H, W = x.shape
+
+    def osz(n):
+        o = (n - 3 + 1) // 2 + 1 if n >= 3 else 1
+        return o - 1 if (o - 1) * 2 >= n else o
+    y = _empty((N, C, osz(H), osz(W)), torch.float32, x.device)
+    check(_lib.lib().srf_maxpool3s2_ceil(_ptr(x), N * C, H, W, _ptr(y), _stream()), "maxpool3s2_ceil")
+    return y
+
+
 def channel_affine(x, scale, shift, relu, out=None, residual=None):
     """y = x * scale + shift (+ residual) (+ ReLU) on a contiguous NCHW tensor; scale / shift hold C values (per
     channel) or N*C values (per sample and channel); shift may be None.  `out` may be x itself or a channel slice of a

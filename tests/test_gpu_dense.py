@@ -118,3 +118,17 @@ def test_upsample_add_equals_interpolate_plus_add(N, C, H, W, Ht, Wt):
     assert ops.upsample_add_supported(lat, top)
     want = lat + torch.nn.functional.interpolate(top, size=(H, W), mode="nearest")
     assert torch.equal(ops.upsample_add(lat, top), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,H,W", [(6, 256, 232, 400), (2, 16, 116, 200), (1, 8, 58, 100), (1, 3, 29, 50), (2, 5, 7, 9), (1, 2, 3, 3),
+                                     (1, 2, 4, 6), (1, 1, 2, 2), (1, 4, 33, 18)])
+def test_maxpool3s2_ceil_equals_torch(N, C, H, W):
+    """VoVNet's stage pooling: equal to nn.MaxPool2d(3, stride=2, ceil_mode=True), clipped windows included"""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H * 131 + W)
+    x = torch.randn(N, C, H, W, generator=g).to(dev)
+    want = torch.nn.functional.max_pool2d(x, 3, stride=2, ceil_mode=True)
+    got = ops.maxpool3s2_ceil(x)
+    assert got.shape == want.shape
+    assert torch.equal(got, want)
