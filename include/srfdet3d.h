@@ -296,6 +296,11 @@ int srf_channel_affine(const float *x, int N, int C, int HW, long long x_batch_s
 int srf_upsample_add(const float *lateral, const float *top, int NC, int H, int W, int Ht, int Wt, float *out,
                      srf_stream_t stream);
 
+/* srf_ese_gate: gate[n][c] = relu6(sum_k W[c][k] * mean[n][k] + bias[c] + 3) / 6 -- the channel gate of VoVNet's eSE
+ * module (mmdet3d_plugin/models/backbones/vovnet.py, eSEModule: Hsigmoid(fc(avg_pool(x)))) on the (N, C) global averages;
+ * W: (C, C) row-major = the 1x1 conv weight, bias (C) or NULL.  N <= 8, C % 4 == 0. */
+int srf_ese_gate(const float *mean, int N, int C, const float *W, const float *bias, float *gate, srf_stream_t stream);
+
 /* srf_maxpool3s2_ceil: nn.MaxPool2d(kernel_size=3, stride=2, ceil_mode=True) on (NC, H, W) f32 -> (NC, Ho, Wo),
  * Ho = ceil((H - 3) / 2) + 1 (the last window must start inside the input), likewise Wo: the stage pooling of the
  * VoVNet image backbone (mmdet3d_plugin/models/backbones/vovnet.py, `_make_layer` of every stage but the first). */

@@ -404,11 +404,29 @@ __global__ __launch_bounds__(256) void srf_linear_gemv_k(const float *__restrict
             for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
             if (lane == 0) {
                 v += bias ? bias[n] : 0.f;
-                if (relu) v = v > 0.f ? v : 0.f;
+                if (relu == 1) v = v > 0.f ? v : 0.f;
+                else if (relu == 2) {  // hard sigmoid as torch spells it in the eSE gate: relu6(v + 3) / 6
+                    v = __fadd_rn(v, 3.0f);
+                    v = v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
+                    v = __fdiv_rn(v, 6.0f);
+                }
                 Y[(size_t)m * ldy + n] = v;
             }
         }
     }
+}
+
+// eSE channel gate of the VoVNet image backbone (vovnet.py eSEModule: hsigmoid(fc(global average))): the 1x1 convolution on
+// a (N, C, 1, 1) tensor is a GEMV per sample; with the bias and the hard sigmoid in its epilogue one launch replaces five
+// (MIOpen's igemm, bias add, + 3, clamp, / 6), 16 times per frame.
+extern "C" int srf_ese_gate(const float *mean, int N, int C, const float *W, const float *bias, float *gate, srf_stream_t stream)
+{
+    if (N < 0 || N > 8 || C <= 0 || (C & 3)) return N > 8 ? SRF_EUNSUPPORTED : SRF_EINVAL;
+    if (N == 0) return SRF_OK;
+    if (!mean || !W || !gate) return SRF_EINVAL;
+    hipLaunchKernelGGL(srf_linear_gemv_k, dim3(srf_ceil_div(C, 4)), dim3(256), 0, (hipStream_t)stream, mean, N, C, C, W, C, C, bias, 2, gate, C);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
 }
 
 extern "C" int srf_linear(const float *X, int M, int K, int ldx, const float *W, int N, int ldw, const float *bias,

@@ -633,6 +633,16 @@ def upsample_add(lateral, top):
     return out
 
 
+def ese_gate(mean, weight, bias):
+    """(N, C) global averages, (C, C[, 1, 1]) fc weight, (C,) bias -> hsigmoid(fc(mean)) (N, C): VoVNet's eSE gate."""
+    mean = _dev(mean, "mean", torch.float32).contiguous()
+    N, C = mean.shape
+    w = _dev(weight, "weight", torch.float32).reshape(C, C).contiguous()
+    gate = _empty((N, C), torch.float32, mean.device)
+    check(_lib.lib().srf_ese_gate(_ptr(mean), N, C, _ptr(w), _ptr(bias), _ptr(gate), _stream()), "ese_gate")
+    return gate
+
+
 def maxpool3s2_ceil(x):
     """nn.MaxPool2d(3, stride=2, ceil_mode=True) on a contiguous NCHW f32 tensor."""
     x = _dev(x, "x", torch.float32).contiguous()

@@ -48,7 +48,11 @@ class eSEModule(nn.Module):
         self.fc = nn.Conv2d(channel, channel, kernel_size=1)
 
     def forward(self, x, identity=None):
-        gate = F.relu6(self.fc(x.mean(dim=(2, 3), keepdim=True)) + 3.0) / 6.0
+        if fusable(x) and x.shape[0] <= 8 and x.shape[1] % 4 == 0:
+            # the 1x1 conv on the pooled (N, C, 1, 1) tensor is a GEMV: fc + bias + hard sigmoid in one launch
+            gate = ops.ese_gate(x.mean(dim=(2, 3)), self.fc.weight, self.fc.bias)
+        else:
+            gate = F.relu6(self.fc(x.mean(dim=(2, 3), keepdim=True)) + 3.0) / 6.0
         if (fusable(x) and x.is_contiguous() and (identity is None or identity.is_contiguous())
                 and x.shape[0] * x.shape[1] <= 65535):
             # gate multiply (+ the OSA identity add) in one in-place pass
