@@ -296,6 +296,11 @@ int srf_channel_affine(const float *x, int N, int C, int HW, long long x_batch_s
 int srf_upsample_add(const float *lateral, const float *top, int NC, int H, int W, int Ht, int Wt, float *out,
                      srf_stream_t stream);
 
+/* srf_nchw_to_nhwc: y[n][p][c] = x[n][c][p] (p = h * W + w): the channels-last copy of a feature level that
+ * srf_roi_extract gathers from (the reference feeds NCHW levels to mmcv RoIAlign, srfdet_head.py:1685 / :2548; this
+ * library's gather wants one contiguous C-run per tap).  HW % 4 == 0, else SRF_EUNSUPPORTED. */
+int srf_nchw_to_nhwc(const float *x, int N, int C, int HW, float *y, srf_stream_t stream);
+
 /* srf_ese_gate: gate[n][c] = relu6(sum_k W[c][k] * mean[n][k] + bias[c] + 3) / 6 -- the channel gate of VoVNet's eSE
  * module (mmdet3d_plugin/models/backbones/vovnet.py, eSEModule: Hsigmoid(fc(avg_pool(x)))) on the (N, C) global averages;
  * W: (C, C) row-major = the 1x1 conv weight, bias (C) or NULL.  N <= 8, C % 4 == 0. */

@@ -46,8 +46,7 @@ def _const(values, like):
 
 
 def _channels_last(feats):
-    return [f if f.is_contiguous(memory_format=torch.channels_last) else f.contiguous(memory_format=torch.channels_last)
-            for f in feats]
+    return [f if f.is_contiguous(memory_format=torch.channels_last) else ops.to_channels_last(f) for f in feats]
 
 
 class DynamicConv(nn.Module):

@@ -151,3 +151,14 @@ def test_ese_gate_matches_torch(N, C):
         # the module itself, fused route against its torch definition
         ref = x * want.view(N, C, 1, 1)
         torch.testing.assert_close(m(x.clone()), ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(6, 128, 232, 400), (1, 128, 184, 184), (2, 40, 23, 24), (1, 3, 2, 2), (3, 33, 5, 8)])
+def test_to_channels_last_equals_torch(shape):
+    dev = torch.device("cuda:0")
+    x = torch.randn(*shape, device=dev)
+    y = ops.to_channels_last(x)
+    want = x.contiguous(memory_format=torch.channels_last)
+    assert y.stride() == want.stride() and torch.equal(y, want)
+    assert ops.to_channels_last(torch.randn(1, 4, 3, 3, device=dev)).is_contiguous(memory_format=torch.channels_last)   # HW % 4 != 0: torch path
