@@ -296,6 +296,13 @@ int srf_channel_affine(const float *x, int N, int C, int HW, long long x_batch_s
 int srf_upsample_add(const float *lateral, const float *top, int NC, int H, int W, int Ht, int Wt, float *out,
                      srf_stream_t stream);
 
+/* srf_dwconv3x3s2: depthwise 3x3 convolution, stride 2, padding 1 (w: (C, 9), no bias) followed by y = y * scale[c] +
+ * shift[c] (eval BatchNorm2d; either may be NULL) and an optional ReLU: the stair of the dynamic proposal generator,
+ * ConvModule(C, C, 3, stride=2, padding=1, groups=C, norm BN2d) built at srfdet_head.py:265-320 and run at :525-536.
+ * x: (N, C, H, W) f32 contiguous -> y: (N, C, (H - 1) / 2 + 1, (W - 1) / 2 + 1). */
+int srf_dwconv3x3s2(const float *x, int N, int C, int H, int W, const float *w, const float *scale, const float *shift,
+                    int relu, float *y, srf_stream_t stream);
+
 /* srf_nchw_to_nhwc: y[n][p][c] = x[n][c][p] (p = h * W + w): the channels-last copy of a feature level that
  * srf_roi_extract gathers from (the reference feeds NCHW levels to mmcv RoIAlign, srfdet_head.py:1685 / :2548; this
  * library's gather wants one contiguous C-run per tap).  HW % 4 == 0, else SRF_EUNSUPPORTED. */

@@ -73,6 +73,7 @@ SIGNATURES = {
     "srf_maxpool3s2_ceil": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "srf_ese_gate": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
     "srf_nchw_to_nhwc": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "srf_dwconv3x3s2": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     "srf_channel_affine": (c_int, [_P, c_int, c_int, c_int, c_longlong, _P, _P, c_int, _P, c_int, _P, c_longlong, _P]),
     "srf_conv1x1_packed_weight_bytes": (c_size_t, [c_int, c_int]),
     "srf_conv1x1_pack_weights": (c_int, [_P, c_int, c_int, _P, _P]),

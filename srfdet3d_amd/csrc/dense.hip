@@ -445,3 +445,79 @@ extern "C" int srf_nchw_to_nhwc(const float *x, int N, int C, int HW, float *y, 
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }
+
+// =====================================================================================================================
+// Depthwise 3x3 convolution, stride 2, padding 1, + eval-mode BatchNorm (+ ReLU): the stair of the proposal generator
+// (srfdet_head.py:265-320 builds them, :525-536 runs them: ConvModule(C, C, 3, stride=2, padding=1, groups=C, BN2d)).
+// MIOpen resolves these to its naive reference kernel (34 ms on the 6 x 128 x 232 x 400 image level) and torch's own
+// depthwise kernel runs at 1.7 TB/s followed by a separate BatchNorm pass; this is a streaming kernel: one thread = 4
+// consecutive outputs of a row from 3 x (1 + two float4) inputs, the nine taps summed in (ky, kx) order, BN and ReLU in
+// registers.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void srf_dwconv3x3s2_k(const float *__restrict__ x, int N, int C, int H, int W, int Ho, int Wo,
+                                                       const float *__restrict__ w, const float *__restrict__ scale,
+                                                       const float *__restrict__ shift, int relu, float *__restrict__ y)
+{
+    const int wq = (Wo + 3) >> 2;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)N * C * Ho * wq;
+    if (t >= total) return;
+    const int xq = (int)(t % wq);
+    long long rest = t / wq;
+    const int yo = (int)(rest % Ho);
+    rest /= Ho;
+    const int c = (int)(rest % C);
+    const long long nc = rest;
+    float k[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) k[j] = w[c * 9 + j];
+    const int xi0 = xq * 8;  // input column of tap kx = 1 of the first output; taps span xi0 - 1 .. xi0 + 7
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yi = yo * 2 - 1 + ky;
+        float v[9];  // v[j] = input column xi0 - 1 + j
+#pragma unroll
+        for (int j = 0; j < 9; ++j) v[j] = 0.f;
+        if (yi >= 0 && yi < H) {
+            const float *row = x + ((size_t)nc * H + yi) * W;
+            if (xi0 > 0) v[0] = row[xi0 - 1];
+            if (xi0 + 7 < W && (W & 3) == 0) {
+                const float4 a = *reinterpret_cast<const float4 *>(row + xi0), b = *reinterpret_cast<const float4 *>(row + xi0 + 4);
+                v[1] = a.x; v[2] = a.y; v[3] = a.z; v[4] = a.w; v[5] = b.x; v[6] = b.y; v[7] = b.z; v[8] = b.w;
+            } else {
+#pragma unroll
+                for (int j = 1; j < 9; ++j) v[j] = xi0 - 1 + j < W ? row[xi0 - 1 + j] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[o] = __fmaf_rn(v[2 * o + kx], k[ky * 3 + kx], acc[o]);
+    }
+    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    float *o = y + ((size_t)nc * Ho + yo) * Wo + xq * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (xq * 4 + j < Wo) {
+            float r = acc[j];
+            if (scale) r = __fmaf_rn(r, sc, sh);
+            else if (shift) r = __fadd_rn(r, sh);
+            if (relu) r = r > 0.f ? r : 0.f;
+            o[j] = r;
+        }
+}
+
+extern "C" int srf_dwconv3x3s2(const float *x, int N, int C, int H, int W, const float *w, const float *scale, const float *shift,
+                               int relu, float *y, srf_stream_t stream)
+{
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0) return SRF_EINVAL;
+    if (N == 0) return SRF_OK;
+    if (!x || !w || !y) return SRF_EINVAL;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;  // floor((H + 2 - 3) / 2) + 1
+    const long long total = (long long)N * C * Ho * ((Wo + 3) >> 2);
+    hipLaunchKernelGGL(srf_dwconv3x3s2_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, N, C, H, W, Ho, Wo, w, scale,
+                       shift, relu, y);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}

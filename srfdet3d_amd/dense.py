@@ -39,7 +39,17 @@ def bn_act_(y, bn, relu):
     return ops.channel_affine(y, scale, shift, relu, out=y)
 
 
+def _is_dw3x3s2(conv, x):
+    return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == conv.in_channels == conv.out_channels and conv.bias is None
+            and x.dim() == 4 and x.is_contiguous())
+
+
 def conv_bn_act(conv, bn, relu, x):
+    if _is_dw3x3s2(conv, x) and _foldable(bn) and fusable(x):
+        # the depthwise stair of the proposal generator: convolution, BatchNorm and ReLU in one streaming kernel
+        scale, shift = _fold_bn2d(bn)
+        return ops.dwconv3x3s2(x, conv.weight, scale, shift, relu)
     y = conv(x)
     if _foldable(bn) and fusable(y) and y.is_contiguous() and y.shape[0] * y.shape[1] <= 65535:  # grid.y of the kernel
         return bn_act_(y, bn, relu)

@@ -633,6 +633,17 @@ def upsample_add(lateral, top):
     return out
 
 
+def dwconv3x3s2(x, weight, scale=None, shift=None, relu=False):
+    """Depthwise 3x3 / stride 2 / padding 1 convolution (weight (C, 1, 3, 3)) + per-channel scale/shift + ReLU."""
+    x = _dev(x, "x", torch.float32).contiguous()
+    N, C, H, W = x.shape
+    w = _dev(weight, "weight", torch.float32).reshape(C, 9).contiguous()
+    y = _empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), torch.float32, x.device)
+    check(_lib.lib().srf_dwconv3x3s2(_ptr(x), N, C, H, W, _ptr(w), _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(y), _stream()),
+          "dwconv3x3s2")
+    return y
+
+
 def to_channels_last(x):
     """x.contiguous(memory_format=torch.channels_last) for a contiguous NCHW f32 GPU tensor with H*W % 4 == 0 (anything
     else goes through torch): same values, same strides, a faster transposing copy."""

@@ -448,7 +448,8 @@ class SRFDetHead(BaseModule):
     def _stair(convs, feats):
         """depthwise stride-2 stair over the pyramid with channel concat (srfdet_head.py:525-536).
         MIOpen resolves these depthwise convs to its naive reference kernel (34 ms on the 6 x 128 x 232 x 400 image
-        level, measured); torch's own depthwise kernel takes 0.2 ms, so MIOpen is bypassed for the stair."""
+        level, measured), so it is kept away from the stair: in inference ConvModule hands them to srf_dwconv3x3s2
+        (conv + BN + ReLU in one streaming kernel), otherwise torch's own depthwise kernel runs (0.2 ms)."""
         with torch.backends.cudnn.flags(enabled=not feats[0].is_cuda):
             x = convs[0](feats[0])
             for lvl in range(1, len(feats)):

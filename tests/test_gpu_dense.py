@@ -162,3 +162,25 @@ def test_to_channels_last_equals_torch(shape):
     want = x.contiguous(memory_format=torch.channels_last)
     assert y.stride() == want.stride() and torch.equal(y, want)
     assert ops.to_channels_last(torch.randn(1, 4, 3, 3, device=dev)).is_contiguous(memory_format=torch.channels_last)   # HW % 4 != 0: torch path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,H,W", [(6, 128, 232, 400), (1, 128, 184, 184), (1, 256, 92, 92), (2, 12, 23, 23), (1, 3, 5, 7), (1, 2, 1, 1),
+                                     (1, 4, 2, 9)])
+def test_dwconv3x3s2_bn_relu_matches_torch(N, C, H, W):
+    """the depthwise stair of the proposal generator (conv 3x3 s2 p1 groups=C + BN(eval) + ReLU) in one kernel"""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(C * 7 + H)
+    conv = nn.Conv2d(C, C, 3, 2, 1, groups=C, bias=False).to(dev)
+    bn = nn.BatchNorm2d(C, eps=1e-3).to(dev).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+        x = torch.randn(N, C, H, W, device=dev)
+        with torch.backends.cudnn.flags(enabled=False):
+            want = torch.relu(bn(conv(x).double().float()))
+            ref64 = torch.relu(torch.nn.functional.batch_norm(torch.nn.functional.conv2d(x.double(), conv.weight.double(), None, 2, 1, 1, C),
+                                                              bn.running_mean.double(), bn.running_var.double(), bn.weight.double(),
+                                                              bn.bias.double(), False, 0.0, bn.eps))
+        got = dense.conv_bn_act(conv, bn, True, x)
+        assert got.shape == want.shape
+        torch.testing.assert_close(got.double(), ref64, rtol=1e-5, atol=1e-5)
