@@ -329,6 +329,21 @@ int srf_conv1x1_pack_weights(const float *W, int Cout, int K, float *packed, srf
 int srf_conv1x1(const float *const *srcs, const int *src_channels, int n_src, int N, int HW, const float *W_packed, int Cout,
                 const float *scale, const float *shift, int relu, float *out, srf_stream_t stream);
 
+/* ---- channels-last (NHWC) dense convolutions on the f32 MFMA (csrc/conv.hip) --------------------------------------
+ * Activations are (N, H, W, ld) f32, `ld` floats per pixel >= the channels used: x / y point at the first channel of
+ * the slice a layer reads / writes inside its buffer, so the OSA concatenation of VoVNet (vovnet.py:205-210) is a set
+ * of slices of one buffer and never a copy.
+ *
+ * srf_wino3x3: Conv2d(Cin, Cout, 3, stride 1, padding 1, bias folded into shift) as Winograd F(2x2, 3x3), followed by
+ * y = y * scale[co] + shift[co] (either may be NULL) and an optional ReLU: the 3x3 layers of VoVNet's OSA blocks
+ * (vovnet.py:116-133, :180-216), the image FPN outputs, `img_convs` (srfdet_head.py:404-416), SECONDCustom
+ * (second_custom.py:41-63) and the BEV FPN.  U_packed comes from srf_wino3x3_pack_weights(W (Cout, Cin, 3, 3)).
+ * Cin % 8 == 0, x 16-byte aligned, x_ld % 4 == 0, 4 H W x_ld < 2^30, else SRF_EUNSUPPORTED. */
+size_t srf_wino3x3_packed_weight_bytes(int Cout, int Cin);
+int srf_wino3x3_pack_weights(const float *W, int Cout, int Cin, float *packed, srf_stream_t stream);
+int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long long x_ld, const float *U_packed, int Cout,
+                const float *scale, const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream);
+
 /* srf_stage_tail: the row-local remainder of a stage in one launch (srfdet_head.py:1506-1520): FFN + residual + norm3,
  * classification tower + class_logits, regression tower + bboxes_delta + apply_deltas.  obj_in (R x C) is norm2's
  * output; outputs obj_out (R x C), logits (R x ncls), pred (R x Dd).  cls_/reg_ arrays are HOST arrays of n_cls / n_reg

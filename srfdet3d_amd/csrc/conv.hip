@@ -1,0 +1,460 @@
+// conv.hip -- dense convolutions of the camera branch and the BEV backbone on the f32 MFMA, channels-last (NHWC).
+//
+// Reference call sites: the 3x3 / stride 1 Conv2d + BatchNorm2d + ReLU layers of VoVNet's OSA blocks
+// (mmdet3d_plugin/models/backbones/vovnet.py:116-133, :180-216), the 3x3 output convolutions of the image FPN
+// (configs/nus/srfdet_voxel_nusc_LC.py:55-64 -> mmdet FPN), `img_convs` of the head (srfdet_head.py:404-416), the dense
+// blocks of SECONDCustom (second_custom.py:41-63, :78-91) and the BEV FPN; the 1x1 `concat` convolution of every OSA block
+// and the FPN laterals.  The reference runs them as cuDNN calls through torch; round 1 of this repo ran them on MIOpen,
+// whose fp32 3x3 algorithm is a VALU Winograd kernel (57.8 % of the LC frame's kernel time).
+//
+// Layout: activations are (N, H, W, ld) f32 with `ld` >= channels floats per pixel: a layer reads a channel SLICE of its
+// source buffer and writes a slice of its destination buffer, so the OSA concatenation (vovnet.py:205-210: torch.cat of
+// the block input and the five branch outputs) is never built -- the six producers write side by side into one buffer
+// and the 1x1 convolution reads it as a plain (pixels x K) matrix.
+//
+// srf_wino3x3: Winograd F(2x2, 3x3) with every stage inside one kernel:
+//   * a workgroup owns 64 output tiles (8 x 8 tiles of 2 x 2 pixels; tile rows run over the N images stacked on top of
+//     each other) x 64 output channels; 4 waves = 2 tile halves x 2 channel halves, each wave keeps all 16 Winograd
+//     frequencies of its 32 tiles x 32 channels in 16 accumulators of v_mfma_f32_32x32x2_f32 (256 AGPRs, one wave per
+//     SIMD), so the output transform needs no exchange: a lane holds the 16 frequencies of the same (tile, channel);
+//   * the reduction runs over input channels in chunks of 8.  Per chunk every thread loads the 3 x 4 pixels x 4 channels
+//     its half of an input tile needs (float4 per pixel, straight from global memory, predicated at the image border),
+//     applies B^T d B in registers and writes the 8 frequencies it owns into the LDS operand image
+//     V[f][k quad][tile][4]; the pre-transformed weights U = G g G^T arrive packed in the same image form
+//     U[f][k quad][channel][4] and are copied linearly.  Both images are read with conflict-free ds_read_b128; the four
+//     floats of a lane feed four consecutive MFMA k-steps (lane half h supplies channel 4 h + s at step s, for A and B
+//     alike);
+//   * software pipeline: global loads run two chunks ahead in registers, the transform + LDS writes of chunk c + 1 are
+//     spread between the MFMA groups of chunk c, fragments are read one group (4 frequencies = 16 MFMAs) ahead; ONE
+//     barrier per chunk, placed so that the first fragments of the next chunk are read behind it, under the last group.
+//   * epilogue: A^T m A per (tile, channel) in registers, then y = acc * scale[co] + shift[co] (folded eval BatchNorm or
+//     the conv bias), optional ReLU, 128-byte channel runs per pixel.
+// Numerics: f32 throughout; the transforms use only +, - and the exact factor 0.5 (in the weight transform).  The result
+// differs from a direct convolution by a few f32 roundings (tested against torch at 2e-4 of the map's max, the bar of the
+// SECOND / FPN tests).
+#include "common.hpp"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WN_LDS_BYTES ((4 * 2048 + 2 * 720) * 16)  // V[2], U[2]: 2048 float4 each; RAW[2]: 720 float4 each
+
+struct WinoArgs {
+    const float *x;
+    float *y;
+    const float4 *U;
+    const float *scale, *shift;
+    long long x_ld, y_ld;
+    int N, H, W, Cout;
+    int rowBlocks, colBlocks, coutBlocks, nchunk, nspatial, relu;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight transform + packing: W (Cout, Cin, 3, 3) -> U[chunk][cout block][f][quad][co 64][4] (floats), U = G g G^T,
+// G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]]; channels >= Cout are zero.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void srf_wino3x3_pack_k(const float *__restrict__ Wt, int Cout, int Cin, int coutBlocks,
+                                                         float *__restrict__ P, long long total)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int kk = (int)(t & 3), co = (int)((t >> 2) & 63), q = (int)((t >> 8) & 1), f = (int)((t >> 9) & 15);
+    const long long rest = t >> 13;
+    const int cb = (int)(rest % coutBlocks), chunk = (int)(rest / coutBlocks);
+    const int cog = cb * 64 + co, ci = chunk * 8 + q * 4 + kk;
+    float r = 0.f;
+    if (cog < Cout) {
+        const float *g = Wt + ((size_t)cog * Cin + ci) * 9;
+        const int fr = f >> 2, fs = f & 3;
+        // rows of G applied to the kernel's rows (fr) and columns (fs)
+        float col[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const float g0 = g[b], g1 = g[3 + b], g2 = g[6 + b];
+            col[b] = fr == 0 ? g0 : fr == 1 ? 0.5f * (g0 + g1 + g2) : fr == 2 ? 0.5f * (g0 - g1 + g2) : g2;
+        }
+        r = fs == 0 ? col[0] : fs == 1 ? 0.5f * (col[0] + col[1] + col[2]) : fs == 2 ? 0.5f * (col[0] - col[1] + col[2]) : col[2];
+    }
+    P[t] = r;
+}
+
+__device__ __forceinline__ float4 wn_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 wn_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+#define WN_MFMA4(ACC, A, B)                                                        \
+    do {                                                                           \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((A).x, (B).x, ACC, 0, 0, 0);    \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((A).y, (B).y, ACC, 0, 0, 0);    \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((A).z, (B).z, ACC, 0, 0, 0);    \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((A).w, (B).w, ACC, 0, 0, 0);    \
+    } while (0)
+
+template <int DBG>
+__global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_w[];  // V[2][2048] | U[2][2048] | RAW[2][720]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroups b and b + 8 share an XCD (round-robin dispatch): the cout blocks of one spatial block sit on one L2
+    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const int cb = jq % a.coutBlocks;
+    const int sp = (jq / a.coutBlocks) * 8 + xcd;
+    if (sp >= a.nspatial) return;
+    const int per_img = a.rowBlocks * a.colBlocks;
+    const int n = sp / per_img;
+    const int rb = (sp - n * per_img) / a.colBlocks, cbk = sp - n * per_img - rb * a.colBlocks;
+
+    // ---- loader role: the 18 x 18 pixel patch of the block, 8 channels per chunk = 648 float4, <= 3 per thread.  Buffer
+    // loads: the descriptor covers image n; a pixel outside the image gets an offset beyond the range and the hardware
+    // returns zeros (the convolution's zero padding) -- no predicates, no selects.  LDS image of the patch:
+    // RAW[k quad][row][column parity][column / 2] with a row pitch of 20 float4, so that the tiles of a wave (column
+    // stride 2) read consecutive float4 and the 8 tile rows fall on alternating bank halves.
+    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.x) + (long long)n * a.H * a.W * a.x_ld, 0, (int)((long long)a.H * a.W * a.x_ld * 4), 0x00020000);
+    unsigned goff[3];
+    int gdst[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int i = tid + 256 * j;
+        const int qq = i & 1, p = i >> 1;
+        const int py = p / 18, px = p - py * 18;
+        const int y = 16 * rb - 1 + py, x = 16 * cbk - 1 + px;
+        const bool ok = i < 648 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+        goff[j] = ok ? (unsigned)((((long long)y * a.W + x) * a.x_ld + qq * 4) * 4) : 0x80000000u;
+        gdst[j] = i < 648 ? 8192 + (qq * 18 + py) * 20 + (px & 1) * 10 + (px >> 1) : 8192 + 9;  // 9: a slot no pixel uses
+    }
+    const float4 z4_ = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gr_0 = z4_, gr_1 = z4_, gr_2 = z4_;
+#define WN_GL(J)                                                                                    \
+    if (!(DBG & 1)) {                                                                               \
+        auto v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)goff[J], soff_, 0);             \
+        gr_##J = *reinterpret_cast<float4 *>(&v_);                                                  \
+    }
+#define WN_LOAD_RAW(CH)              \
+    do {                             \
+        const int soff_ = (CH) * 32; \
+        WN_GL(0) WN_GL(1) WN_GL(2)   \
+    } while (0)
+#define WN_STORE_RAW(RAWB)                             \
+    do {                                               \
+        s_w[gdst[0] + (RAWB)] = gr_0;                  \
+        s_w[gdst[1] + (RAWB)] = gr_1;                  \
+        s_w[gdst[2] + (RAWB)] = gr_2;                  \
+    } while (0)
+
+    // ---- transform role: tile t = lane, k quad q, half hh of the 4 frequency rows ----
+    // Rows of the 4 x 4 input tile this half needs, in the order (RA, RB, RC) = (d[2 hh], d[1 + 2 hh], d[2 - hh]):
+    // frequency rows  t0 = RA - RC,  t1 = RC + s RB  with s = +1 (hh = 0: d0 - d2, d1 + d2) or -1 (hh = 1: d2 - d1, d1 - d3).
+    const int q = wave & 1, hh = wave >> 1;
+    const float sgn = hh ? -1.f : 1.f;
+    int rsrc_row[3];
+    {
+        const int tx = lane & 7, ty = lane >> 3;
+        const int rsel[3] = {2 * hh, 1 + 2 * hh, 2 - hh};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) rsrc_row[r] = 8192 + (q * 18 + 2 * ty + rsel[r]) * 20 + tx;
+    }
+    const float4 *Ug = a.U + (size_t)cb * 2048 + tid;
+    const size_t u_chunk_stride = (size_t)a.coutBlocks * 2048;
+
+    // staging registers as named scalars (arrays indexed from macro loops were left in scratch by hipcc)
+    float4 pr_0, pr_1, pr_2, pr_3, pr_4, pr_5, pr_6, pr_7, pr_8, pr_9, pr_10, pr_11;
+    float4 ur_0 = z4_, ur_1 = z4_, ur_2 = z4_, ur_3 = z4_, ur_4 = z4_, ur_5 = z4_, ur_6 = z4_, ur_7 = z4_;
+    // pixel column 2 tx + c of the patch: parity c & 1, index tx + (c >> 1)
+#define WN_RD(R, C, I) pr_##I = s_w[rsrc_row[R] + (RAWB_) + ((C) & 1) * 10 + ((C) >> 1)];
+#define WN_READ_RAW(RAWB)                                               \
+    do {                                                                \
+        const int RAWB_ = (RAWB);                                       \
+        WN_RD(0, 0, 0) WN_RD(0, 1, 1) WN_RD(0, 2, 2) WN_RD(0, 3, 3)     \
+        WN_RD(1, 0, 4) WN_RD(1, 1, 5) WN_RD(1, 2, 6) WN_RD(1, 3, 7)     \
+        WN_RD(2, 0, 8) WN_RD(2, 1, 9) WN_RD(2, 2, 10) WN_RD(2, 3, 11)   \
+    } while (0)
+#define WN_LOAD_U_LO(CH)                                              \
+    do {                                                              \
+        const float4 *ub_ = Ug + (size_t)(CH) * u_chunk_stride;       \
+        if (!(DBG & 2)) { ur_0 = ub_[0]; ur_1 = ub_[256]; ur_2 = ub_[512]; ur_3 = ub_[768]; } \
+    } while (0)
+#define WN_LOAD_U_HI(CH)                                              \
+    do {                                                              \
+        const float4 *ub_ = Ug + (size_t)(CH) * u_chunk_stride;       \
+        if (!(DBG & 2)) { ur_4 = ub_[1024]; ur_5 = ub_[1280]; ur_6 = ub_[1536]; ur_7 = ub_[1792]; } \
+    } while (0)
+#define WN_STORE_U_LO(WB)                                             \
+    do {                                                              \
+        float4 *ud_ = s_w + 4096 + (WB) + tid;                        \
+        ud_[0] = ur_0; ud_[256] = ur_1; ud_[512] = ur_2; ud_[768] = ur_3; \
+    } while (0)
+#define WN_STORE_U_HI(WB)                                             \
+    do {                                                              \
+        float4 *ud_ = s_w + 4096 + (WB) + tid;                        \
+        ud_[1024] = ur_4; ud_[1280] = ur_5; ud_[1536] = ur_6; ud_[1792] = ur_7; \
+    } while (0)
+    // vertical stage: the two frequency rows this half owns, for the 4 columns (register rows RA = 0-3, RB = 4-7, RC = 8-11)
+#define WN_S1(C, A, B, D)                                                                                           \
+    t0_##C = wn_sub(pr_##A, pr_##D);                                                                                \
+    t1_##C = make_float4(__fmaf_rn(sgn, pr_##B.x, pr_##D.x), __fmaf_rn(sgn, pr_##B.y, pr_##D.y),                    \
+                         __fmaf_rn(sgn, pr_##B.z, pr_##D.z), __fmaf_rn(sgn, pr_##B.w, pr_##D.w));
+#define WN_STAGE1()         \
+    do {                    \
+        WN_S1(0, 0, 4, 8)   \
+        WN_S1(1, 1, 5, 9)   \
+        WN_S1(2, 2, 6, 10)  \
+        WN_S1(3, 3, 7, 11)  \
+    } while (0)
+    // horizontal stage of one frequency row + its 4 LDS writes
+#define WN_STAGE2(T, FR, WB)                                                     \
+    do {                                                                         \
+        const int o_ = (WB) + (((FR) * 4) * 2 + q) * 64 + lane;                  \
+        s_w[o_] = wn_sub(T##_0, T##_2);                                          \
+        s_w[o_ + 128] = wn_add(T##_1, T##_2);                                    \
+        s_w[o_ + 256] = wn_sub(T##_2, T##_1);                                    \
+        s_w[o_ + 384] = wn_sub(T##_1, T##_3);                                    \
+    } while (0)
+
+    // ---- MFMA role: tile half th, channel half chh ----
+    const int th = wave & 1, chh = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_off = lh * 64 + th * 32 + li;          // + f * 128 (+ buffer)
+    const int b_off = 4096 + lh * 64 + chh * 32 + li;  // + f * 128 (+ buffer)
+#define WN_READ_GROUP(SET, G, RB)                                                 \
+    do {                                                                          \
+        _Pragma("unroll") for (int e_ = 0; e_ < 2; ++e_) {                        \
+            fa[SET][e_] = *reinterpret_cast<const f32x4 *>(&s_w[(RB) + a_off + ((G) * 2 + e_) * 128]); \
+            fb[SET][e_] = *reinterpret_cast<const f32x4 *>(&s_w[(RB) + b_off + ((G) * 2 + e_) * 128]); \
+        }                                                                         \
+    } while (0)
+// hipcc moves the register-only MFMAs across sched_barrier (they carry no chain): without the two empty asm pins below it
+// merged pairs of groups and waited for the NEXT group's fragments right after issuing their reads.  The first pin holds
+// the group's MFMAs behind this point (they consume the pinned fragments), the second keeps them in front of the
+// region's end (it consumes their accumulators).
+#define WN_MFMA_GROUP(SET, G)                                                                   \
+    do {                                                                                        \
+        f32x4 pa0_ = fa[SET][0], pa1_ = fa[SET][1], pb0_ = fb[SET][0], pb1_ = fb[SET][1];       \
+        asm volatile("" : "+v"(pa0_), "+v"(pa1_), "+v"(pb0_), "+v"(pb1_));                      \
+        f32x16 c0_ = acc[(G) * 2], c1_ = acc[(G) * 2 + 1];                                      \
+        if (!(DBG & 4)) {                                                                       \
+            WN_MFMA4(c0_, pa0_, pb0_);                                                          \
+            WN_MFMA4(c1_, pa1_, pb1_);                                                          \
+        }                                                                                       \
+        asm volatile("" : "+a"(c0_), "+a"(c1_));                                                \
+        acc[(G) * 2] = c0_;                                                                     \
+        acc[(G) * 2 + 1] = c1_;                                                                 \
+    } while (0)
+#define WN_MFMA_HALF(SET, G, E)                                                                 \
+    do {                                                                                        \
+        f32x4 pa_ = fa[SET][E], pb_ = fb[SET][E];                                               \
+        asm volatile("" : "+v"(pa_), "+v"(pb_));                                                \
+        f32x16 c_ = acc[(G) * 2 + (E)];                                                         \
+        if (!(DBG & 4)) WN_MFMA4(c_, pa_, pb_);                                                 \
+        asm volatile("" : "+a"(c_));                                                            \
+        acc[(G) * 2 + (E)] = c_;                                                                \
+    } while (0)
+#define WN_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+    f32x4 fa[2][2], fb[2][2];  // fragments of two groups (2 frequencies each): one in use, one in flight
+    float4 t0_0, t0_1, t0_2, t0_3, t1_0, t1_1, t1_2, t1_3;
+    const int nchunk = a.nchunk;
+    const int last = nchunk - 1;
+
+    // ---- prologue: chunk 0 transformed into V[0] / U[0], chunk 1's vertical stage in registers, chunk 2's patch and
+    // chunk 1's weights in the staging registers ----
+    WN_LOAD_RAW(0);
+    WN_LOAD_U_LO(0);
+    WN_LOAD_U_HI(0);
+    WN_STORE_RAW(0);
+    WN_LOAD_RAW(last < 1 ? last : 1);
+    WN_STORE_RAW(720);
+    WN_STORE_U_LO(0);
+    WN_STORE_U_HI(0);
+    WN_LOAD_RAW(last < 2 ? last : 2);
+    WN_LOAD_U_LO(last < 1 ? last : 1);
+    WN_LOAD_U_HI(last < 1 ? last : 1);
+    __syncthreads();
+    WN_READ_RAW(0);
+    WN_STAGE1();
+    WN_STAGE2(t0, 2 * hh, 0);
+    WN_STAGE2(t1, 2 * hh + 1, 0);
+    WN_READ_RAW(720);
+    WN_STAGE1();
+    __syncthreads();
+    WN_READ_GROUP(0, 0, 0);
+
+    // Iteration c: multiplies chunk c (8 groups of 2 frequencies = 8 MFMAs each; group g + 1 is read while group g
+    // multiplies); writes the patch of chunk c + 2 (registers -> RAW) and loads the one of chunk c + 3; finishes the
+    // transform of chunk c + 1 (horizontal stage -> V) and stages its weights (-> U), loads the weights of chunk c + 2;
+    // behind the barrier, under the last group: chunk c + 2's patch RAW -> registers -> vertical stage.
+    for (int c = 0; c < nchunk; ++c) {
+        const int rbuf = (c & 1) * 2048, wbuf = 2048 - rbuf;
+        const int rawb = (c & 1) * 720;
+        const int c2 = c + 2 < nchunk ? c + 2 : last, c3 = c + 3 < nchunk ? c + 3 : last;
+        WN_READ_GROUP(1, 1, rbuf);
+        WN_FENCE();
+        WN_STORE_RAW(rawb);
+        WN_LOAD_RAW(c3);
+        WN_MFMA_GROUP(0, 0);
+        WN_FENCE();
+        WN_READ_GROUP(0, 2, rbuf);
+        WN_FENCE();
+        WN_STAGE2(t0, 2 * hh, wbuf);
+        WN_MFMA_GROUP(1, 1);
+        WN_FENCE();
+        WN_READ_GROUP(1, 3, rbuf);
+        WN_FENCE();
+        WN_STORE_U_LO(wbuf);
+        WN_LOAD_U_LO(c2);
+        WN_MFMA_GROUP(0, 2);
+        WN_FENCE();
+        WN_READ_GROUP(0, 4, rbuf);
+        WN_FENCE();
+        WN_STAGE2(t1, 2 * hh + 1, wbuf);
+        WN_MFMA_GROUP(1, 3);
+        WN_FENCE();
+        WN_READ_GROUP(1, 5, rbuf);
+        WN_FENCE();
+        WN_STORE_U_HI(wbuf);
+        WN_LOAD_U_HI(c2);
+        WN_MFMA_GROUP(0, 4);
+        WN_FENCE();
+        WN_READ_GROUP(0, 6, rbuf);
+        WN_FENCE();
+        WN_MFMA_GROUP(1, 5);
+        WN_FENCE();
+        WN_READ_GROUP(1, 7, rbuf);
+        WN_FENCE();
+        WN_MFMA_GROUP(0, 6);
+        WN_FENCE();
+        __syncthreads();
+        WN_READ_GROUP(0, 0, wbuf);
+        WN_READ_RAW(rawb);
+        WN_FENCE();
+        WN_MFMA_HALF(1, 7, 0);  // 4 MFMAs cover the latency of the 12 patch reads the vertical stage waits for
+        WN_FENCE();
+        WN_STAGE1();
+        WN_MFMA_HALF(1, 7, 1);
+        WN_FENCE();
+    }
+
+    // ---- epilogue: A^T m A, affine, ReLU, store ----
+    const int co = cb * 64 + chh * 32 + li;
+    const bool co_ok = co < a.Cout;
+    const float sc = (co_ok && a.scale) ? a.scale[co] : 1.f;
+    const float sh = (co_ok && a.shift) ? a.shift[co] : 0.f;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int oy = 2 * (rb * 8 + th * 4 + rg);
+        const bool row_ok = oy < a.H && co_ok;
+        float *yrow = a.y + (((long long)n * a.H + oy) * a.W) * a.y_ld + co;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = rg * 4 + rr;
+            const int ox = 2 * (cbk * 8 + rr + 4 * lh);
+            float s[4], d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float m0 = acc[j][r], m1 = acc[4 + j][r], m2 = acc[8 + j][r], m3 = acc[12 + j][r];
+                s[j] = (m0 + m1) + m2;
+                d[j] = (m1 - m2) - m3;
+            }
+            float o00 = (s[0] + s[1]) + s[2], o01 = (s[1] - s[2]) - s[3];
+            float o10 = (d[0] + d[1]) + d[2], o11 = (d[1] - d[2]) - d[3];
+            o00 = __fmaf_rn(o00, sc, sh);
+            o01 = __fmaf_rn(o01, sc, sh);
+            o10 = __fmaf_rn(o10, sc, sh);
+            o11 = __fmaf_rn(o11, sc, sh);
+            if (a.relu) {
+                o00 = fmaxf(o00, 0.f);
+                o01 = fmaxf(o01, 0.f);
+                o10 = fmaxf(o10, 0.f);
+                o11 = fmaxf(o11, 0.f);
+            }
+            if (row_ok && ox < a.W) {
+                float *p = yrow + (long long)ox * a.y_ld;
+                p[0] = o00;
+                if (ox + 1 < a.W) p[a.y_ld] = o01;
+                if (oy + 1 < a.H) {
+                    float *p2 = p + (long long)a.W * a.y_ld;
+                    p2[0] = o10;
+                    if (ox + 1 < a.W) p2[a.y_ld] = o11;
+                }
+            }
+        }
+    }
+}
+
+extern "C" size_t srf_wino3x3_packed_weight_bytes(int Cout, int Cin)
+{
+    if (Cout <= 0 || Cin <= 0 || (Cin & 7)) return 0;
+    return (size_t)(Cin / 8) * srf_ceil_div(Cout, 64) * 2048 * 16;
+}
+
+extern "C" int srf_wino3x3_pack_weights(const float *W, int Cout, int Cin, float *packed, srf_stream_t stream)
+{
+    if (Cout <= 0 || Cin <= 0 || !W || !packed) return SRF_EINVAL;
+    if (Cin & 7) return SRF_EUNSUPPORTED;
+    const int coutBlocks = srf_ceil_div(Cout, 64);
+    const long long total = (long long)(Cin / 8) * coutBlocks * 8192;
+    hipLaunchKernelGGL(srf_wino3x3_pack_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, W, Cout, Cin, coutBlocks,
+                       packed, total);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long long x_ld, const float *U_packed, int Cout,
+                           const float *scale, const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream)
+{
+    if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || x_ld < Cin || y_ld < Cout) return SRF_EINVAL;
+    if (N == 0) return SRF_OK;
+    if (!x || !U_packed || !y) return SRF_EINVAL;
+    if ((Cin & 7) || (x_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)U_packed & 15)) return SRF_EUNSUPPORTED;
+    // per-lane byte offsets inside one image must stay below 2^30 (the buffer descriptor covers one image)
+    if ((long long)H * W * x_ld * 4 >= (1ll << 30)) return SRF_EUNSUPPORTED;
+    WinoArgs a;
+    a.x = x;
+    a.y = y;
+    a.U = reinterpret_cast<const float4 *>(U_packed);
+    a.scale = scale;
+    a.shift = shift;
+    a.x_ld = x_ld;
+    a.y_ld = y_ld;
+    a.N = N;
+    a.H = H;
+    a.W = W;
+    a.Cout = Cout;
+    a.rowBlocks = srf_ceil_div(H, 16);
+    a.colBlocks = srf_ceil_div(W, 16);
+    a.coutBlocks = srf_ceil_div(Cout, 64);
+    a.nchunk = Cin / 8;
+    const long long nspatial = (long long)N * a.rowBlocks * a.colBlocks;
+    if (nspatial * a.coutBlocks >= (1ll << 30)) return SRF_EUNSUPPORTED;
+    a.nspatial = (int)nspatial;
+    a.relu = relu;
+    const long long blocks = ((nspatial + 7) / 8) * 8 * a.coutBlocks;
+    int dev = 0;
+    SRF_HIP_TRY(hipGetDevice(&dev));
+    static bool attr_set[64] = {false};
+    if (dev < 0 || dev >= 64) return SRF_EUNSUPPORTED;
+    static const int dbg = getenv("SRF_WINO_DBG") ? atoi(getenv("SRF_WINO_DBG")) : 0;  // timing ablations (developer knob)
+    if (!attr_set[dev]) {
+        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
+        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
+        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
+        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
+        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
+        attr_set[dev] = true;
+    }
+    const dim3 grid((unsigned)blocks), blk(256);
+    switch (dbg) {
+    case 1: hipLaunchKernelGGL(srf_wino3x3_k<1>, grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL(srf_wino3x3_k<2>, grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a); break;
+    case 3: hipLaunchKernelGGL(srf_wino3x3_k<3>, grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a); break;
+    case 4: hipLaunchKernelGGL(srf_wino3x3_k<4>, grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL(srf_wino3x3_k<0>, grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a); break;
+    }
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}

@@ -748,6 +748,59 @@ def conv1x1(xs, packed_weight, Cout, scale=None, shift=None, relu=False):
     return out
 
 
+# ---- channels-last (NHWC) dense convolutions (csrc/conv.hip) ---------------------------------------------------------
+def nhwc_ld(x):
+    """Floats per pixel of an (N, H, W, C) f32 view whose channels are a slice of a pixel-major buffer; raises if the
+    view is not of that form."""
+    if x.dim() != 4 or x.dtype != torch.float32 or not x.is_cuda:
+        raise RuntimeError("srfdet3d: expected a 4-d f32 GPU tensor (N, H, W, C)")
+    N, H, W, C = x.shape
+    ld = x.stride(2) if W > 1 else (x.stride(1) if H > 1 else max(C, 1))
+    ok = (C == 1 or x.stride(3) == 1) and ld >= C and (W == 1 or x.stride(2) == ld) and (H == 1 or x.stride(1) == W * ld) \
+        and (N == 1 or x.stride(0) == H * W * ld)
+    if not ok:
+        raise RuntimeError(f"srfdet3d: tensor of shape {tuple(x.shape)} / strides {x.stride()} is not a channel slice of an NHWC buffer")
+    return ld
+
+
+def pack_wino3x3_weights(weight):
+    """(Cout, Cin, 3, 3) -> G g G^T in the LDS operand order srf_wino3x3 copies (once per layer)."""
+    weight = _dev(weight, "weight", torch.float32)
+    Cout, Cin, kh, kw = weight.shape
+    L = _lib.lib()
+    nbytes = L.srf_wino3x3_packed_weight_bytes(Cout, Cin)
+    if (kh, kw) != (3, 3) or nbytes == 0:
+        raise ValueError("wino3x3: needs a (Cout, Cin, 3, 3) weight with Cin % 8 == 0")
+    packed = _empty((nbytes // 4,), torch.float32, weight.device)
+    check(L.srf_wino3x3_pack_weights(_ptr(weight), Cout, Cin, _ptr(packed), _stream()), "wino3x3_pack_weights")
+    return packed
+
+
+def wino3x3_supported(x):
+    return (x.dim() == 4 and x.is_cuda and x.dtype == torch.float32 and x.shape[3] % 8 == 0 and x.data_ptr() % 16 == 0
+            and x.stride(2) % 4 == 0 and 4 * x.shape[1] * x.shape[2] * x.stride(2) < (1 << 30))
+
+
+def wino3x3(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None):
+    """3x3 / stride 1 / padding 1 convolution of the NHWC slice x (N, H, W, Cin) + per-channel scale / shift + ReLU into
+    `out` (an (N, H, W, Cout) slice of an NHWC buffer; a new contiguous tensor when None)."""
+    x_ld = nhwc_ld(x)
+    N, H, W, Cin = x.shape
+    if out is None:
+        out = _empty((N, H, W, Cout), torch.float32, x.device)
+    elif tuple(out.shape) != (N, H, W, Cout):
+        raise ValueError("wino3x3: out has the wrong shape")
+    y_ld = nhwc_ld(out)
+    L = _lib.lib()
+    if packed_weight.numel() * 4 != L.srf_wino3x3_packed_weight_bytes(Cout, Cin):
+        raise ValueError("wino3x3: packed weight does not match (Cout, Cin)")
+    check(L.srf_wino3x3(_ptr(x), N, H, W, Cin, x_ld, _ptr(packed_weight), Cout,
+                        None if scale is None else _ptr(_dev(scale, "scale", torch.float32)),
+                        None if shift is None else _ptr(_dev(shift, "shift", torch.float32)), int(bool(relu)),
+                        _ptr(out), y_ld, _stream()), "wino3x3")
+    return out
+
+
 def _ptr_array(tensors):
     import ctypes
     arr = (ctypes.c_void_p * max(len(tensors), 1))()

@@ -1,0 +1,70 @@
+"""srf_wino3x3 on the 3x3 / stride 1 layer shapes of the LC image branch and the BEV backbone, beside torch (MIOpen) on
+the same data: time, direct-equivalent TFLOP/s (2 * 9 * Cin * Cout * pixels) and executed Winograd TFLOP/s (/ 2.25).
+`python tools/bench_wino.py [--quick]`"""
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, ".")
+from srfdet3d_amd import ops  # noqa: E402
+
+SHAPES = [  # (name, N, H, W, Cin, Cout)
+    ("stem_2 64->64 @464x800", 6, 464, 800, 64, 64),
+    ("stage2 128->128 @232x400", 6, 232, 400, 128, 128),
+    ("stage3 first 256->160 @116x200", 6, 116, 200, 256, 160),
+    ("stage3 160->160 @116x200", 6, 116, 200, 160, 160),
+    ("stage3 first 512->160", 6, 116, 200, 512, 160),
+    ("stage4 first 768->192 @58x100", 6, 58, 100, 768, 192),
+    ("stage4 192->192 @58x100", 6, 58, 100, 192, 192),
+    ("stage5 first 1024->224 @29x50", 6, 29, 50, 1024, 224),
+    ("stage5 224->224 @29x50", 6, 29, 50, 224, 224),
+    ("fpn out 256->256 @232x400", 6, 232, 400, 256, 256),
+    ("img_convs 256->128 @232x400", 6, 232, 400, 256, 128),
+    ("fpn out 256->256 @116x200", 6, 116, 200, 256, 256),
+    ("SECOND 256->128 @184", 1, 184, 184, 256, 128),
+    ("SECOND 128->128 @184", 1, 184, 184, 128, 128),
+    ("SECOND 256->256 @92", 1, 92, 92, 256, 256),
+]
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def main():
+    quick = "--quick" in sys.argv
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(0)
+    print(f"{'layer':36s} {'wino us':>9s} {'TF dir-eq':>10s} {'TF exec':>8s} {'miopen us':>10s} {'TF':>7s} {'maxerr/max':>10s}")
+    for name, N, H, W, Cin, Cout in SHAPES[:4] if quick else SHAPES:
+        x = torch.randn(N, H, W, Cin, generator=g).to(dev)
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dev)
+        shift = torch.randn(Cout, generator=g).to(dev)
+        scale = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+        pk = ops.pack_wino3x3_weights(w)
+        out = torch.empty(N, H, W, Cout, device=dev)
+        iters = 10
+        t_w = timeit(lambda: ops.wino3x3(x, pk, Cout, scale, shift, True, out=out), iters)
+        xc = x.permute(0, 3, 1, 2).contiguous()
+        t_m = timeit(lambda: F.conv2d(xc, w, padding=1), iters)
+        ref = (F.conv2d(xc, w, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).relu().permute(0, 2, 3, 1)
+        err = ((out - ref).abs().max() / ref.abs().max()).item()
+        fl = 2.0 * 9 * Cin * Cout * N * H * W
+        print(f"{name:36s} {t_w:9.1f} {fl / t_w / 1e6:10.1f} {fl / 2.25 / t_w / 1e6:8.1f} {t_m:10.1f} {fl / t_m / 1e6:7.1f} {err:10.2e}")
+        del x, xc, out, ref
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
