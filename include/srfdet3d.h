@@ -344,6 +344,40 @@ int srf_wino3x3_pack_weights(const float *W, int Cout, int Cin, float *packed, s
 int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long long x_ld, const float *U_packed, int Cout,
                 const float *scale, const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream);
 
+/* srf_conv1x1_nhwc: Conv2d(K, Cout, 1) on channels-last activations = the GEMM y[p][co] = sum_k x[p][k] W[co][k] over
+ * M = N * H * W pixels, then y = y * scale[co] + shift[co] (either may be NULL) and an optional ReLU: the `concat` layer of
+ * VoVNet's OSA blocks read straight from the block's concat buffer (vovnet.py:205-216) and the FPN lateral convolutions.
+ * W_packed comes from srf_conv1x1_nhwc_pack_weights(W (Cout, K) row-major).  K % 32 == 0, x 16-byte aligned, x_ld % 4 == 0,
+ * else SRF_EUNSUPPORTED. */
+size_t srf_conv1x1_nhwc_packed_weight_bytes(int Cout, int K);
+int srf_conv1x1_nhwc_pack_weights(const float *W, int Cout, int K, float *packed, srf_stream_t stream);
+int srf_conv1x1_nhwc(const float *x, long long M, int K, long long x_ld, const float *W_packed, int Cout, const float *scale,
+                     const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream);
+
+/* ---- streaming layers of the channels-last camera branch (csrc/nhwc.hip); all take (N, H, W, ld) channel slices, C % 4 == 0,
+ * 16-byte aligned pointers, ld % 4 == 0 ---------------------------------------------------------------------------------
+ * srf_nhwc_affine: y = x * scale[(per_sample ? n : 0)][c] + shift[c] (+ residual), optional ReLU; scale / shift / residual
+ *   may be NULL; in place allowed: eval BatchNorm2d + ReLU behind a library convolution, and the eSE gate multiply + OSA
+ *   identity add of VoVNet (vovnet.py:135-160, :212-216).  HW = pixels per sample.
+ * srf_nhwc_colmean: mean[n][c] over the HW pixels (AdaptiveAvgPool2d(1) of the eSE module), deterministic two-level sum;
+ *   C <= 1024.
+ * srf_nhwc_maxpool3s2_ceil: MaxPool2d(3, stride 2, ceil_mode=True) (the VoVNet stage pooling) -> (N, Ho, Wo, C).
+ * srf_nhwc_upsample_add: y = lat + nearest-upsampled top (the FPN top-down step; F.interpolate 'nearest' index rule).
+ * srf_nhwc_dwconv3x3s2: depthwise Conv2d(C, C, 3, stride 2, padding 1, groups=C) + scale / shift (+ ReLU): the stair of the
+ *   proposal generator on the camera levels (srfdet_head.py:265-320, :525-536); w is (C, 3, 3). */
+int srf_nhwc_affine(const float *x, long long x_ld, int N, long long HW, int C, const float *scale, int per_sample,
+                    const float *shift, const float *residual, long long r_ld, int relu, float *y, long long y_ld,
+                    srf_stream_t stream);
+size_t srf_nhwc_colmean_workspace_bytes(int N, int C);
+int srf_nhwc_colmean(const float *x, long long x_ld, int N, long long HW, int C, float *mean, void *workspace,
+                     size_t workspace_bytes, srf_stream_t stream);
+int srf_nhwc_maxpool3s2_ceil(const float *x, long long x_ld, int N, int H, int W, int C, float *y, long long y_ld,
+                             srf_stream_t stream);
+int srf_nhwc_upsample_add(const float *lat, long long l_ld, const float *top, long long t_ld, int N, int H, int W, int Ht, int Wt,
+                          int C, float *y, long long y_ld, srf_stream_t stream);
+int srf_nhwc_dwconv3x3s2(const float *x, long long x_ld, int N, int H, int W, int C, const float *w, const float *scale,
+                         const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream);
+
 /* srf_stage_tail: the row-local remainder of a stage in one launch (srfdet_head.py:1506-1520): FFN + residual + norm3,
  * classification tower + class_logits, regression tower + bboxes_delta + apply_deltas.  obj_in (R x C) is norm2's
  * output; outputs obj_out (R x C), logits (R x ncls), pred (R x Dd).  cls_/reg_ arrays are HOST arrays of n_cls / n_reg

@@ -81,6 +81,15 @@ SIGNATURES = {
     "srf_wino3x3_packed_weight_bytes": (c_size_t, [c_int, c_int]),
     "srf_wino3x3_pack_weights": (c_int, [_P, c_int, c_int, _P, _P]),
     "srf_wino3x3": (c_int, [_P, c_int, c_int, c_int, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_longlong, _P]),
+    "srf_conv1x1_nhwc_packed_weight_bytes": (c_size_t, [c_int, c_int]),
+    "srf_conv1x1_nhwc_pack_weights": (c_int, [_P, c_int, c_int, _P, _P]),
+    "srf_conv1x1_nhwc": (c_int, [_P, c_longlong, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_longlong, _P]),
+    "srf_nhwc_affine": (c_int, [_P, c_longlong, c_int, c_longlong, c_int, _P, c_int, _P, _P, c_longlong, c_int, _P, c_longlong, _P]),
+    "srf_nhwc_colmean_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "srf_nhwc_colmean": (c_int, [_P, c_longlong, c_int, c_longlong, c_int, _P, _P, c_size_t, _P]),
+    "srf_nhwc_maxpool3s2_ceil": (c_int, [_P, c_longlong, c_int, c_int, c_int, c_int, _P, c_longlong, _P]),
+    "srf_nhwc_upsample_add": (c_int, [_P, c_longlong, _P, c_longlong, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_longlong, _P]),
+    "srf_nhwc_dwconv3x3s2": (c_int, [_P, c_longlong, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_longlong, _P]),
     "srf_stage_tail": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, c_int, POINTER(c_void_p), POINTER(c_void_p),
                                POINTER(c_void_p), _HF, c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), _HF, _P, _P,
                                c_int, _P, _P, c_int, _P, _HF, _HF, c_float, _P, _P, _P, _P]),

@@ -41,6 +41,9 @@ class FPN(BaseModule):
                                                  norm_cfg=norm_cfg, act_cfg=act_cfg, inplace=False))
 
     def forward(self, inputs):
+        from .. import nhwc
+        if nhwc.enabled() and nhwc.fpn_supported(self, inputs):
+            return nhwc.fpn_forward(self, inputs)   # channels-last levels from the NHWC backbone path
         lat = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
         n = len(lat)
         for i in range(n - 1, 0, -1):

@@ -1,0 +1,277 @@
+// nhwc.hip -- the streaming (HBM-bound) layers of the channels-last camera branch: everything around the two MFMA
+// kernels of conv.hip.  Activations are (N, H, W, ld) f32 channel slices of pixel-major buffers (see conv.hip); every
+// kernel here moves float4 = 4 consecutive channels per thread with the channel quad fastest, so a wave reads and writes
+// whole 128-byte runs.
+//
+// Reference call sites: eval BatchNorm2d + ReLU behind the two stride-2 stem convolutions, the eSE gate multiply and
+// the OSA identity add (mmdet3d_plugin/models/backbones/vovnet.py:135-160, :212-216), the stage pooling
+// (MaxPool2d(3, 2, ceil_mode=True), vovnet.py `_OSA_stage`), the global average pool of the eSE module, the FPN top-down
+// step (mmdet FPN: lateral + nearest-upsampled coarser level), and the depthwise stride-2 stair of the proposal
+// generator (srfdet_head.py:265-320, :525-536).
+#include "common.hpp"
+
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------------------
+// y[p][c] = x[p][c] * scale[(per_sample ? n : 0)][c] + shift[c] (+ residual[p][c]), optional ReLU.  In place allowed.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void srf_nhwc_affine_k(const float *__restrict__ x, long long x_ld, long long M, long long HW, int Cq,
+                                                         const float *__restrict__ scale, int per_sample, const float *__restrict__ shift,
+                                                         const float *__restrict__ res, long long r_ld, int relu, float *__restrict__ y,
+                                                         long long y_ld)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= M * Cq) return;
+    const long long p = t / Cq;
+    const int cq = (int)(t - p * Cq);
+    f32x4n v = *reinterpret_cast<const f32x4n *>(x + p * x_ld + cq * 4);
+    if (scale) {
+        const long long n = per_sample ? p / HW : 0;
+        v *= *reinterpret_cast<const f32x4n *>(scale + n * Cq * 4 + cq * 4);
+    }
+    if (shift) v += *reinterpret_cast<const f32x4n *>(shift + cq * 4);
+    if (res) v += *reinterpret_cast<const f32x4n *>(res + p * r_ld + cq * 4);
+    if (relu) {
+        v[0] = fmaxf(v[0], 0.f);
+        v[1] = fmaxf(v[1], 0.f);
+        v[2] = fmaxf(v[2], 0.f);
+        v[3] = fmaxf(v[3], 0.f);
+    }
+    *reinterpret_cast<f32x4n *>(y + p * y_ld + cq * 4) = v;
+}
+
+extern "C" int srf_nhwc_affine(const float *x, long long x_ld, int N, long long HW, int C, const float *scale, int per_sample,
+                               const float *shift, const float *residual, long long r_ld, int relu, float *y, long long y_ld,
+                               srf_stream_t stream)
+{
+    if (N < 0 || HW < 0 || C <= 0 || x_ld < C || y_ld < C || (residual && r_ld < C)) return SRF_EINVAL;
+    if (N == 0 || HW == 0) return SRF_OK;
+    if (!x || !y) return SRF_EINVAL;
+    if ((C & 3) || (x_ld & 3) || (y_ld & 3) || (r_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)residual & 15) ||
+        ((uintptr_t)scale & 15) || ((uintptr_t)shift & 15))
+        return SRF_EUNSUPPORTED;
+    const long long M = (long long)N * HW, total = M * (C / 4);
+    hipLaunchKernelGGL(srf_nhwc_affine_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld, M, HW, C / 4, scale,
+                       per_sample, shift, residual, r_ld, relu, y, y_ld);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// mean over the pixels of every (sample, channel): AdaptiveAvgPool2d(1) of the eSE module.  Deterministic two-level sum:
+// level 1: grid (P chunks of pixels, N); a workgroup = 256 threads = (C / 4 channel quads) x (256 / (C / 4) pixel lanes)
+// when C <= 1024; each thread sums its pixels in order, the pixel lanes are combined through LDS in a fixed order;
+// level 2: one thread per (n, channel) adds the P partial sums in order and divides.
+// ---------------------------------------------------------------------------------------------------------------------
+#define CM_CHUNKS 64
+
+__global__ __launch_bounds__(256) void srf_nhwc_colsum_k(const float *__restrict__ x, long long x_ld, long long HW, int Cq,
+                                                         float *__restrict__ partial)
+{
+    __shared__ f32x4n s_p[256];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int lanes = 256 / Cq;  // pixel lanes (>= 1); threads past lanes * Cq idle
+    const int cq = threadIdx.x % Cq, pl = threadIdx.x / Cq;
+    const long long per = (HW + CM_CHUNKS - 1) / CM_CHUNKS;
+    const long long p0 = chunk * per;
+    long long p1 = p0 + per;
+    if (p1 > HW) p1 = HW;
+    f32x4n acc = {0.f, 0.f, 0.f, 0.f};
+    const float *xn = x + (long long)n * HW * x_ld + cq * 4;
+    if (pl < lanes)
+        for (long long p = p0 + pl; p < p1; p += lanes) acc += *reinterpret_cast<const f32x4n *>(xn + p * x_ld);
+    s_p[threadIdx.x] = acc;
+    __syncthreads();
+    if (pl == 0) {
+        for (int l = 1; l < lanes; ++l) acc += s_p[l * Cq + cq];
+        *reinterpret_cast<f32x4n *>(partial + (((long long)n * CM_CHUNKS + chunk) * Cq + cq) * 4) = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void srf_nhwc_colmean_finish_k(const float *__restrict__ partial, int N, int C, float inv,
+                                                                 float *__restrict__ mean)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= N * C) return;
+    const int n = t / C, c = t - n * C;
+    float s = 0.f;
+    for (int k = 0; k < CM_CHUNKS; ++k) s += partial[((long long)n * CM_CHUNKS + k) * C + c];
+    mean[t] = s * inv;
+}
+
+extern "C" size_t srf_nhwc_colmean_workspace_bytes(int N, int C) { return (N <= 0 || C <= 0) ? 0 : (size_t)N * CM_CHUNKS * C * 4; }
+
+extern "C" int srf_nhwc_colmean(const float *x, long long x_ld, int N, long long HW, int C, float *mean, void *workspace,
+                                size_t workspace_bytes, srf_stream_t stream)
+{
+    if (N < 0 || HW <= 0 || C <= 0 || x_ld < C) return SRF_EINVAL;
+    if (N == 0) return SRF_OK;
+    if (!x || !mean || !workspace) return SRF_EINVAL;
+    const int Cq = C / 4;
+    if ((C & 3) || Cq > 256 || (x_ld & 3) || ((uintptr_t)x & 15) || N > 65535) return SRF_EUNSUPPORTED;
+    if (workspace_bytes < srf_nhwc_colmean_workspace_bytes(N, C)) return SRF_EWORKSPACE;
+    hipLaunchKernelGGL(srf_nhwc_colsum_k, dim3(CM_CHUNKS, N), dim3(256), 0, (hipStream_t)stream, x, x_ld, HW, Cq, (float *)workspace);
+    hipLaunchKernelGGL(srf_nhwc_colmean_finish_k, dim3(srf_ceil_div((long long)N * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)workspace, N, C, 1.0f / (float)HW, mean);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MaxPool2d(kernel 3, stride 2, ceil_mode=True, no padding): windows that reach past the bottom / right edge are clipped.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void srf_nhwc_maxpool3s2_k(const float *__restrict__ x, long long x_ld, int N, int H, int W, int Cq, int Ho,
+                                                             int Wo, float *__restrict__ y, long long y_ld)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)N * Ho * Wo * Cq;
+    if (t >= total) return;
+    const int cq = (int)(t % Cq);
+    long long r = t / Cq;
+    const int xo = (int)(r % Wo);
+    r /= Wo;
+    const int yo = (int)(r % Ho), n = (int)(r / Ho);
+    const float NEG = -__builtin_inff();
+    f32x4n m = {NEG, NEG, NEG, NEG};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yi = 2 * yo + dy;
+        if (yi >= H) break;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xi = 2 * xo + dx;
+            if (xi < W) {
+                const f32x4n v = *reinterpret_cast<const f32x4n *>(x + (((long long)n * H + yi) * W + xi) * x_ld + cq * 4);
+                m[0] = fmaxf(m[0], v[0]);
+                m[1] = fmaxf(m[1], v[1]);
+                m[2] = fmaxf(m[2], v[2]);
+                m[3] = fmaxf(m[3], v[3]);
+            }
+        }
+    }
+    *reinterpret_cast<f32x4n *>(y + (((long long)n * Ho + yo) * Wo + xo) * y_ld + cq * 4) = m;
+}
+
+static inline int srf_pool_out(int H)
+{
+    int Ho = (H - 3 + 1) / 2 + 1;  // ceil((H - 3) / 2) + 1
+    if (H < 3) Ho = 1;
+    if ((Ho - 1) * 2 >= H) --Ho;   // the last window must start inside the input
+    return Ho;
+}
+
+extern "C" int srf_nhwc_maxpool3s2_ceil(const float *x, long long x_ld, int N, int H, int W, int C, float *y, long long y_ld,
+                                        srf_stream_t stream)
+{
+    if (N < 0 || H < 1 || W < 1 || C <= 0 || x_ld < C || y_ld < C) return SRF_EINVAL;
+    if (N == 0) return SRF_OK;
+    if (!x || !y) return SRF_EINVAL;
+    if ((C & 3) || (x_ld & 3) || (y_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return SRF_EUNSUPPORTED;
+    const int Ho = srf_pool_out(H), Wo = srf_pool_out(W);
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(srf_nhwc_maxpool3s2_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld, N, H, W, C / 4, Ho, Wo,
+                       y, y_ld);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FPN top-down step: y[n][yy][xx][c] = lat[n][yy][xx][c] + top[n][floor(yy Ht / H)][floor(xx Wt / W)][c] (F.interpolate
+// mode='nearest' index rule: src = floor(dst * in / out), computed in float like torch: min(int(dst * scale), in - 1)).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void srf_nhwc_upsample_add_k(const float *__restrict__ lat, long long l_ld, const float *__restrict__ top,
+                                                               long long t_ld, int N, int H, int W, int Ht, int Wt, int Cq, float sy, float sx,
+                                                               float *__restrict__ y, long long y_ld)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)N * H * W * Cq;
+    if (t >= total) return;
+    const int cq = (int)(t % Cq);
+    long long r = t / Cq;
+    const int xx = (int)(r % W);
+    r /= W;
+    const int yy = (int)(r % H), n = (int)(r / H);
+    int ys = (int)floorf((float)yy * sy), xs = (int)floorf((float)xx * sx);
+    if (ys > Ht - 1) ys = Ht - 1;
+    if (xs > Wt - 1) xs = Wt - 1;
+    const long long p = ((long long)n * H + yy) * W + xx;
+    f32x4n v = *reinterpret_cast<const f32x4n *>(lat + p * l_ld + cq * 4);
+    v += *reinterpret_cast<const f32x4n *>(top + (((long long)n * Ht + ys) * Wt + xs) * t_ld + cq * 4);
+    *reinterpret_cast<f32x4n *>(y + p * y_ld + cq * 4) = v;
+}
+
+extern "C" int srf_nhwc_upsample_add(const float *lat, long long l_ld, const float *top, long long t_ld, int N, int H, int W, int Ht, int Wt,
+                                     int C, float *y, long long y_ld, srf_stream_t stream)
+{
+    if (N < 0 || H < 1 || W < 1 || Ht < 1 || Wt < 1 || C <= 0 || l_ld < C || t_ld < C || y_ld < C) return SRF_EINVAL;
+    if (N == 0) return SRF_OK;
+    if (!lat || !top || !y) return SRF_EINVAL;
+    if ((C & 3) || (l_ld & 3) || (t_ld & 3) || (y_ld & 3) || ((uintptr_t)lat & 15) || ((uintptr_t)top & 15) || ((uintptr_t)y & 15))
+        return SRF_EUNSUPPORTED;
+    const long long total = (long long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(srf_nhwc_upsample_add_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, lat, l_ld, top, t_ld, N, H, W,
+                       Ht, Wt, C / 4, (float)Ht / (float)H, (float)Wt / (float)W, y, y_ld);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Depthwise 3x3 / stride 2 / padding 1 convolution + eval BatchNorm (+ ReLU), channels-last: the stair of the proposal
+// generator on the camera levels.  Taps summed in (ky, kx) order like srf_dwconv3x3s2_k; weights w (C, 3, 3).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void srf_nhwc_dwconv3x3s2_k(const float *__restrict__ x, long long x_ld, int N, int H, int W, int Cq, int Ho,
+                                                              int Wo, const float *__restrict__ w, const float *__restrict__ scale,
+                                                              const float *__restrict__ shift, int relu, float *__restrict__ y, long long y_ld)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)N * Ho * Wo * Cq;
+    if (t >= total) return;
+    const int cq = (int)(t % Cq);
+    long long r = t / Cq;
+    const int xo = (int)(r % Wo);
+    r /= Wo;
+    const int yo = (int)(r % Ho), n = (int)(r / Ho);
+    float k[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) k[c][j] = w[(cq * 4 + c) * 9 + j];
+    f32x4n acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yi = 2 * yo - 1 + ky;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xi = 2 * xo - 1 + kx;
+            f32x4n v = {0.f, 0.f, 0.f, 0.f};
+            if (yi >= 0 && yi < H && xi >= 0 && xi < W)
+                v = *reinterpret_cast<const f32x4n *>(x + (((long long)n * H + yi) * W + xi) * x_ld + cq * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = __fmaf_rn(v[c], k[c][ky * 3 + kx], acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float o = acc[c];
+        if (scale) o = __fmaf_rn(o, scale[cq * 4 + c], shift ? shift[cq * 4 + c] : 0.f);
+        else if (shift) o = __fadd_rn(o, shift[cq * 4 + c]);
+        if (relu) o = fmaxf(o, 0.f);
+        acc[c] = o;
+    }
+    *reinterpret_cast<f32x4n *>(y + (((long long)n * Ho + yo) * Wo + xo) * y_ld + cq * 4) = acc;
+}
+
+extern "C" int srf_nhwc_dwconv3x3s2(const float *x, long long x_ld, int N, int H, int W, int C, const float *w, const float *scale,
+                                    const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream)
+{
+    if (N < 0 || H < 1 || W < 1 || C <= 0 || x_ld < C || y_ld < C) return SRF_EINVAL;
+    if (N == 0) return SRF_OK;
+    if (!x || !w || !y) return SRF_EINVAL;
+    if ((C & 3) || (x_ld & 3) || (y_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return SRF_EUNSUPPORTED;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(srf_nhwc_dwconv3x3s2_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld, N, H, W, C / 4, Ho, Wo,
+                       w, scale, shift, relu, y, y_ld);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}

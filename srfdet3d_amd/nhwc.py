@@ -1,0 +1,257 @@
+"""Channels-last (NHWC) inference of the camera branch on the hand-written kernels of csrc/conv.hip and csrc/nhwc.hip:
+VoVNet (vovnet.py:268-374) -> FPN (configs/nus/srfdet_voxel_nusc_LC.py:55-64) -> `img_convs` (srfdet_head.py:404-416).
+
+The torch modules stay the owners of the parameters (state_dict names untouched); this file only EXECUTES them:
+
+* every 3x3 / stride 1 convolution runs on `srf_wino3x3` (Winograd F(2x2, 3x3) on the f32 MFMA) with the eval BatchNorm
+  (or the bias) and the ReLU as its epilogue;
+* an OSA block owns ONE pixel-major buffer of Cin + 5 w channels: the block input sits in slice 0, each 3x3 branch writes
+  its slice, and the 1x1 `concat` convolution (`srf_conv1x1_nhwc`) reads the buffer as a plain matrix -- the
+  torch.cat of vovnet.py:205-210 is never built;
+* eSE: pixel mean (`srf_nhwc_colmean`) -> fc + hard sigmoid (`srf_ese_gate`) -> gate multiply + identity add in one pass
+  that writes straight into slice 0 of the next block's buffer (`srf_nhwc_affine`);
+* the two stride-2 stem convolutions stay on MIOpen (channels_last tensors in, channels_last out; 1.3 % of the FLOPs).
+
+Tensors handed to the rest of the model are logical NCHW views with channels_last strides, so every consumer that only
+looks at shapes keeps working and the RoI gather finds its channels-last operand without a copy.
+
+Taken only for fp32 CUDA inference with BatchNorm in eval mode (`dense.fusable` / `dense._foldable`); anything else goes
+through the modules as written.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .dense import _fold_bn2d, _foldable, fusable
+
+
+def enabled():
+    """SRF_IMG_NHWC=0 sends the camera branch through torch / MIOpen as in round 1 (A/B switch for tests and benchmarks)."""
+    import os
+    return os.environ.get("SRF_IMG_NHWC", "1") != "0"
+
+
+def nhwc_view(x):
+    """Logical (N, C, H, W) tensor with channels_last strides -> its (N, H, W, C) view."""
+    return x.permute(0, 2, 3, 1)
+
+
+def nchw_view(x):
+    return x.permute(0, 3, 1, 2)
+
+
+def is_channels_last(x):
+    return x.dim() == 4 and x.stride(1) == 1 and x.shape[1] > 1
+
+
+def _cached(mod, key, vers, make):
+    cache = getattr(mod, key, None)
+    if cache is None or cache[0] != vers:
+        cache = (vers, make())
+        setattr(mod, key, cache)
+    return cache[1]
+
+
+def _wino_weights(conv):
+    w = conv.weight
+    return _cached(conv, "_srf_wino", (w._version, w.data_ptr()), lambda: ops.pack_wino3x3_weights(w.detach()))
+
+
+def _gemm_weights(conv):
+    w = conv.weight
+    return _cached(conv, "_srf_gemm", (w._version, w.data_ptr()), lambda: ops.pack_conv1x1_nhwc_weights(w.detach()))
+
+
+def _is_conv(conv, k, stride=1):
+    return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (k, k) and conv.stride == (stride, stride)
+            and conv.padding == (k // 2, k // 2) and conv.dilation == (1, 1) and conv.groups == 1)
+
+
+def _affine_of(conv, bn):
+    """(scale, shift) of the layer's epilogue: folded eval BatchNorm (and bias), or the bias alone."""
+    if bn is not None:
+        scale, shift = _fold_bn2d(bn)
+        if conv.bias is not None:
+            shift = shift + conv.bias * scale
+        return scale, shift
+    return None, conv.bias
+
+
+def conv3x3(x, conv, bn=None, relu=False, out=None):
+    """x: NHWC slice; conv: nn.Conv2d 3x3 / stride 1 / padding 1."""
+    scale, shift = _affine_of(conv, bn)
+    return ops.wino3x3(x, _wino_weights(conv), conv.out_channels, scale, shift, relu, out=out)
+
+
+def conv1x1(x, conv, bn=None, relu=False, out=None):
+    scale, shift = _affine_of(conv, bn)
+    return ops.conv1x1_nhwc(x, _gemm_weights(conv), conv.out_channels, scale, shift, relu, out=out)
+
+
+def wino_ok(conv, cin):
+    return _is_conv(conv, 3) and cin % 8 == 0
+
+
+def gemm_ok(conv, cin):
+    return _is_conv(conv, 1) and cin % 32 == 0
+
+
+# ---- VoVNet ----------------------------------------------------------------------------------------------------------
+def _cbr(seq):
+    """[conv, bn, relu] children of an nn.Sequential built by vovnet._cbr; None if it has another form."""
+    mods = list(seq.children())
+    if len(mods) == 3 and isinstance(mods[0], nn.Conv2d) and _foldable(mods[1]) and isinstance(mods[2], nn.ReLU):
+        return mods[0], mods[1]
+    return None
+
+
+def vovnet_supported(net, x):
+    from .plugin.vovnet import OSAModule
+    if not (fusable(x) and x.dim() == 4):
+        return False
+    stem = list(net.stem.children())
+    if len(stem) != 9:
+        return False
+    for i in (0, 3, 6):
+        if not (isinstance(stem[i], nn.Conv2d) and _foldable(stem[i + 1]) and isinstance(stem[i + 2], nn.ReLU)):
+            return False
+    if not (wino_ok(stem[3], stem[3].in_channels) and stem[3].bias is None):
+        return False
+    for name in net.stage_names:
+        for m in getattr(net, name).children():
+            if isinstance(m, nn.MaxPool2d):
+                if not (m.kernel_size == 3 and m.stride == 2 and m.padding == 0 and m.ceil_mode and m.dilation == 1):
+                    return False
+            elif isinstance(m, OSAModule):
+                if m.reduce is not None:
+                    return False
+                cin = None
+                for layer in m.layers:
+                    cb = _cbr(layer)
+                    if cb is None or not wino_ok(cb[0], cb[0].in_channels):
+                        return False
+                    cin = cin or cb[0].in_channels
+                cc = _cbr(m.concat)
+                if cc is None or not gemm_ok(cc[0], cc[0].in_channels) or cc[0].out_channels % 4 or cc[0].out_channels > 1024:
+                    return False
+            else:
+                return False
+    return True
+
+
+def _osa_forward(m, buf, cin, dst):
+    """One OSA block.  buf: (N, H, W, cin + L w) with the block input in [..., :cin]; dst: NHWC slice that receives the
+    block output (gate * concat (+ input))."""
+    off = cin
+    src = buf[..., :cin]
+    for layer in m.layers:
+        conv, bn = _cbr(layer)
+        w = conv.out_channels
+        out = buf[..., off:off + w]
+        conv3x3(src, conv, bn, True, out=out)
+        src, off = out, off + w
+    conv, bn = _cbr(m.concat)
+    t = conv1x1(buf, conv, bn, True)
+    gate = ops.ese_gate(ops.nhwc_colmean(t), m.ese.fc.weight, m.ese.fc.bias)
+    ops.nhwc_affine(t, scale=gate, residual=buf[..., :cin] if m.identity else None, out=dst)
+    return dst
+
+
+def vovnet_forward(net, x):
+    """x (N, 3, H, W) f32 -> OrderedDict of the requested stage outputs (logical NCHW, channels_last strides)."""
+    from collections import OrderedDict
+    from .plugin.vovnet import OSAModule
+    out = OrderedDict()
+    stem = list(net.stem.children())
+    # stem_1 (3 -> 64, stride 2) on MIOpen, BatchNorm + ReLU in place
+    y = stem[0](x.contiguous(memory_format=torch.channels_last))
+    if not is_channels_last(y):
+        y = y.contiguous(memory_format=torch.channels_last)
+    y = nhwc_view(y)
+    s, b = _affine_of(stem[0], stem[1])
+    ops.nhwc_affine(y, s, b, True, out=y)
+    # stem_2 (64 -> 64) Winograd, stem_3 (64 -> 128, stride 2) on MIOpen
+    y = conv3x3(y, stem[3], stem[4], True)
+    y = stem[6](nchw_view(y))
+    if not is_channels_last(y):
+        y = y.contiguous(memory_format=torch.channels_last)
+    y = nhwc_view(y)
+    s3, b3 = _affine_of(stem[6], stem[7])
+    cur = None          # finished NHWC tensor (stage output) when not already inside a block buffer
+    pending = (y, s3, b3)  # stem output still needs its BatchNorm + ReLU: applied while it is written into the first buffer
+    if "stem" in net._out_features:
+        ops.nhwc_affine(y, s3, b3, True, out=y)
+        pending = None
+        cur = y
+        out["stem"] = nchw_view(y)
+    for name in net.stage_names:
+        mods = list(getattr(net, name).children())
+        blocks = [m for m in mods if isinstance(m, OSAModule)]
+        pool = any(isinstance(m, nn.MaxPool2d) for m in mods)
+        first = blocks[0]
+        cin = _cbr(first.layers[0])[0].in_channels
+        width = sum(_cbr(l)[0].out_channels for l in first.layers)
+        if pending is not None:
+            src = pending[0]
+        else:
+            src = cur
+        N, H, W, _ = src.shape
+        if pool:
+            H, W = ops.pool3s2_out(H), ops.pool3s2_out(W)
+        buf = torch.empty((N, H, W, cin + width), dtype=torch.float32, device=src.device)
+        if pending is not None:
+            ops.nhwc_affine(pending[0], pending[1], pending[2], True, out=buf[..., :cin])
+            pending = None
+        elif pool:
+            ops.nhwc_maxpool3s2_ceil(src, out=buf[..., :cin])
+        else:
+            buf[..., :cin].copy_(src)
+        for i, m in enumerate(blocks):
+            cout = _cbr(m.concat)[0].out_channels
+            if i + 1 < len(blocks):
+                nxt = blocks[i + 1]
+                ncin = _cbr(nxt.layers[0])[0].in_channels
+                nwidth = sum(_cbr(l)[0].out_channels for l in nxt.layers)
+                nbuf = torch.empty((N, H, W, ncin + nwidth), dtype=torch.float32, device=src.device)
+                _osa_forward(m, buf, cin, nbuf[..., :cout])
+                buf, cin = nbuf, ncin
+            else:
+                cur = torch.empty((N, H, W, cout), dtype=torch.float32, device=src.device)
+                _osa_forward(m, buf, cin, cur)
+        if name in net._out_features:
+            out[name] = nchw_view(cur)
+    return out
+
+
+# ---- FPN -------------------------------------------------------------------------------------------------------------
+def fpn_supported(fpn, inputs):
+    n = len(fpn.lateral_convs)
+    if fpn.num_outs != n or fpn.start_level != 0 or fpn.backbone_end_level != fpn.num_ins or len(inputs) != n:
+        return False
+    if fpn.upsample_cfg.get("mode", "nearest") != "nearest" or len(fpn.upsample_cfg) != 1:
+        return False
+    for x, lat, fc in zip(inputs, fpn.lateral_convs, fpn.fpn_convs):
+        if not (fusable(x) and is_channels_last(x)):
+            return False
+        for cm in (lat, fc):
+            if cm.with_activation and not isinstance(cm.activate, nn.ReLU):
+                return False
+            if cm.with_norm and not _foldable(getattr(cm, cm.norm_name)):
+                return False
+        if not (gemm_ok(lat.conv, lat.conv.in_channels) and wino_ok(fc.conv, fc.conv.in_channels)):
+            return False
+        if lat.conv.out_channels % 4:
+            return False
+    return True
+
+
+def _cm(cm, x, fn):
+    bn = getattr(cm, cm.norm_name) if cm.with_norm else None
+    return fn(x, cm.conv, bn, cm.with_activation)
+
+
+def fpn_forward(fpn, inputs):
+    lats = [_cm(cm, nhwc_view(inputs[i]), conv1x1) for i, cm in enumerate(fpn.lateral_convs)]
+    for i in range(len(lats) - 1, 0, -1):
+        ops.nhwc_upsample_add(lats[i - 1], lats[i])
+    return tuple(nchw_view(_cm(cm, lats[i], conv3x3)) for i, cm in enumerate(fpn.fpn_convs))

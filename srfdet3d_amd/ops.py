@@ -801,6 +801,112 @@ def wino3x3(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None
     return out
 
 
+def pack_conv1x1_nhwc_weights(weight):
+    """(Cout, K) or (Cout, K, 1, 1) -> the LDS operand order srf_conv1x1_nhwc copies (once per layer)."""
+    weight = _dev(weight.reshape(weight.shape[0], -1), "weight", torch.float32)
+    Cout, K = weight.shape
+    L = _lib.lib()
+    nbytes = L.srf_conv1x1_nhwc_packed_weight_bytes(Cout, K)
+    if nbytes == 0:
+        raise ValueError("conv1x1_nhwc: K must be a multiple of 32")
+    packed = _empty((nbytes // 4,), torch.float32, weight.device)
+    check(L.srf_conv1x1_nhwc_pack_weights(_ptr(weight), Cout, K, _ptr(packed), _stream()), "conv1x1_nhwc_pack_weights")
+    return packed
+
+
+def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None):
+    """1x1 convolution of the NHWC slice x (N, H, W, K) + per-channel scale / shift + ReLU into `out` ((N, H, W, Cout) slice
+    of an NHWC buffer; new contiguous tensor when None)."""
+    x_ld = nhwc_ld(x)
+    N, H, W, K = x.shape
+    if out is None:
+        out = _empty((N, H, W, Cout), torch.float32, x.device)
+    elif tuple(out.shape) != (N, H, W, Cout):
+        raise ValueError("conv1x1_nhwc: out has the wrong shape")
+    y_ld = nhwc_ld(out)
+    L = _lib.lib()
+    if packed_weight.numel() * 4 != L.srf_conv1x1_nhwc_packed_weight_bytes(Cout, K):
+        raise ValueError("conv1x1_nhwc: packed weight does not match (Cout, K)")
+    check(L.srf_conv1x1_nhwc(_ptr(x), N * H * W, K, x_ld, _ptr(packed_weight), Cout,
+                             None if scale is None else _ptr(_dev(scale, "scale", torch.float32)),
+                             None if shift is None else _ptr(_dev(shift, "shift", torch.float32)), int(bool(relu)),
+                             _ptr(out), y_ld, _stream()), "conv1x1_nhwc")
+    return out
+
+
+def _opt(t, name):
+    return None if t is None else _ptr(_dev(t, name, torch.float32))
+
+
+def nhwc_affine(x, scale=None, shift=None, relu=False, residual=None, out=None):
+    """out = x * scale + shift (+ residual), optional ReLU, on NHWC slices.  scale: (C,) or per sample (N, C)."""
+    x_ld = nhwc_ld(x)
+    N, H, W, C = x.shape
+    if out is None:
+        out = _empty((N, H, W, C), torch.float32, x.device)
+    per_sample = int(scale is not None and scale.dim() == 2)
+    if scale is not None and scale.numel() != (N * C if per_sample else C):
+        raise ValueError("nhwc_affine: scale has the wrong size")
+    check(_lib.lib().srf_nhwc_affine(_ptr(x), x_ld, N, H * W, C, _opt(scale, "scale"), per_sample, _opt(shift, "shift"),
+                                     None if residual is None else _ptr(residual),
+                                     0 if residual is None else nhwc_ld(residual), int(bool(relu)), _ptr(out), nhwc_ld(out),
+                                     _stream()), "nhwc_affine")
+    return out
+
+
+def nhwc_colmean(x):
+    """(N, H, W, C) NHWC slice -> (N, C) mean over the pixels."""
+    x_ld = nhwc_ld(x)
+    N, H, W, C = x.shape
+    L = _lib.lib()
+    ws = _empty((max(L.srf_nhwc_colmean_workspace_bytes(N, C) // 4, 1),), torch.float32, x.device)
+    mean = _empty((N, C), torch.float32, x.device)
+    check(L.srf_nhwc_colmean(_ptr(x), x_ld, N, H * W, C, _ptr(mean), _ptr(ws), ws.numel() * 4, _stream()), "nhwc_colmean")
+    return mean
+
+
+def pool3s2_out(h):
+    ho = 1 if h < 3 else (h - 3 + 1) // 2 + 1
+    return ho - 1 if (ho - 1) * 2 >= h else ho
+
+
+def nhwc_maxpool3s2_ceil(x, out=None):
+    x_ld = nhwc_ld(x)
+    N, H, W, C = x.shape
+    Ho, Wo = pool3s2_out(H), pool3s2_out(W)
+    if out is None:
+        out = _empty((N, Ho, Wo, C), torch.float32, x.device)
+    elif tuple(out.shape) != (N, Ho, Wo, C):
+        raise ValueError("nhwc_maxpool3s2_ceil: out has the wrong shape")
+    check(_lib.lib().srf_nhwc_maxpool3s2_ceil(_ptr(x), x_ld, N, H, W, C, _ptr(out), nhwc_ld(out), _stream()), "nhwc_maxpool3s2_ceil")
+    return out
+
+
+def nhwc_upsample_add(lat, top, out=None):
+    """lat (N, H, W, C) + nearest-upsampled top (N, Ht, Wt, C); out defaults to lat (in place)."""
+    N, H, W, C = lat.shape
+    if out is None:
+        out = lat
+    check(_lib.lib().srf_nhwc_upsample_add(_ptr(lat), nhwc_ld(lat), _ptr(top), nhwc_ld(top), N, H, W, top.shape[1], top.shape[2], C,
+                                           _ptr(out), nhwc_ld(out), _stream()), "nhwc_upsample_add")
+    return out
+
+
+def nhwc_dwconv3x3s2(x, weight, scale=None, shift=None, relu=False, out=None):
+    """Depthwise 3x3 / stride 2 / padding 1 on an NHWC slice; weight (C, 1, 3, 3)."""
+    x_ld = nhwc_ld(x)
+    N, H, W, C = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = _empty((N, Ho, Wo, C), torch.float32, x.device)
+    elif tuple(out.shape) != (N, Ho, Wo, C):
+        raise ValueError("nhwc_dwconv3x3s2: out has the wrong shape")
+    w = _dev(weight.reshape(C, 9), "weight", torch.float32)
+    check(_lib.lib().srf_nhwc_dwconv3x3s2(_ptr(x), x_ld, N, H, W, C, _ptr(w), _opt(scale, "scale"), _opt(shift, "shift"),
+                                          int(bool(relu)), _ptr(out), nhwc_ld(out), _stream()), "nhwc_dwconv3x3s2")
+    return out
+
+
 def _ptr_array(tensors):
     import ctypes
     arr = (ctypes.c_void_p * max(len(tensors), 1))()

@@ -21,10 +21,10 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .. import ops
+from .. import nhwc, ops
 from ..compat.cnn import BaseModule, ConvModule, ModuleList, build_activation_layer, build_conv_layer
 from ..compat.registry import HEADS, LOSSES, BBOX_ASSIGNERS, build_head, build_roi_extractor
-from ..dense import linear_graph_safe
+from ..dense import _fold_bn2d, _foldable, fusable, linear_graph_safe
 from ..roi import SingleRoIExtractor
 from .bbox_util import denormalize_bbox
 
@@ -450,6 +450,9 @@ class SRFDetHead(BaseModule):
         MIOpen resolves these depthwise convs to its naive reference kernel (34 ms on the 6 x 128 x 232 x 400 image
         level, measured), so it is kept away from the stair: in inference ConvModule hands them to srf_dwconv3x3s2
         (conv + BN + ReLU in one streaming kernel), otherwise torch's own depthwise kernel runs (0.2 ms)."""
+        if nhwc.enabled() and all(fusable(f) and nhwc.is_channels_last(f) and f.shape[1] % 4 == 0 for f in feats) \
+                and all(SRFDetHead._dw_ok(c) for c in convs):
+            return SRFDetHead._stair_nhwc(convs, feats)
         with torch.backends.cudnn.flags(enabled=not feats[0].is_cuda):
             x = convs[0](feats[0])
             for lvl in range(1, len(feats)):
@@ -457,6 +460,33 @@ class SRFDetHead(BaseModule):
                 if lvl < len(convs):
                     x = convs[lvl](x)
         return x
+
+    @staticmethod
+    def _dw_ok(cm):
+        conv = cm.conv
+        return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1)
+                and conv.groups == conv.in_channels == conv.out_channels and conv.bias is None and cm.with_norm
+                and _foldable(getattr(cm, cm.norm_name)) and cm.with_activation and isinstance(cm.activate, nn.ReLU))
+
+    @staticmethod
+    def _stair_nhwc(convs, feats):
+        """The same stair on channels-last levels: each depthwise conv + BN + ReLU writes its slice of the next level's
+        concat buffer, the level itself is copied into slice 0 (torch.cat([feats[lvl], x], 1) of srfdet_head.py:531)."""
+        x = nhwc.nhwc_view(feats[0])
+        for lvl in range(1, len(feats)):
+            f = nhwc.nhwc_view(feats[lvl])
+            cm = convs[lvl - 1]
+            c_lvl, c_x = f.shape[3], x.shape[3]
+            buf = torch.empty((*f.shape[:3], c_lvl + c_x), dtype=torch.float32, device=f.device)
+            buf[..., :c_lvl].copy_(f)
+            scale, shift = _fold_bn2d(getattr(cm, cm.norm_name))
+            ops.nhwc_dwconv3x3s2(x, cm.conv.weight, scale, shift, True, out=buf[..., c_lvl:])
+            x = buf
+            if lvl == len(feats) - 1 and lvl < len(convs):
+                cm = convs[lvl]
+                scale, shift = _fold_bn2d(getattr(cm, cm.norm_name))
+                x = ops.nhwc_dwconv3x3s2(x, cm.conv.weight, scale, shift, True)
+        return nhwc.nchw_view(x)
 
     @staticmethod
     def _channel_sum(x):
@@ -497,7 +527,12 @@ class SRFDetHead(BaseModule):
             img_feats = list(img_feats)
             for i, f in enumerate(img_feats):
                 bs, n_cam, C, H, W = f.shape
-                g = self.img_convs[i](f.reshape(bs * n_cam, C, H, W))
+                f4 = f.reshape(bs * n_cam, C, H, W)
+                conv = self.img_convs[i]
+                if nhwc.enabled() and fusable(f4) and nhwc.is_channels_last(f4) and nhwc.wino_ok(conv, C):
+                    g = nhwc.nchw_view(nhwc.conv3x3(nhwc.nhwc_view(f4), conv))  # Winograd on the f32 MFMA, bias in the epilogue
+                else:
+                    g = conv(f4)
                 img_feats[i] = g.reshape(bs, n_cam, *g.shape[1:])
         boxes, prop_feats = self._get_init_proposals(img_feats, point_feats)
         boxes = boxes.contiguous()

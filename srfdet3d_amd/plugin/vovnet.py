@@ -120,6 +120,10 @@ class VoVNet(BaseModule):
             self.add_module(name, _stage(ins[i], widths[i], outs[i], n_blocks[i], n_layers, i + 2, dw))
 
     def forward(self, x):
+        from .. import nhwc
+        if nhwc.enabled() and nhwc.vovnet_supported(self, x):
+            # fp32 inference on the GPU: channels-last execution on the Winograd / GEMM kernels of csrc/conv.hip
+            return nhwc.vovnet_forward(self, x)
         out = OrderedDict()
         x = run_sequential(self.stem, x)
         if "stem" in self._out_features:

@@ -94,3 +94,109 @@ def test_wino3x3_vs_torch_gpu_at_layer_sizes(N, H, W, Cin, Cout):
     ref = F.conv2d(x.permute(0, 3, 1, 2), w, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     ref = ref.relu().permute(0, 2, 3, 1)
     assert (y - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+
+
+# ---- 1x1 convolution (GEMM) on channels-last slices ------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,W,K,Cout", [
+    (1, 3, 5, 32, 8),          # a partial pixel tile, Cout < 32
+    (2, 9, 14, 64, 300),       # two channel blocks, Cout not a multiple of 32
+    (1, 29, 50, 160, 256),     # small-map path (128-pixel tiles)
+    (6, 58, 100, 96, 256),     # 256-pixel tiles, partial last tile
+])
+def test_conv1x1_nhwc_matches_float64(N, H, W, K, Cout):
+    g = torch.Generator().manual_seed(K + Cout)
+    x = torch.randn(N, H, W, K, generator=g).to(DEV)
+    w = (torch.randn(Cout, K, generator=g) / K ** 0.5).to(DEV)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    pk = ops.pack_conv1x1_nhwc_weights(w)
+    y = ops.conv1x1_nhwc(x, pk, Cout, scale, shift, True)
+    ref = ((x.cpu().double() @ w.cpu().double().t()) * scale.cpu().double() + shift.cpu().double()).relu()
+    assert (y.cpu().double() - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1.0)
+    y = ops.conv1x1_nhwc(x, pk, Cout)
+    ref = x.cpu().double() @ w.cpu().double().t()
+    assert (y.cpu().double() - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1.0)
+
+
+def test_conv1x1_nhwc_is_a_k_ordered_fma_chain():
+    """The f32 MFMA accumulates k ascending with one rounding per product: with small-integer data the result is exact,
+    and a slice of a wider buffer is read / written in place."""
+    g = torch.Generator().manual_seed(3)
+    buf = torch.randint(-4, 5, (2, 6, 7, 80), generator=g).float().to(DEV)
+    w = torch.randint(-3, 4, (24, 32), generator=g).float().to(DEV)
+    dst = torch.full((2, 6, 7, 40), 7.0, device=DEV)
+    ops.conv1x1_nhwc(buf[..., 16:48], ops.pack_conv1x1_nhwc_weights(w), 24, out=dst[..., 8:32])
+    ref = buf[..., 16:48] @ w.t()
+    assert torch.equal(dst[..., 8:32], ref)
+    assert torch.all(dst[..., :8] == 7.0) and torch.all(dst[..., 32:] == 7.0)
+
+
+# ---- streaming NHWC layers ---------------------------------------------------------------------------------------------
+def test_nhwc_streaming_layers_match_torch():
+    g = torch.Generator().manual_seed(11)
+    N, H, W, C = 2, 13, 18, 64
+    big = torch.randn(N, H, W, C + 32, generator=g).to(DEV)
+    x = big[..., 16:16 + C]                      # a channel slice
+    xc = x.permute(0, 3, 1, 2)
+    # affine: per-channel scale / shift + ReLU; per-sample gate + residual
+    sc, sh = torch.rand(C, generator=g).to(DEV) + 0.5, torch.randn(C, generator=g).to(DEV)
+    y = ops.nhwc_affine(x, sc, sh, True)
+    assert torch.equal(y, torch.relu(x * sc + sh))
+    gate = torch.rand(N, C, generator=g).to(DEV)
+    res = torch.randn(N, H, W, C, generator=g).to(DEV)
+    y = ops.nhwc_affine(x, gate, None, False, residual=res)
+    assert torch.equal(y, x * gate.view(N, 1, 1, C) + res)
+    # global average pool (deterministic order differs from torch's: a few ulp)
+    m = ops.nhwc_colmean(x)
+    assert torch.allclose(m, x.mean(dim=(1, 2)), rtol=1e-5, atol=1e-6)
+    for Cw in (768, 1024):
+        xx = torch.randn(1, 7, 9, Cw, generator=g).to(DEV)
+        assert torch.allclose(ops.nhwc_colmean(xx), xx.mean(dim=(1, 2)), rtol=1e-5, atol=1e-6)
+    # max pool 3 / 2 ceil
+    y = ops.nhwc_maxpool3s2_ceil(x)
+    ref = F.max_pool2d(xc, 3, 2, ceil_mode=True).permute(0, 2, 3, 1)
+    assert torch.equal(y, ref)
+    # nearest upsample + add
+    top = torch.randn(N, 7, 9, C, generator=g).to(DEV)
+    lat = x.clone()
+    y = ops.nhwc_upsample_add(lat, top)
+    ref = x + F.interpolate(top.permute(0, 3, 1, 2), size=(H, W), mode="nearest").permute(0, 2, 3, 1)
+    assert torch.equal(y, ref) and y.data_ptr() == lat.data_ptr()
+    # depthwise 3x3 stride 2 + BN + ReLU
+    w = torch.randn(C, 1, 3, 3, generator=g).to(DEV)
+    y = ops.nhwc_dwconv3x3s2(x, w, sc, sh, True)
+    ref = torch.relu(F.conv2d(xc, w, stride=2, padding=1, groups=C) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    assert (y - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def _randomize_bn(m, g):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+            mod.weight.data.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+            mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+
+
+def test_vovnet_fpn_channels_last_path_matches_module_path(monkeypatch):
+    """VoVNet-99 -> FPN -> img_convs on the NHWC kernels against the same modules run through torch (SRF_IMG_NHWC=0):
+    features within 2e-4 of the level's max (the bar of the SECOND / FPN tests)."""
+    from srfdet3d_amd.compat.necks import FPN
+    from srfdet3d_amd.plugin.vovnet import VoVNet
+    g = torch.Generator().manual_seed(2)
+    torch.manual_seed(2)
+    net = VoVNet("V-99-eSE", out_features=["stage2", "stage3", "stage4", "stage5"])
+    fpn = FPN([256, 512, 768, 1024], 256, 4, add_extra_convs="on_output", relu_before_extra_convs=True)
+    _randomize_bn(net, g)
+    net, fpn = net.to(DEV).eval(), fpn.to(DEV).eval()
+    x = torch.randn(2, 3, 96, 160, generator=g).to(DEV)
+    with torch.no_grad():
+        monkeypatch.setenv("SRF_IMG_NHWC", "0")
+        ref = fpn(list(net(x).values()))
+        monkeypatch.setenv("SRF_IMG_NHWC", "1")
+        feats = net(x)
+        assert all(f.stride(1) == 1 for f in feats.values())   # channels_last views of the NHWC buffers
+        out = fpn(list(feats.values()))
+    for o, r in zip(out, ref):
+        assert o.shape == r.shape
+        assert (o - r).abs().max().item() <= 2e-4 * r.abs().max().item()

@@ -1,0 +1,57 @@
+"""srf_conv1x1_nhwc on the 1x1 layer shapes of the LC image branch beside torch (rocBLAS / hipBLASLt) on the same data.
+`python tools/bench_gemm1x1.py`"""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from srfdet3d_amd import ops  # noqa: E402
+
+SHAPES = [  # (name, pixels, K, Cout)
+    ("stage2 concat 768->256", 6 * 232 * 400, 768, 256),
+    ("stage3 concat 1056->512", 6 * 116 * 200, 1056, 512),
+    ("stage3 concat 1312->512", 6 * 116 * 200, 1312, 512),
+    ("stage4 concat 1472->768", 6 * 58 * 100, 1472, 768),
+    ("stage4 concat 1728->768", 6 * 58 * 100, 1728, 768),
+    ("stage5 concat 1888->1024", 6 * 29 * 50, 1888, 1024),
+    ("stage5 concat 2144->1024", 6 * 29 * 50, 2144, 1024),
+    ("fpn lateral 256->256", 6 * 232 * 400, 256, 256),
+    ("fpn lateral 512->256", 6 * 116 * 200, 512, 256),
+    ("fpn lateral 768->256", 6 * 58 * 100, 768, 256),
+    ("fpn lateral 1024->256", 6 * 29 * 50, 1024, 256),
+]
+
+
+def timeit(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def main():
+    g = torch.Generator().manual_seed(0)
+    print(f"{'layer':30s} {'ours us':>9s} {'TF':>7s} {'torch us':>9s} {'TF':>7s} {'maxerr/max':>10s}")
+    for name, M, K, Cout in SHAPES:
+        x = torch.randn(1, 1, M, K, generator=g).cuda()
+        w = (torch.randn(Cout, K, generator=g) / K ** 0.5).cuda()
+        shift = torch.randn(Cout, generator=g).cuda()
+        pk = ops.pack_conv1x1_nhwc_weights(w)
+        out = torch.empty(1, 1, M, Cout, device="cuda")
+        t_o = timeit(lambda: ops.conv1x1_nhwc(x, pk, Cout, None, shift, True, out=out))
+        x2 = x.view(M, K)
+        t_t = timeit(lambda: torch.mm(x2, w.t()))
+        ref = (torch.mm(x2, w.t()) + shift).relu()
+        err = ((out.view(M, Cout) - ref).abs().max() / ref.abs().max()).item()
+        fl = 2.0 * M * K * Cout
+        print(f"{name:30s} {t_o:9.1f} {fl / t_o / 1e6:7.1f} {t_t:9.1f} {fl / t_t / 1e6:7.1f} {err:10.2e}")
+
+
+if __name__ == "__main__":
+    main()
