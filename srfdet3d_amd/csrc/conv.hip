@@ -400,277 +400,6 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
 }
 
 // =====================================================================================================================
-// srf_wino3x3_w8_k: the same algorithm on 512 threads = TWO waves per SIMD.  Measured on gfx950 (tools/micro/
-// mfma_overlap*.hip): v_mfma_f32_32x32x2_f32 does NOT overlap with vector instructions of its OWN wave (each v_fma of
-// the same wave adds 5-9 cycles to the 64-cycle MFMA), but a partner wave on the same SIMD gets ~2.8 vector
-// instructions per MFMA time for free.  So the two waves of a SIMD (w and w + 4) share one (32 tiles x 32 channels)
-// accumulator block and split its 16 frequencies: rows 0-1 of the 4 x 4 frequency grid in wave w, rows 2-3 in wave w + 4
-// (8 accumulators = 128 AGPRs each).  The staging work per chunk is split over 512 threads: one (tile, k quad, frequency
-// row) per thread in the transform, 4 weight float4, <= 2 patch float4.  Epilogue: the output transform needs all four
-// frequency rows of a (tile, channel): wave w sends row 1 and receives row 2 through LDS and produces output row 0 of
-// every tile, wave w + 4 the converse and output row 1.
-// =====================================================================================================================
-template <int DBG>
-__global__ __launch_bounds__(512, 2) void srf_wino3x3_w8_k(WinoArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) float4 s_w[];  // V[2][2048] | U[2][2048] | RAW[2][720]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
-    const int cb = jq % a.coutBlocks;
-    const int sp = (jq / a.coutBlocks) * 8 + xcd;
-    if (sp >= a.nspatial) return;
-    const int per_img = a.rowBlocks * a.colBlocks;
-    const int n = sp / per_img;
-    const int rb = (sp - n * per_img) / a.colBlocks, cbk = sp - n * per_img - rb * a.colBlocks;
-
-    // ---- loader role: 648 float4 of the 18 x 18 x 8 patch, <= 2 per thread ----
-    __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.x) + (long long)n * a.H * a.W * a.x_ld, 0, (int)((long long)a.H * a.W * a.x_ld * 4), 0x00020000);
-    unsigned goff[2];
-    int gdst[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int i = tid + 512 * j;
-        const int qq = i & 1, p = i >> 1;
-        const int py = p / 18, px = p - py * 18;
-        const int y = 16 * rb - 1 + py, x = 16 * cbk - 1 + px;
-        const bool ok = i < 648 && y >= 0 && y < a.H && x >= 0 && x < a.W;
-        goff[j] = ok ? (unsigned)((((long long)y * a.W + x) * a.x_ld + qq * 4) * 4) : 0x80000000u;
-        gdst[j] = i < 648 ? 8192 + (qq * 18 + py) * 20 + (px & 1) * 10 + (px >> 1) : 8192 + 9;
-    }
-    const f32x4 z4_ = {0.f, 0.f, 0.f, 0.f};
-    f32x4 gr_0 = z4_, gr_1 = z4_;
-    f32x4 *s_v = reinterpret_cast<f32x4 *>(s_w);
-#define W8_GL(J)                                                                                    \
-    if (!(DBG & 1)) {                                                                               \
-        auto v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)goff[J], soff_, 0);             \
-        gr_##J = *reinterpret_cast<f32x4 *>(&v_);                                                   \
-    }
-#define W8_LOAD_RAW(CH)              \
-    do {                             \
-        const int soff_ = (CH) * 32; \
-        W8_GL(0) W8_GL(1)            \
-    } while (0)
-#define W8_STORE_RAW(RAWB)              \
-    do {                                \
-        s_v[gdst[0] + (RAWB)] = gr_0;   \
-        s_v[gdst[1] + (RAWB)] = gr_1;   \
-    } while (0)
-
-    // ---- transform role: tile = lane, k quad q = wave & 1, frequency row fr = wave >> 1.  Row fr of B^T d is X + s Y with
-    // (X, Y, s) = (d0, d2, -1), (d1, d2, +1), (d2, d1, -1), (d1, d3, -1).
-    const int q = wave & 1, fr = wave >> 1;
-    const float sgn = fr == 1 ? 1.f : -1.f;
-    int raw_x, raw_y;
-    {
-        const int tx = lane & 7, ty = lane >> 3;
-        const int rx = fr == 0 ? 0 : fr == 2 ? 2 : 1;
-        const int ry = fr == 2 ? 1 : fr == 3 ? 3 : 2;
-        raw_x = 8192 + (q * 18 + 2 * ty + rx) * 20 + tx;
-        raw_y = 8192 + (q * 18 + 2 * ty + ry) * 20 + tx;
-    }
-    const int v_dst = ((fr * 4) * 2 + q) * 64 + lane;  // + c' * 128 (+ buffer)
-    const f32x4 *Ug = reinterpret_cast<const f32x4 *>(a.U) + (size_t)cb * 2048 + tid;
-    const size_t u_chunk_stride = (size_t)a.coutBlocks * 2048;
-    f32x4 ur_0 = z4_, ur_1 = z4_, ur_2 = z4_, ur_3 = z4_;
-    f32x4 x_0, x_1, x_2, x_3, y_0, y_1, y_2, y_3, t_0, t_1, t_2, t_3;
-#define W8_READ_RAW(RAWB)                                                       \
-    do {                                                                        \
-        x_0 = s_v[raw_x + (RAWB)]; x_1 = s_v[raw_x + (RAWB) + 10];              \
-        x_2 = s_v[raw_x + (RAWB) + 1]; x_3 = s_v[raw_x + (RAWB) + 11];          \
-        y_0 = s_v[raw_y + (RAWB)]; y_1 = s_v[raw_y + (RAWB) + 10];              \
-        y_2 = s_v[raw_y + (RAWB) + 1]; y_3 = s_v[raw_y + (RAWB) + 11];          \
-    } while (0)
-#define W8_STAGE1()                     \
-    do {                                \
-        t_0 = x_0 + sgn * y_0;          \
-        t_1 = x_1 + sgn * y_1;          \
-        t_2 = x_2 + sgn * y_2;          \
-        t_3 = x_3 + sgn * y_3;          \
-    } while (0)
-#define W8_STAGE2(WB)                           \
-    do {                                        \
-        s_v[(WB) + v_dst] = t_0 - t_2;          \
-        s_v[(WB) + v_dst + 128] = t_1 + t_2;    \
-        s_v[(WB) + v_dst + 256] = t_2 - t_1;    \
-        s_v[(WB) + v_dst + 384] = t_1 - t_3;    \
-    } while (0)
-#define W8_LOAD_U(CH)                                                                           \
-    do {                                                                                        \
-        const f32x4 *ub_ = Ug + (size_t)(CH) * u_chunk_stride;                                  \
-        if (!(DBG & 2)) { ur_0 = ub_[0]; ur_1 = ub_[512]; ur_2 = ub_[1024]; ur_3 = ub_[1536]; } \
-    } while (0)
-#define W8_STORE_U(WB)                                                    \
-    do {                                                                  \
-        f32x4 *ud_ = s_v + 4096 + (WB) + tid;                             \
-        ud_[0] = ur_0; ud_[512] = ur_1; ud_[1024] = ur_2; ud_[1536] = ur_3; \
-    } while (0)
-
-    // ---- MFMA role: tile half th, channel half chh, frequency half fh (rows 2 fh, 2 fh + 1 = frequencies 8 fh .. 8 fh + 7)
-    const int th = wave & 1, chh = (wave >> 1) & 1, fh = wave >> 2;
-    const int li = lane & 31, lh = lane >> 5;
-    const int a_off = fh * 1024 + lh * 64 + th * 32 + li;          // + f' * 128 (+ buffer), f' = 0..7
-    const int b_off = 4096 + fh * 1024 + lh * 64 + chh * 32 + li;
-    f32x4 fa[2][2], fb[2][2];
-#define W8_READ_GROUP(SET, G, RB)                                      \
-    do {                                                               \
-        _Pragma("unroll") for (int e_ = 0; e_ < 2; ++e_) {             \
-            fa[SET][e_] = s_v[(RB) + a_off + ((G) * 2 + e_) * 128];    \
-            fb[SET][e_] = s_v[(RB) + b_off + ((G) * 2 + e_) * 128];    \
-        }                                                              \
-    } while (0)
-#define W8_MFMA_HALF(SET, G, E)                                                                 \
-    do {                                                                                        \
-        f32x4 pa_ = fa[SET][E], pb_ = fb[SET][E];                                               \
-        asm volatile("" : "+v"(pa_), "+v"(pb_));                                                \
-        f32x16 c_ = acc[(G) * 2 + (E)];                                                         \
-        if (!(DBG & 4)) WN_MFMA4(c_, pa_, pb_);                                                 \
-        asm volatile("" : "+a"(c_));                                                            \
-        acc[(G) * 2 + (E)] = c_;                                                                \
-    } while (0)
-#define W8_MFMA_GROUP(SET, G)       \
-    do {                            \
-        W8_MFMA_HALF(SET, G, 0);    \
-        W8_MFMA_HALF(SET, G, 1);    \
-    } while (0)
-
-    f32x16 acc[8];
-#pragma unroll
-    for (int f = 0; f < 8; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-    const int nchunk = a.nchunk;
-    const int last = nchunk - 1;
-
-    // ---- prologue (as in the 4-wave kernel) ----
-    W8_LOAD_RAW(0);
-    W8_LOAD_U(0);
-    W8_STORE_RAW(0);
-    W8_LOAD_RAW(last < 1 ? last : 1);
-    W8_STORE_RAW(720);
-    W8_STORE_U(0);
-    W8_LOAD_RAW(last < 2 ? last : 2);
-    W8_LOAD_U(last < 1 ? last : 1);
-    __syncthreads();
-    W8_READ_RAW(0);
-    W8_STAGE1();
-    W8_STAGE2(0);
-    W8_READ_RAW(720);
-    W8_STAGE1();
-    __syncthreads();
-    W8_READ_GROUP(0, 0, 0);
-
-    for (int c = 0; c < nchunk; ++c) {
-        const int rbuf = (c & 1) * 2048, wbuf = 2048 - rbuf;
-        const int rawb = (c & 1) * 720;
-        const int c2 = c + 2 < nchunk ? c + 2 : last, c3 = c + 3 < nchunk ? c + 3 : last;
-        W8_READ_GROUP(1, 1, rbuf);
-        WN_FENCE();
-        W8_STORE_RAW(rawb);
-        W8_LOAD_RAW(c3);
-        W8_MFMA_GROUP(0, 0);
-        WN_FENCE();
-        W8_READ_GROUP(0, 2, rbuf);
-        WN_FENCE();
-        W8_STAGE2(wbuf);
-        W8_MFMA_GROUP(1, 1);
-        WN_FENCE();
-        W8_READ_GROUP(1, 3, rbuf);
-        WN_FENCE();
-        W8_STORE_U(wbuf);
-        W8_LOAD_U(c2);
-        W8_MFMA_GROUP(0, 2);
-        WN_FENCE();
-        __syncthreads();
-        W8_READ_GROUP(0, 0, wbuf);
-        W8_READ_RAW(rawb);
-        WN_FENCE();
-        W8_MFMA_HALF(1, 3, 0);
-        WN_FENCE();
-        W8_STAGE1();
-        W8_MFMA_HALF(1, 3, 1);
-        WN_FENCE();
-    }
-
-    // ---- epilogue ----
-    // acc[4 i' + j][r]: frequency row 2 fh + i', column j, tile row-in-block th * 4 + (r >> 2), tile column (r & 3) + 4 lh.
-    // Exchange through LDS (the operand images are dead): wave fh = 0 publishes its row 1, wave fh = 1 its row 2 (= its i' = 0).
-    __syncthreads();
-    {
-        f32x4 *xs = s_v + wave * 1024 + lane;  // [r][lane] float4 (j = 0..3)
-        if (fh == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                f32x4 v = {acc[4][r], acc[5][r], acc[6][r], acc[7][r]};
-                xs[r * 64] = v;
-                if ((r & 3) == 3) WN_FENCE();
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-                xs[r * 64] = v;
-                if ((r & 3) == 3) WN_FENCE();
-            }
-        }
-    }
-    __syncthreads();
-    const int co = cb * 64 + chh * 32 + li;
-    const bool co_ok = co < a.Cout;
-    const float sc = (co_ok && a.scale) ? a.scale[co] : 1.f;
-    const float sh = (co_ok && a.shift) ? a.shift[co] : 0.f;
-    const f32x4 *xr = s_v + (wave ^ 4) * 1024 + lane;
-    // one output row of every tile: (tile row-in-block th * 4 + rg, tile column rr + 4 lh)
-#define W8_OUT(R, S0, S1, S2, S3)                                                   \
-    do {                                                                            \
-        float o0 = ((S0) + (S1)) + (S2), o1 = ((S1) - (S2)) - (S3);                 \
-        o0 = __fmaf_rn(o0, sc, sh);                                                 \
-        o1 = __fmaf_rn(o1, sc, sh);                                                 \
-        if (a.relu) {                                                               \
-            o0 = fmaxf(o0, 0.f);                                                    \
-            o1 = fmaxf(o1, 0.f);                                                    \
-        }                                                                           \
-        const int ox = 2 * (cbk * 8 + ((R) & 3) + 4 * lh);                          \
-        if (row_ok && ox < a.W) {                                                   \
-            float *p = yrow + (long long)ox * a.y_ld;                               \
-            p[0] = o0;                                                              \
-            if (ox + 1 < a.W) p[a.y_ld] = o1;                                       \
-        }                                                                           \
-    } while (0)
-    if (fh == 0) {  // output row 0 of a tile: (m0 + m1) + m2, m2 from the partner
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int oy = 2 * (rb * 8 + th * 4 + rg);
-            const bool row_ok = oy < a.H && co_ok;
-            float *yrow = a.y + (((long long)n * a.H + oy) * a.W) * a.y_ld + co;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int r = rg * 4 + rr;
-                const f32x4 o = xr[r * 64];
-                W8_OUT(r, (acc[0][r] + acc[4][r]) + o[0], (acc[1][r] + acc[5][r]) + o[1], (acc[2][r] + acc[6][r]) + o[2],
-                       (acc[3][r] + acc[7][r]) + o[3]);
-            }
-            WN_FENCE();
-        }
-    } else {        // output row 1: (m1 - m2) - m3, m1 from the partner
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int oy = 2 * (rb * 8 + th * 4 + rg) + 1;
-            const bool row_ok = oy < a.H && co_ok;
-            float *yrow = a.y + (((long long)n * a.H + oy) * a.W) * a.y_ld + co;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int r = rg * 4 + rr;
-                const f32x4 o = xr[r * 64];
-                W8_OUT(r, (o[0] - acc[0][r]) - acc[4][r], (o[1] - acc[1][r]) - acc[5][r], (o[2] - acc[2][r]) - acc[6][r],
-                       (o[3] - acc[3][r]) - acc[7][r]);
-            }
-            WN_FENCE();
-        }
-    }
-}
-
-// =====================================================================================================================
 // srf_conv1x1_nhwc: Y[p][co] = sum_k X[p][k] W[co][k] on channels-last activations -- the `concat` 1x1 convolution of the
 // OSA blocks over the whole concat buffer (vovnet.py:205-216) and the FPN laterals -- with scale / shift / ReLU as the
 // epilogue.  A plain GEMM on v_mfma_f32_32x32x2_f32:
@@ -713,22 +442,32 @@ __global__ __launch_bounds__(256) void srf_conv1x1_nhwc_pack_k(const float *__re
     P[t] = cog < Cout ? Wt[(size_t)cog * K + k] : 0.f;
 }
 
-template <int RM>
-__global__ __launch_bounds__(256, 1) void srf_conv1x1_nhwc_k(GemmArgs a)
+// Workgroup tile: (64 RM) pixels x (64 RN) channels, 4 waves = 2 x 2 wave tiles of (32 RM) x (32 RN); the weights are packed
+// in blocks of 256 channels, a workgroup reads the (64 RN)-channel part `cs` of its block.
+//   <2, 2>: 128 x 128, 64 accumulator registers per wave, 32 KB of LDS (one stage + register prefetch) -> several
+//           workgroups per CU: the waves of different workgroups fill each other's barrier / staging gaps (an f32 MFMA
+//           overlaps with another wave's vector and LDS instructions, not with its own wave's);
+//   <4, 4>: 256 x 256, 16 accumulators per wave, one workgroup per CU (kept for A/B timing: SRF_GEMM_BIG=1).
+template <int RM, int RN, int WPE>
+__global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
 {
-    constexpr int TM = 64 * RM;          // pixels per workgroup
+    constexpr int TM = 64 * RM, TN = 64 * RN;
     constexpr int ASZ = 8 * TM;          // float4 per A stage
-    constexpr int BSZ = 8 * 256;         // float4 per B stage
+    constexpr int BSZ = 8 * TN;          // float4 per B stage
     constexpr int NA = ASZ / 256;        // A float4 per thread and chunk (= 2 RM)
-    extern __shared__ __attribute__((aligned(16))) f32x4 s_g[];  // A[2][ASZ] | B[2][BSZ]
+    constexpr int NB = BSZ / 256;
+    constexpr int NCS = 256 / TN;        // channel sub-blocks per packed block
+    extern __shared__ __attribute__((aligned(16))) f32x4 s_g[];  // A[ASZ] | B[BSZ]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
-    const int cb = jq % a.coutBlocks;
-    const long long mb = (long long)(jq / a.coutBlocks) * 8 + xcd;
+    const int nct = a.coutBlocks * NCS;
+    const int ct = jq % nct;
+    const int cb = ct / NCS, cs = ct - cb * NCS;
+    const long long mb = (long long)(jq / nct) * 8 + xcd;
     if (mb >= a.mblocks) return;
+    if ((cb * 256 + cs * TN) >= a.Cout) return;
     const long long p0 = mb * TM;
 
-    // loader: A float4 e = tid + 256 j: row = e >> 3, quad = e & 7 -> 8 lanes read one 128-byte line
     __amdgpu_buffer_rsrc_t xrsrc;
     {
         long long rows = a.M - p0;
@@ -738,112 +477,101 @@ __global__ __launch_bounds__(256, 1) void srf_conv1x1_nhwc_k(GemmArgs a)
     const unsigned aoff0 = (unsigned)(((tid >> 3) * a.x_ld + (tid & 7) * 4) * 4);
     const unsigned aoff_step = (unsigned)(32 * a.x_ld * 4);  // 32 rows per j
     const int a_dst = (tid >> 3) * 8 + ((tid & 7) ^ ((tid >> 4) & 7));  // + 256 j: rows advance by 32, the swizzle repeats
-    const f32x4 *Bg = a.Wp + (size_t)cb * BSZ + tid;
-    const size_t b_chunk_stride = (size_t)a.coutBlocks * BSZ;
-    f32x4 ar[NA], br[8];
-#define GM_LOAD_A(CH)                                                                             \
+    const f32x4 *Bg = a.Wp + (size_t)cb * 2048 + cs * BSZ + tid;
+    const size_t b_chunk_stride = (size_t)a.coutBlocks * 2048;
+    f32x4 ar[NA], br[NB];
+#define GM_LOAD(CH)                                                                               \
     do {                                                                                          \
         const int soff_ = (CH) * 128;                                                             \
         _Pragma("unroll") for (int j_ = 0; j_ < NA; ++j_) {                                       \
             auto v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(aoff0 + j_ * aoff_step), soff_, 0); \
             ar[j_] = *reinterpret_cast<f32x4 *>(&v_);                                             \
         }                                                                                         \
-    } while (0)
-#define GM_LOAD_B(CH)                                                                             \
-    do {                                                                                          \
         const f32x4 *bb_ = Bg + (size_t)(CH) * b_chunk_stride;                                    \
-        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) br[j_] = bb_[j_ * 256];                  \
+        _Pragma("unroll") for (int j_ = 0; j_ < NB; ++j_) br[j_] = bb_[j_ * 256];                 \
     } while (0)
-#define GM_STORE_A(BUF, J0, J1)                                                                   \
+#define GM_STORE()                                                                                \
     do {                                                                                          \
-        _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_) s_g[(BUF) * ASZ + a_dst + 256 * j_] = ar[j_]; \
-    } while (0)
-#define GM_STORE_B(BUF, J0, J1)                                                                   \
-    do {                                                                                          \
-        _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_) s_g[2 * ASZ + (BUF) * BSZ + tid + 256 * j_] = br[j_]; \
+        _Pragma("unroll") for (int j_ = 0; j_ < NA; ++j_) s_g[a_dst + 256 * j_] = ar[j_];         \
+        _Pragma("unroll") for (int j_ = 0; j_ < NB; ++j_) s_g[ASZ + tid + 256 * j_] = br[j_];     \
     } while (0)
 
-    // MFMA role: wave (wm, wn): pixels wm * 32 RM .., channels wn * 128 ..
     const int wm = wave & 1, wn = wave >> 1;
     const int li = lane & 31, lh = lane >> 5;
     const int swz = (li >> 1) & 7;
-    const int a_row = (wm * 32 * RM + li) * 8;          // + im * 256
-    const int b_row = 2 * ASZ + (wn * 128 + li) * 8;    // + jn * 256
+    const int a_row = (wm * 32 * RM + li) * 8;        // + im * 256
+    const int b_row = ASZ + (wn * 32 * RN + li) * 8;  // + jn * 256
     int qs[4];
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) qs[s2] = (2 * s2 + lh) ^ swz;
-    f32x16 acc[RM][4];
+    f32x16 acc[RM][RN];
 #pragma unroll
     for (int i = 0; i < RM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < RN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    f32x4 fa[2][RM], fb[2][4];
-#define GM_READ(SET, S2, BUF)                                                                               \
+    f32x4 fa[2][RM], fb[2][RN];
+#define GM_READ(SET, S2)                                                                                    \
     do {                                                                                                    \
-        _Pragma("unroll") for (int i_ = 0; i_ < RM; ++i_) fa[SET][i_] = s_g[(BUF) * ASZ + a_row + i_ * 256 + qs[S2]]; \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) fb[SET][j_] = s_g[(BUF) * BSZ + b_row + j_ * 256 + qs[S2]];  \
+        _Pragma("unroll") for (int i_ = 0; i_ < RM; ++i_) fa[SET][i_] = s_g[a_row + i_ * 256 + qs[S2]];     \
+        _Pragma("unroll") for (int j_ = 0; j_ < RN; ++j_) fb[SET][j_] = s_g[b_row + j_ * 256 + qs[S2]];     \
     } while (0)
 #define GM_MFMA(SET)                                                                                        \
     do {                                                                                                    \
         _Pragma("unroll") for (int i_ = 0; i_ < RM; ++i_) asm volatile("" : "+v"(fa[SET][i_]));             \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) asm volatile("" : "+v"(fb[SET][j_]));              \
+        _Pragma("unroll") for (int j_ = 0; j_ < RN; ++j_) asm volatile("" : "+v"(fb[SET][j_]));             \
         _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)                                                 \
             _Pragma("unroll") for (int i_ = 0; i_ < RM; ++i_)                                               \
-                _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                            \
+                _Pragma("unroll") for (int j_ = 0; j_ < RN; ++j_)                                           \
                     acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][i_][ks_], fb[SET][j_][ks_], acc[i_][j_], 0, 0, 0); \
     } while (0)
 
+    // One LDS stage: chunk c is multiplied out of LDS while chunk c + 1 waits in registers; at the end of the chunk a
+    // barrier retires the readers, the registers go to LDS, chunk c + 2 is requested, a second barrier publishes.
     const int nchunk = a.nchunk, last = nchunk - 1;
-    GM_LOAD_A(0);
-    GM_LOAD_B(0);
-    GM_STORE_A(0, 0, NA);
-    GM_STORE_B(0, 0, 8);
-    GM_LOAD_A(last < 1 ? last : 1);
-    GM_LOAD_B(last < 1 ? last : 1);
+    GM_LOAD(0);
+    GM_STORE();
+    GM_LOAD(last < 1 ? last : 1);
     __syncthreads();
-    GM_READ(0, 0, 0);
+    GM_READ(0, 0);
     for (int c = 0; c < nchunk; ++c) {
-        const int buf = c & 1;
         const int c2 = c + 2 < nchunk ? c + 2 : last;
-        // chunk c + 1 (registers) -> the other stage (its last readers passed the previous barrier), spread over the sub-steps
-        GM_READ(1, 1, buf);
+        GM_READ(1, 1);
         WN_FENCE();
-        GM_STORE_A(buf ^ 1, 0, NA);
-        GM_LOAD_A(c2);
         GM_MFMA(0);
         WN_FENCE();
-        GM_READ(0, 2, buf);
+        GM_READ(0, 2);
         WN_FENCE();
-        GM_STORE_B(buf ^ 1, 0, 4);
         GM_MFMA(1);
         WN_FENCE();
-        GM_READ(1, 3, buf);
+        GM_READ(1, 3);
         WN_FENCE();
-        GM_STORE_B(buf ^ 1, 4, 8);
-        GM_LOAD_B(c2);
         GM_MFMA(0);
+        WN_FENCE();
+        GM_MFMA(1);
         WN_FENCE();
         __syncthreads();
-        GM_READ(0, 0, buf ^ 1);
-        WN_FENCE();
-        GM_MFMA(1);
+        GM_STORE();
+        GM_LOAD(c2);
+        __syncthreads();
+        GM_READ(0, 0);
         WN_FENCE();
     }
 
-    // epilogue: lane = channel (li) within 4 blocks of 32, accumulator register = pixel row
-    float sc[4], sh[4];
-    bool co_ok[4];
+    // epilogue: lane = channel (li) within RN blocks of 32, accumulator register = pixel row
+    float sc[RN], sh[RN];
+    bool co_ok[RN];
+    const int co0 = cb * 256 + cs * TN + wn * 32 * RN + li;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int co = cb * 256 + wn * 128 + j * 32 + li;
+    for (int j = 0; j < RN; ++j) {
+        const int co = co0 + j * 32;
         co_ok[j] = co < a.Cout;
         sc[j] = (co_ok[j] && a.scale) ? a.scale[co] : 1.f;
         sh[j] = (co_ok[j] && a.shift) ? a.shift[co] : 0.f;
     }
     const long long prow = p0 + wm * 32 * RM + 4 * lh;  // + i * 32 + (r & 3) + 8 * (r >> 2)
-    float *yb = a.y + prow * a.y_ld + cb * 256 + wn * 128 + li;
+    float *yb = a.y + prow * a.y_ld + co0;
     const long long rows_left = a.M - prow;
 #pragma unroll
     for (int i = 0; i < RM; ++i) {
@@ -853,7 +581,7 @@ __global__ __launch_bounds__(256, 1) void srf_conv1x1_nhwc_k(GemmArgs a)
             float *yp = yb + (long long)dr * a.y_ld;
             if (dr < rows_left) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < RN; ++j) {
                     float v = __fmaf_rn(acc[i][j][r], sc[j], sh[j]);
                     if (a.relu) v = fmaxf(v, 0.f);
                     if (co_ok[j]) yp[j * 32] = v;
@@ -931,22 +659,6 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
         SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<8>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
         attr_set[dev] = true;
     }
-    static const int w8 = getenv("SRF_WINO_W8") ? atoi(getenv("SRF_WINO_W8")) : 0;  // A/B knob: 1 = the 8-wave kernel (measured slower)
-    static bool attr8_set[64] = {false};
-    if (w8) {
-        if (!attr8_set[dev]) {
-            SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_w8_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
-            SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_w8_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
-            SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_w8_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
-            attr8_set[dev] = true;
-        }
-        const dim3 g8((unsigned)blocks), b8(512);
-        if (dbg == 1) hipLaunchKernelGGL(srf_wino3x3_w8_k<1>, g8, b8, WN_LDS_BYTES, (hipStream_t)stream, a);
-        else if (dbg == 4) hipLaunchKernelGGL(srf_wino3x3_w8_k<4>, g8, b8, WN_LDS_BYTES, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(srf_wino3x3_w8_k<0>, g8, b8, WN_LDS_BYTES, (hipStream_t)stream, a);
-        SRF_LAUNCH_CHECK();
-        return SRF_OK;
-    }
     const dim3 grid((unsigned)blocks), blk(256);
     switch (dbg) {
     case 1: hipLaunchKernelGGL(srf_wino3x3_k<1>, grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a); break;
@@ -1004,23 +716,20 @@ extern "C" int srf_conv1x1_nhwc(const float *x, long long M, int K, long long x_
     SRF_HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return SRF_EUNSUPPORTED;
     static bool attr_set[64] = {false};
-    constexpr int LDS4 = 2 * (8 * 256 + 8 * 256) * 16, LDS2 = 2 * (8 * 128 + 8 * 256) * 16;
+    constexpr int LDS_BIG = (8 * 256 + 8 * 256) * 16, LDS_STD = (8 * 128 + 8 * 128) * 16;
     if (!attr_set[dev]) {
-        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_conv1x1_nhwc_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
-        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_conv1x1_nhwc_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_conv1x1_nhwc_k<4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BIG));
         attr_set[dev] = true;
     }
-    // 256-pixel tiles unless that leaves most of the 256 CUs without a workgroup
-    const long long wg4 = (long long)srf_ceil_div(M, 256) * a.coutBlocks;
-    const bool small = wg4 < 512;
-    const int TM = small ? 128 : 256;
+    static const int big = getenv("SRF_GEMM_BIG") ? atoi(getenv("SRF_GEMM_BIG")) : 0;
+    const int TM = big ? 256 : 128, ncs = big ? 1 : 2;
     a.mblocks = srf_ceil_div(M, TM);
-    const long long blocks = ((a.mblocks + 7) / 8) * 8 * a.coutBlocks;
+    const long long blocks = ((a.mblocks + 7) / 8) * 8 * a.coutBlocks * ncs;
     if (blocks >= (1ll << 31)) return SRF_EUNSUPPORTED;
-    if (small)
-        hipLaunchKernelGGL(srf_conv1x1_nhwc_k<2>, dim3((unsigned)blocks), dim3(256), LDS2, (hipStream_t)stream, a);
+    if (big)
+        hipLaunchKernelGGL((srf_conv1x1_nhwc_k<4, 4, 1>), dim3((unsigned)blocks), dim3(256), LDS_BIG, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(srf_conv1x1_nhwc_k<4>, dim3((unsigned)blocks), dim3(256), LDS4, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((srf_conv1x1_nhwc_k<2, 2, 3>), dim3((unsigned)blocks), dim3(256), LDS_STD, (hipStream_t)stream, a);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }
