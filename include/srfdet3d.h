@@ -185,6 +185,21 @@ int srf_spconv_fwd(const float *in, int A_in, int Cin, const float *W, int K, co
                    int A_out, int Cout, const float *alpha, const float *beta, const float *residual, int relu,
                    float *out, const int *rows_dev, srf_stream_t stream);
 
+/* Gradients of the sparse convolution, for the configurations that train the LiDAR branch (the reference does so in every
+ * L-only config: tools/train.py:221-234 freezes it only under `freeze_lidar_components`); they stand where spconv's
+ * indice_conv_backward runs.
+ * srf_spconv_transpose_rulebook: nbrT (K x A_in) with nbrT[k][i] = o <=> nbr[k][o] = i, -1 elsewhere.
+ * srf_spconv_bwd_data: d_in[i] = sum_k W[k] d_out[nbrT[k][i]]; W_T is (K, Cout, Cin) row-major (each offset's matrix
+ *   transposed).  It is srf_spconv_fwd with the roles swapped, so Cin must be one of its output widths (16, 32, 64, 128).
+ *   A submanifold layer may pass nbrT = its own nbr with W_T's offsets reversed (the rulebook is symmetric).
+ * srf_spconv_bwd_weight: d_W[k][ci][co] = sum_o in[nbr[k][o]][ci] d_out[o][co], (K, Cin, Cout); Cin, Cout <= 128.  Row
+ *   ranges are combined with float atomics: reproducible to rounding, not bitwise. */
+int srf_spconv_transpose_rulebook(const int *nbr, int nbr_stride, int K, int A_out, int *nbrT, int A_in, srf_stream_t stream);
+int srf_spconv_bwd_data(const float *grad_out, int A_out, int Cout, const float *W_T, int K, const int *nbrT, int nbrT_stride,
+                        int A_in, int Cin, float *grad_in, srf_stream_t stream);
+int srf_spconv_bwd_weight(const float *in, int A_in, int Cin, const float *grad_out, int A_out, int Cout, const int *nbr,
+                          int nbr_stride, int K, float *grad_W, srf_stream_t stream);
+
 /* Fast path of K5 for constant weights: re-lay W once (srf_spconv_pack_weights -> packed, of
  * srf_spconv_packed_weight_bytes bytes) into the LDS operand image of the kernel, then call srf_spconv_fwd_packed with
  * the same remaining arguments.  Results are bit-identical to srf_spconv_fwd.  Cout in {32, 64, 128}, Cin % 4 == 0. */

@@ -48,6 +48,9 @@ SIGNATURES = {
                                              _P]),
     "srf_rulebook_strided_pairs": (c_int, [c_int, _HI, _P, c_int, _P, c_int, _P, _P, _P]),
     "srf_spconv_fwd": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
+    "srf_spconv_transpose_rulebook": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
+    "srf_spconv_bwd_data": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, _P]),
+    "srf_spconv_bwd_weight": (c_int, [_P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, _P]),
     "srf_spconv_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int]),
     "srf_spconv_pack_weights": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "srf_spconv_fwd_packed": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),

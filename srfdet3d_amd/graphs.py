@@ -67,7 +67,7 @@ def _validate(graph, outputs, reference, what, rtol=1e-3, atol=1e-4):
 
 
 class _StaticMetas:
-    """The head reads `lidar2img` through a device tensor cached in the metas ("srf_lidar2img_dev").  A captured graph
+    """The head reads `lidar2img` through a device tensor found in the metas ("srf_lidar2img_static").  A captured graph
     would keep reading the capture-time matrices, while real data brings new ones every frame (ego-motion between the
     camera and LiDAR timestamps): the graph therefore owns ONE persistent device buffer, captured by address, that is
     refreshed with a small host->device copy before a replay whenever the matrices changed."""
@@ -78,7 +78,7 @@ class _StaticMetas:
         self.dev = None
         if self.host is not None:
             self.dev = torch.from_numpy(self.host).to(device)
-            self.metas[0]["srf_lidar2img_dev"] = self.dev
+            self.metas[0]["srf_lidar2img_static"] = self.dev  # owned and refreshed by the graph; the head uses it as is
 
     def refresh(self, img_metas):
         if self.dev is None:

@@ -166,6 +166,11 @@ class VoxelMap:
         self.point2voxel = self.point2voxel[:n]
 
     def reduce(self, feats, mode):
+        if torch.is_grad_enabled() and feats.requires_grad:
+            return _ScatterReduceFn.apply(feats, self, mode)
+        return self._reduce(feats, mode)
+
+    def _reduce(self, feats, mode):
         feats = _dev(feats, "feats", torch.float32)
         C = feats.shape[1]
         if self.static:
@@ -373,10 +378,20 @@ def spconv_tiles(nbr, rows_dev=None):
 
 
 def spconv_fwd(feats, weight, nbr, alpha=None, beta=None, residual=None, relu=False, pair_counts=None, packed=None,
-               rows_dev=None, tiles=None):
+               rows_dev=None, tiles=None, subm=False):
     """feats (A_in,Cin); weight (K,Cin,Cout); nbr (K,A_out) (row stride nbr.stride(0)) -> (A_out,Cout).
     `packed` = pack_spconv_weights(weight) selects the packed-weight kernel (Cout >= 32, Cin % 4 == 0);
     `tiles` = spconv_tiles(nbr) lets its 128-channel variant balance the workgroups by pair count."""
+    if torch.is_grad_enabled() and (feats.requires_grad or weight.requires_grad or (residual is not None and residual.requires_grad)
+                                    or (alpha is not None and alpha.requires_grad) or (beta is not None and beta.requires_grad)):
+        # a gradient is wanted: plain convolution through the autograd Function (srf_spconv_bwd_data / _bwd_weight), the
+        # epilogue as torch ops so that autograd differentiates it
+        out = _SpconvFn.apply(feats, weight, nbr, bool(subm))
+        if alpha is not None:
+            out = out * alpha + beta
+        if residual is not None:
+            out = out + residual
+        return torch.relu(out) if relu else out
     feats = _dev(feats, "feats", torch.float32)
     weight = _dev(weight, "weight", torch.float32)
     if not nbr.is_cuda or nbr.dtype != torch.int32 or nbr.stride(1) != 1:
@@ -426,6 +441,12 @@ class _SpconvRecord:
 
 
 def densify(feats, indices, batch, spatial_shape):
+    if torch.is_grad_enabled() and feats.requires_grad:
+        return _DensifyFn.apply(feats, indices, batch, tuple(spatial_shape))
+    return _densify(feats, indices, batch, spatial_shape)
+
+
+def _densify(feats, indices, batch, spatial_shape):
     feats = _dev(feats, "feats", torch.float32)
     indices = _dev(indices, "indices", torch.int32)
     A, C = feats.shape
@@ -433,6 +454,108 @@ def densify(feats, indices, batch, spatial_shape):
     out = _empty((batch, C, D, H, W), torch.float32, feats.device)
     check(_lib.lib().srf_densify(_ptr(feats), _ptr(indices), A, C, batch, D, H, W, _ptr(out), 1, _stream()), "densify")
     return out
+
+
+# ---------------------------------------------------------------------------------------------- gradients of the sparse half
+def spconv_transpose_rulebook(nbr, a_in):
+    """(K, A_out) output-stationary table -> (K, A_in): nbrT[k][i] = o <=> nbr[k][o] = i."""
+    K, A_out = nbr.shape
+    nbrT = _empty((K, max(a_in, 1)), torch.int32, nbr.device)
+    check(_lib.lib().srf_spconv_transpose_rulebook(_ptr(nbr), nbr.stride(0) if A_out > 0 else 0, K, A_out, _ptr(nbrT), a_in,
+                                                   _stream()), "spconv_transpose_rulebook")
+    return nbrT[:, :a_in]
+
+
+def _spconv_plain(feats, weight, nbr):
+    """out[o] = sum_k W[k]^T in[nbr[k][o]] without epilogue; output widths below 16 run zero-padded on the 16-wide kernel."""
+    K, Cin, Cout = weight.shape
+    pad = 0
+    if Cout not in (16, 32, 64, 128):
+        if Cout > 16:
+            raise RuntimeError(f"srfdet3d spconv: no kernel for {Cout} output channels")
+        pad = 16 - Cout
+        weight = torch.nn.functional.pad(weight, (0, pad))
+    with torch.no_grad():
+        out = spconv_fwd(feats.detach().contiguous(), weight.detach().contiguous(), nbr)
+    return out[:, :Cout].contiguous() if pad else out
+
+
+class _SpconvFn(torch.autograd.Function):
+    """Sparse convolution with gradients: data gradient = the forward kernel on the transposed rulebook with transposed
+    weights, weight gradient = srf_spconv_bwd_weight (csrc/spconv_bwd.hip)."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, nbr, subm):
+        ctx.save_for_backward(feats, weight, nbr)
+        ctx.subm = subm
+        return _spconv_plain(feats, weight, nbr)
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, weight, nbr = ctx.saved_tensors
+        g = g.contiguous()
+        K, Cin, Cout = weight.shape
+        gf = gw = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().transpose(1, 2)
+            if ctx.subm:   # symmetric rulebook: offset k of the transpose is offset K - 1 - k of the table itself
+                nbrT, wt = nbr, wt.flip(0)
+            else:
+                nbrT = spconv_transpose_rulebook(nbr, feats.shape[0])
+            gf = _spconv_plain(g, wt.contiguous(), nbrT)
+        if ctx.needs_input_grad[1]:
+            gw = _empty((K, Cin, Cout), torch.float32, g.device)
+            f = feats.detach().contiguous()
+            check(_lib.lib().srf_spconv_bwd_weight(_ptr(f), f.shape[0], Cin, _ptr(g), g.shape[0], Cout, _ptr(nbr),
+                                                   nbr.stride(0) if nbr.shape[1] > 0 else 0, K, _ptr(gw), _stream()),
+                  "spconv_bwd_weight")
+        return gf, gw, None, None
+
+
+class _DensifyFn(torch.autograd.Function):
+    """SparseConvTensor.dense(): scatter forward, gather backward."""
+
+    @staticmethod
+    def forward(ctx, feats, indices, batch, spatial_shape):
+        ctx.save_for_backward(indices)
+        return _densify(feats.detach(), indices, batch, spatial_shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        i = idx.long()
+        ok = (i[:, 0] >= 0).unsqueeze(1)
+        i = i.clamp(min=0)
+        return g[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]] * ok, None, None, None
+
+
+class _ScatterReduceFn(torch.autograd.Function):
+    """DynamicScatter mean / max over the points of a voxel.  mean: every point receives d_voxel / count; max: the gradient
+    of a (voxel, channel) goes to the first point (in input order) that attains the maximum."""
+
+    @staticmethod
+    def forward(ctx, feats, vmap, mode):
+        out = vmap._reduce(feats.detach(), mode)
+        ctx.vmap, ctx.mode = vmap, mode
+        ctx.save_for_backward(feats, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, out = ctx.saved_tensors
+        vm = ctx.vmap
+        p2v = vm.point2voxel.long()
+        ok = p2v >= 0
+        pv = p2v.clamp(min=0)
+        if ctx.mode == "mean":
+            cnt = vm.counts[:vm.M].clamp(min=1).to(g.dtype).unsqueeze(1)
+            return (g / cnt)[pv] * ok.unsqueeze(1), None, None
+        n, C = feats.shape
+        hit = (feats.detach() == out[pv]) & ok.unsqueeze(1)
+        cand = torch.where(hit, torch.arange(n, device=g.device).unsqueeze(1).expand(n, C), torch.full((1, 1), n, device=g.device))
+        first = torch.full((vm.M, C), n, dtype=torch.long, device=g.device).scatter_reduce(0, pv.unsqueeze(1).expand(n, C), cand, "amin")
+        sel = hit & (first[pv] == torch.arange(n, device=g.device).unsqueeze(1))
+        return g[pv] * sel, None, None
 
 
 # ---------------------------------------------------------------------------------------------- RoI gather

@@ -175,15 +175,21 @@ class _StageBase(BaseModule):
 
     @staticmethod
     def _lidar2img(img_metas, like):
-        cached = img_metas[0].get("srf_lidar2img_dev") if isinstance(img_metas[0], dict) else None
-        if cached is not None and cached.device == like.device:
-            return cached
+        static = img_metas[0].get("srf_lidar2img_static") if isinstance(img_metas[0], dict) else None
+        if static is not None:
+            return static  # a hipGraph's persistent buffer (graphs._StaticMetas keeps it current)
         m = np.asarray([meta["lidar2img"] for meta in img_metas], dtype=np.float32)
         if m.ndim == 3:  # KITTI: one camera, (bs,4,4) (srfdet_head.py:2462-2464)
             m = m[:, None]
-        t = torch.from_numpy(np.ascontiguousarray(m)).to(like.device)
+        m = np.ascontiguousarray(m)
+        # the device copy is cached in the metas (one upload per frame, not one per stage: :2452-2456) next to the host
+        # matrices it was made from: a metas dict that comes back with other matrices or another batch size is re-uploaded
+        cached = img_metas[0].get("srf_lidar2img_dev") if isinstance(img_metas[0], dict) else None
+        if cached is not None and cached[0].device == like.device and cached[1].shape == m.shape and np.array_equal(cached[1], m):
+            return cached[0]
+        t = torch.from_numpy(m).to(like.device)
         if isinstance(img_metas[0], dict):
-            img_metas[0]["srf_lidar2img_dev"] = t
+            img_metas[0]["srf_lidar2img_dev"] = (t, m)
         return t
 
     def _img_rois_feats(self, img_feats, rois_img, pooler_img, bs, n_p, n_cam):

@@ -18,6 +18,10 @@ def box3d_multiclass_nms(boxes, scores, score_thr, max_num, nms_thr):
     cand = (scores > score_thr).nonzero(as_tuple=False)  # (m, 2): box index, class -- row-major in box index
     if cand.shape[0] == 0:
         return boxes.new_zeros((0, boxes.shape[1])), scores.new_zeros((0,)), scores.new_zeros((0,), dtype=torch.long)
+    if cand.shape[0] > NMS_MAX_BOXES:
+        # more (box, class) pairs than one srf_nms_rotated launch takes (np = 900 x 10 classes with an untrained model):
+        # run the classes one by one like the reference's loop -- a class never has more than n boxes
+        return _per_class_nms(boxes, scores, score_thr, max_num, nms_thr)
     # class-major order, original box order inside a class (what the per-class loop yields)
     order = torch.argsort(cand[:, 1] * n + cand[:, 0])
     bi, ci = cand[order, 0], cand[order, 1]
@@ -31,6 +35,30 @@ def box3d_multiclass_nms(boxes, scores, score_thr, max_num, nms_thr):
     k2 = torch.argsort(ci[keep] * 4 - s[keep].clamp(0, 1) * 2, stable=True)
     keep = keep[k2]
     out_b, out_s, out_l = boxes[bi[keep]], s[keep], ci[keep]
+    if out_b.shape[0] > max_num:
+        top = out_s.sort(descending=True)[1][:max_num]
+        out_b, out_s, out_l = out_b[top], out_s[top], out_l[top]
+    return out_b, out_s, out_l
+
+
+NMS_MAX_BOXES = 4096  # boxes per srf_nms_rotated launch (64 mask words per row)
+
+
+def _per_class_nms(boxes, scores, score_thr, max_num, nms_thr):
+    out_b, out_s, out_l = [], [], []
+    for c in range(scores.shape[1]):
+        idx = (scores[:, c] > score_thr).nonzero(as_tuple=False).squeeze(1)
+        if idx.numel() == 0:
+            continue
+        if idx.numel() > NMS_MAX_BOXES:  # keep the best ones: anything below them cannot reach the top max_num anyway
+            idx = idx[scores[idx, c].topk(NMS_MAX_BOXES).indices]
+        keep = idx[ops.nms_rotated(boxes[idx][:, [0, 1, 3, 4, 6]].contiguous(), scores[idx, c], nms_thr)]  # descending score
+        out_b.append(boxes[keep])
+        out_s.append(scores[keep, c])
+        out_l.append(torch.full((keep.numel(),), c, dtype=torch.long, device=boxes.device))
+    if not out_b:
+        return boxes.new_zeros((0, boxes.shape[1])), scores.new_zeros((0,)), scores.new_zeros((0,), dtype=torch.long)
+    out_b, out_s, out_l = torch.cat(out_b), torch.cat(out_s), torch.cat(out_l)
     if out_b.shape[0] > max_num:
         top = out_s.sort(descending=True)[1][:max_num]
         out_b, out_s, out_l = out_b[top], out_s[top], out_l[top]

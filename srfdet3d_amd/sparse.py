@@ -201,7 +201,7 @@ class _SparseConv(SparseModule):
             if tiles is None:
                 tiles = x.indice_dict[tkey] = ops.spconv_tiles(nbr, rows_dev)
         feats = ops.spconv_fwd(x.features, w, nbr, alpha, beta, residual, relu, pair_counts=counts, packed=packed,
-                               rows_dev=rows_dev, tiles=tiles)
+                               rows_dev=rows_dev, tiles=tiles, subm=self.subm)
         return SparseConvTensor(feats, out_idx, oshape, x.batch_size, x.indice_dict, rows_dev)
 
 
