@@ -7,9 +7,12 @@ driver launches this file under torch.distributed.run and every rank runs K fram
 are independent: no data-path collective); the job's time is the max over ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline     -- the dominant hand-written kernel (the 128->128 SubM sparse conv, srf_spconv_packed_k, f32 MFMA), its
-                  algorithmic FLOPs per launch (2 * pairs * Cin * Cout) over its mean duration measured with HIP
-                  events on the launch stream inside the timed region, against the 157.3 TFLOP/s f32 MFMA peak;
+  roofline     -- the dominant hand-written kernel of the workload against the 157.3 TFLOP/s f32 MFMA peak, from HIP events
+                  on the launch stream around every launch: LC = srf_wino3x3_k (the 89 Winograd 3x3 launches of the
+                  camera branch: FLOPs it executes on the MFMA = direct FLOPs / 2.25, direct-equivalent rate beside it);
+                  LiDAR-only = the 128->128 SubM sparse conv (2 * pairs * Cin * Cout per launch); plus
+                  roofline.stage = the WHOLE sparse-conv stage (all 21 launches: sum of algorithmic FLOPs and bytes over the sum
+                  of their event times, against the MFMA and the HBM peak) and, on LC, roofline.gemm for srf_conv1x1_nhwc_k;
   cpu_baseline -- oracle/pipeline.py (the CPU port of the same path: C/OpenMP operators + torch-CPU dense layers)
                   timed on this host, rank 0 at N=1 only.
 """
@@ -26,6 +29,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0         # same guide, "HBM3E peak BW" (spec)
+ROUND = "r02"                 # prefix of the profiles/ files this build's counter numbers live in
 
 WORKLOADS = {
     "nusc_L": dict(cfg="srfdet_voxel_nusc_L", desc="srfdet_voxel_nusc_L inference (LiDAR-only), synthetic 30k-pt sweep, "
@@ -66,6 +71,10 @@ def main():
                     help="LC only: replay the image-branch graph on a side stream beside the LiDAR half (about 3.8 %% "
                          "more frames/s, but the sparse-conv kernels then share the chip and their per-launch times "
                          "no longer describe the kernel; off by default so that `roofline` stays a kernel figure)")
+    ap.add_argument("--img-precomputed", action="store_true",
+                    help="LC only: the camera features (VoVNet -> FPN) are computed once before the timed region and reused: the "
+                         "'image features pre-computed' line of SURVEY.md 8d / BASELINE.md C3 (decoder + LiDAR path with the fusion "
+                         "RoI gather); never the headline number")
     ap.add_argument("--img-dtype", default="fp32", choices=["fp32", "fp16", "bf16"],
                     help="LC only: run the image backbone+neck under autocast (the reference's auto_fp16 mode); "
                          "fp32 is the default and the only setting the headline number may use")
@@ -88,7 +97,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from srfdet3d_amd import ops, synthetic, workloads
+    from srfdet3d_amd import graphs, nhwc, ops, synthetic, workloads
+    nhwc_on = nhwc.enabled()
     from srfdet3d_amd.compat.boxes import LiDARInstance3DBoxes
 
     wl = WORKLOADS[args.workload]
@@ -115,6 +125,14 @@ def main():
         img = torch.from_numpy(synthetic.camera_images(3000)).to(dev)
         metas[0]["lidar2img"] = [m for m in synthetic.camera_rig()]
 
+    if args.img_precomputed and model.use_img:
+        # the camera branch runs once, here; the timed frames reuse its features (the fusion gather, img_convs included in
+        # the head, and everything on the LiDAR side still run per frame)
+        with torch.no_grad():
+            cached_feats = [f.clone() for f in model.extract_img_feat(img, metas)]
+        model._graphed_img = None
+        model.extract_img_feat = lambda *_a, **_k: cached_feats
+
     def step(i):
         with torch.no_grad():
             return model.simple_test(img, [frames[(rank + i) % n_pool]], metas)
@@ -128,7 +146,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ops.KERNEL_TIMING = {"spconv": []}  # HIP-event pairs around every sparse-conv launch of the timed region
+    ops.KERNEL_TIMING = {"spconv": [], "wino": [], "gemm": []}  # HIP-event pairs around every launch of the timed region
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -148,6 +166,20 @@ def main():
                 model.extract_bev([frames[(rank + i) % n_pool]])
         torch.cuda.synchronize()
         records = ops.KERNEL_TIMING["spconv"]
+    dense_source = roofline_source
+    if model.use_img and not ops.KERNEL_TIMING["wino"] and not args.img_precomputed:
+        # the camera branch replayed as a hipGraph: time its launches on 3 eager passes right after the timed region
+        dense_source = ("HIP events around the launches of 3 eager passes of the camera branch run right after the timed region "
+                        "(the timed frames replay it as a hipGraph; per-launch times inside it: profiles/)")
+        gi, model._graphed_img = model._graphed_img, None
+        with torch.no_grad():
+            for _ in range(3):
+                feats_ = model.extract_img_feat(img, metas)
+                if model.bbox_head.hidden_dim != model.bbox_head.feat_channels_img:
+                    model.bbox_head._img_convs_only(feats_)  # the head's 3x3 convolutions on the camera levels: same kernel
+        torch.cuda.synchronize()
+        model._graphed_img = gi
+    wino_rec, gemm_rec = ops.KERNEL_TIMING["wino"], ops.KERNEL_TIMING["gemm"]
     ops.KERNEL_TIMING = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -155,30 +187,67 @@ def main():
         elapsed = t.item()
 
     if rank == 0:
-        # dominant kernel: the 128 -> 128, 27-offset SubM conv (4 launches per frame on the 5x184x184 level)
+        def _traffic(name):
+            """HBM bytes per launch from the rocprofv3 --pmc passes of THIS round (tools/measure_traffic.py writes the file)."""
+            path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_{name}_traffic.json")
+            if not os.path.exists(path):
+                return None
+            with open(path) as fh:
+                return json.load(fh).get("traffic_bytes_per_launch")
+
+        # the 128 -> 128, 27-offset SubM conv (4 launches per frame on the 5x184x184 level)
         dom = [(s.elapsed_time(e), flops, byts) for (s, e, cin, cout, K, flops, byts) in records
                if cin == 128 and cout == 128 and K == 27]
-        roofline = None
+        spconv128 = None
         if dom:
             ms = sum(d[0] for d in dom) / len(dom)
             flops = sum(d[1] for d in dom) / len(dom)
             achieved = flops / (ms * 1e-3) / 1e12
-            # HBM traffic cannot be read from inside the process: it comes from the separate rocprofv3 --pmc passes
-            # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied) recorded under profiles/
-            traffic = None
-            direct = os.environ.get("SRF_SPCONV_DIRECT", "") == "1"  # developer switch of the C library: previous kernel
-            tpath = os.path.join(ROOT, "profiles", "r01_pmc_spconv128_traffic.json" if direct
-                                 else "r01_pmc_spconv128_gs_traffic.json")
-            if os.path.exists(tpath) and args.workload in ("nusc_L", "nusc_LC"):  # counted on a nuScenes-shaped sweep
-                with open(tpath) as fh:
-                    traffic = json.load(fh).get("traffic_bytes_per_launch")
-            kname = "srf_spconv_direct_k<32,4,2>" if direct else "srf_spconv_gs_k<4>"
-            roofline = dict(kernel=kname + " (SubM 3x3x3, 128->128, last level of the sparse encoder)", bound="mfma",
-                            achieved=round(achieved, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
-                            launches=len(dom), avg_us=round(ms * 1e3, 2), measured=roofline_source,
-                            algorithmic_flops_per_launch=int(flops),
-                            algorithmic_bytes_per_launch=int(sum(d[2] for d in dom) / len(dom)))
+            spconv128 = dict(kernel="srf_spconv_gs_k<4> (SubM 3x3x3, 128->128, last level of the sparse encoder)", bound="mfma",
+                             achieved=round(achieved, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                             frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                             traffic=_traffic("spconv128") if args.workload in ("nusc_L", "nusc_LC") else None,
+                             launches=len(dom), avg_us=round(ms * 1e3, 2), measured=roofline_source,
+                             algorithmic_flops_per_launch=int(flops),
+                             algorithmic_bytes_per_launch=int(sum(d[2] for d in dom) / len(dom)))
+        stage = None
+        if records:
+            rows = [(s.elapsed_time(e), flops, byts) for (s, e, cin, cout, K, flops, byts) in records]
+            nfr = max(1, len(dom) // 4) if dom else 1
+            ms, fl, by = sum(r[0] for r in rows), sum(r[1] for r in rows), sum(r[2] for r in rows)
+            stage = dict(name="sparse-conv stage: every srf_spconv_* launch of the encoder (21 per nuScenes frame)", launches=len(rows),
+                         ms_per_frame=round(ms / nfr, 4), gflop_per_frame=round(fl / nfr / 1e9, 3), mbytes_per_frame=round(by / nfr / 1e6, 2),
+                         tflops=round(fl / (ms * 1e-3) / 1e12, 3), frac_mfma=round(fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                         gbs=round(by / (ms * 1e-3) / 1e9, 1), frac_hbm=round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         measured=roofline_source)
+
+        def _dense(recs, kernel, name):
+            if not recs:
+                return None
+            t_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            direct, executed, byts = sum(r[3] for r in recs), sum(r[4] for r in recs), sum(r[5] for r in recs)
+            worst = max(recs, key=lambda r: r[0].elapsed_time(r[1]))
+            ach = executed / (t_ms * 1e-3) / 1e12
+            return dict(kernel=kernel, bound="mfma", achieved=round(ach, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / F32_MFMA_PEAK_TFLOPS, 4), traffic=_traffic(name), launches=len(recs),
+                        avg_us=round(t_ms * 1e3 / len(recs), 2), measured=dense_source,
+                        algorithmic_flops_per_launch=int(executed / len(recs)),
+                        direct_equivalent_tflops=round(direct / (t_ms * 1e-3) / 1e12, 3),
+                        algorithmic_bytes_per_launch=int(byts / len(recs)),
+                        longest_launch=dict(layer=worst[2], us=round(worst[0].elapsed_time(worst[1]) * 1e3, 1)),
+                        note="aggregate over all launches of the kernel in a frame: sum of FLOPs over sum of event times")
+
+        wino = _dense(wino_rec, "srf_wino3x3_k (Winograd F(2x2,3x3), every 3x3 / stride 1 convolution of VoVNet-99, the image FPN and "
+                                "img_convs; `achieved` counts the FLOPs it executes on the MFMA = direct FLOPs / 2.25)", "wino3x3")
+        gemm = _dense(gemm_rec, "srf_conv1x1_nhwc_k (the OSA concat 1x1 convolutions and the FPN laterals as one GEMM each)", "conv1x1")
+        if wino is not None:   # LC: the camera branch dominates the frame, its Winograd kernel is the dominant kernel
+            roofline = wino
+            roofline["gemm"] = gemm
+            roofline["spconv128"] = spconv128
+        else:
+            roofline = spconv128
+        if roofline is not None:
+            roofline["stage"] = stage
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pipeline
@@ -206,7 +275,11 @@ def main():
                    data="synthetic",
                    config=dict(workload=wl["desc"], num_proposals=args.np, points_per_frame=n_points,
                                frames_per_rank=args.steps, hip_graph_tail=not args.eager,
-                               whole_frame_graph=bool(getattr(model, "_graphed_frame", None) is not None), img_branch_overlap=bool(args.img_overlap and model.use_img), weights="seeded random init, randomised BN statistics",
+                               whole_frame_graph=bool(getattr(model, "_graphed_frame", None) is not None), img_branch_overlap=bool(args.img_overlap and model.use_img),
+                               img_features_precomputed=bool(args.img_precomputed and model.use_img),
+                               img_branch="channels-last on srf_wino3x3 / srf_conv1x1_nhwc" if (model.use_img and nhwc_on) else ("MIOpen" if model.use_img else None),
+                               graph_validation_failures=len(graphs.VALIDATION_LOG),
+                               weights="seeded random init, randomised BN statistics",
                                parallelism=f"replica per GPU x{world}, frames sharded, no data-path collective"),
                    roofline=roofline, cpu_baseline=cpu_baseline)
         print(json.dumps(out))

@@ -369,6 +369,20 @@ int srf_conv1x1_nhwc_pack_weights(const float *W, int Cout, int K, float *packed
 int srf_conv1x1_nhwc(const float *x, long long M, int K, long long x_ld, const float *W_packed, int Cout, const float *scale,
                      const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream);
 
+/* srf_conv_gemm_nhwc: Conv2d(Cin, Cout, (kh, kw), stride, padding) on channels-last activations as the GEMM of
+ * srf_conv1x1_nhwc with an implicit im2col (rows = output pixels, k = (tap, input channel)): the stride-2 3x3 layers of the
+ * path (VoVNet stem_3, vovnet.py stem; the first layer of SECONDCustom's later blocks, second_custom.py:41-52; the extra levels
+ * of the BEV FPN) -- deterministic k-ordered fma chains where MIOpen's channels-last choice is an atomic split-K kernel.
+ * W_packed = srf_conv1x1_nhwc_pack_weights(W reordered to (Cout, kh * kw * Cin), tap slowest).  Cin % 32 == 0, the input
+ * tensor below 2 GiB.  y: (N, Ho, Wo, y_ld), Ho = (H + 2 pad - kh) / stride + 1.
+ * srf_stem_conv_nchw: Conv2d(Cin <= 4, 64, 3, stride 2, padding 1) + scale / shift + ReLU from NCHW images to channels-last
+ * (VoVNet stem_1 on the 6 camera views); Wt is the (64, Cin, 3, 3) weight. */
+int srf_conv_gemm_nhwc(const float *x, int N, int H, int W, int Cin, long long x_ld, const float *W_packed, int Cout, int kh,
+                       int kw, int stride, int pad, const float *scale, const float *shift, int relu, float *y, long long y_ld,
+                       srf_stream_t stream);
+int srf_stem_conv_nchw(const float *x, int N, int Cin, int H, int W, const float *Wt, int Cout, const float *scale,
+                       const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream);
+
 /* ---- streaming layers of the channels-last camera branch (csrc/nhwc.hip); all take (N, H, W, ld) channel slices, C % 4 == 0,
  * 16-byte aligned pointers, ld % 4 == 0 ---------------------------------------------------------------------------------
  * srf_nhwc_affine: y = x * scale[(per_sample ? n : 0)][c] + shift[c] (+ residual), optional ReLU; scale / shift / residual

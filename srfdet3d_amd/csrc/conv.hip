@@ -425,6 +425,9 @@ struct GemmArgs {
     long long x_ld, y_ld, M;
     int K, Cout, coutBlocks, nchunk, relu;
     long long mblocks;
+    // convolution mode (CONV): rows are OUTPUT pixels (n, oy, ox), k runs over (tap, input channel): implicit im2col
+    int H, W, Ho, Wo, kw, stride, pad, cin_chunks;  // cin_chunks = Cin / 32
+    long long x_bytes;                               // extent of the input tensor (buffer descriptor range)
 };
 
 // W (Cout, K) row-major -> [chunk of 32][cout block of 256][channel 256][slot 8][4]; slot s of row co holds quad
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(256) void srf_conv1x1_nhwc_pack_k(const float *__re
 //           workgroups per CU: the waves of different workgroups fill each other's barrier / staging gaps (an f32 MFMA
 //           overlaps with another wave's vector and LDS instructions, not with its own wave's);
 //   <4, 4>: 256 x 256, 16 accumulators per wave, one workgroup per CU (kept for A/B timing: SRF_GEMM_BIG=1).
-template <int RM, int RN, int WPE>
+template <int RM, int RN, int WPE, bool CONV>
 __global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
 {
     constexpr int TM = 64 * RM, TN = 64 * RN;
@@ -469,23 +472,53 @@ __global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
     const long long p0 = mb * TM;
 
     __amdgpu_buffer_rsrc_t xrsrc;
-    {
+    if (CONV) {
+        xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    } else {
         long long rows = a.M - p0;
         if (rows > TM) rows = TM;
         xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x) + p0 * a.x_ld, 0, (int)(rows * a.x_ld * 4), 0x00020000);
     }
     const unsigned aoff0 = (unsigned)(((tid >> 3) * a.x_ld + (tid & 7) * 4) * 4);
     const unsigned aoff_step = (unsigned)(32 * a.x_ld * 4);  // 32 rows per j
+    // CONV: the output pixel of each of this thread's rows, as the input coordinates of tap (0, 0)
+    int cy[CONV ? 2 * RM : 1], cx[CONV ? 2 * RM : 1], cn[CONV ? 2 * RM : 1];
+    if (CONV) {
+#pragma unroll
+        for (int j = 0; j < 2 * RM; ++j) {
+            const long long p = p0 + (tid >> 3) + 32 * j;
+            const long long hw = (long long)a.Ho * a.Wo;
+            const int n = (int)(p / hw);
+            const int rem = (int)(p - n * hw);
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            cn[j] = p < a.M ? n : -1;
+            cy[j] = oy * a.stride - a.pad;
+            cx[j] = ox * a.stride - a.pad;
+        }
+    }
     const int a_dst = (tid >> 3) * 8 + ((tid & 7) ^ ((tid >> 4) & 7));  // + 256 j: rows advance by 32, the swizzle repeats
     const f32x4 *Bg = a.Wp + (size_t)cb * 2048 + cs * BSZ + tid;
     const size_t b_chunk_stride = (size_t)a.coutBlocks * 2048;
     f32x4 ar[NA], br[NB];
 #define GM_LOAD(CH)                                                                               \
     do {                                                                                          \
-        const int soff_ = (CH) * 128;                                                             \
-        _Pragma("unroll") for (int j_ = 0; j_ < NA; ++j_) {                                       \
-            auto v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(aoff0 + j_ * aoff_step), soff_, 0); \
-            ar[j_] = *reinterpret_cast<f32x4 *>(&v_);                                             \
+        if (CONV) {                                                                               \
+            const int tap_ = (CH) / a.cin_chunks, cc_ = (CH) - tap_ * a.cin_chunks;               \
+            const int ky_ = tap_ / a.kw, kx_ = tap_ - ky_ * a.kw;                                 \
+            _Pragma("unroll") for (int j_ = 0; j_ < NA; ++j_) {                                   \
+                const int iy_ = cy[j_] + ky_, ix_ = cx[j_] + kx_;                                 \
+                const bool ok_ = cn[j_] >= 0 && iy_ >= 0 && iy_ < a.H && ix_ >= 0 && ix_ < a.W;   \
+                const unsigned off_ = ok_ ? (unsigned)(((((long long)cn[j_] * a.H + iy_) * a.W + ix_) * a.x_ld + cc_ * 32 + (tid & 7) * 4) * 4) \
+                                          : 0x80000000u;                                          \
+                auto v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off_, 0, 0);          \
+                ar[j_] = *reinterpret_cast<f32x4 *>(&v_);                                         \
+            }                                                                                     \
+        } else {                                                                                  \
+            const int soff_ = (CH) * 128;                                                         \
+            _Pragma("unroll") for (int j_ = 0; j_ < NA; ++j_) {                                   \
+                auto v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(aoff0 + j_ * aoff_step), soff_, 0); \
+                ar[j_] = *reinterpret_cast<f32x4 *>(&v_);                                         \
+            }                                                                                     \
         }                                                                                         \
         const f32x4 *bb_ = Bg + (size_t)(CH) * b_chunk_stride;                                    \
         _Pragma("unroll") for (int j_ = 0; j_ < NB; ++j_) br[j_] = bb_[j_ * 256];                 \
@@ -712,13 +745,15 @@ extern "C" int srf_conv1x1_nhwc(const float *x, long long M, int K, long long x_
     a.coutBlocks = srf_ceil_div(Cout, 256);
     a.nchunk = K / 32;
     a.relu = relu;
+    a.H = a.W = a.Ho = a.Wo = a.kw = a.stride = a.pad = a.cin_chunks = 0;
+    a.x_bytes = 0;
     int dev = 0;
     SRF_HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return SRF_EUNSUPPORTED;
     static bool attr_set[64] = {false};
     constexpr int LDS_BIG = (8 * 256 + 8 * 256) * 16, LDS_STD = (8 * 128 + 8 * 128) * 16;
     if (!attr_set[dev]) {
-        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_conv1x1_nhwc_k<4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BIG));
+        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_conv1x1_nhwc_k<4, 4, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BIG));
         attr_set[dev] = true;
     }
     static const int big = getenv("SRF_GEMM_BIG") ? atoi(getenv("SRF_GEMM_BIG")) : 0;
@@ -727,9 +762,132 @@ extern "C" int srf_conv1x1_nhwc(const float *x, long long M, int K, long long x_
     const long long blocks = ((a.mblocks + 7) / 8) * 8 * a.coutBlocks * ncs;
     if (blocks >= (1ll << 31)) return SRF_EUNSUPPORTED;
     if (big)
-        hipLaunchKernelGGL((srf_conv1x1_nhwc_k<4, 4, 1>), dim3((unsigned)blocks), dim3(256), LDS_BIG, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((srf_conv1x1_nhwc_k<4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), LDS_BIG, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL((srf_conv1x1_nhwc_k<2, 2, 3>), dim3((unsigned)blocks), dim3(256), LDS_STD, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((srf_conv1x1_nhwc_k<2, 2, 3, false>), dim3((unsigned)blocks), dim3(256), LDS_STD, (hipStream_t)stream, a);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// srf_conv_gemm_nhwc: Conv2d(Cin, Cout, (kh, kw), stride, padding) on channels-last activations as the same GEMM with an
+// implicit im2col: rows = output pixels, k = (tap, input channel).  Used for the stride-2 3x3 layers (VoVNet stem_3, the
+// first layer of SECONDCustom's second block, the extra levels of the BEV FPN): MIOpen's channels-last choice for them is
+// a split-K kernel that accumulates with atomics (`igemm_fwd_gtcx35_nhwc_*_gkgs`), i.e. results that differ from run to
+// run in the last bits -- here every output is one k-ordered fma chain.  W_packed = srf_conv1x1_nhwc_pack_weights of the
+// weight reordered to (Cout, kh * kw * Cin) with the tap index slowest.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int srf_conv_gemm_nhwc(const float *x, int N, int H, int W, int Cin, long long x_ld, const float *W_packed, int Cout, int kh,
+                                  int kw, int stride, int pad, const float *scale, const float *shift, int relu, float *y, long long y_ld,
+                                  srf_stream_t stream)
+{
+    if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0 || x_ld < Cin || y_ld < Cout)
+        return SRF_EINVAL;
+    if (N == 0) return SRF_OK;
+    if (!x || !W_packed || !y) return SRF_EINVAL;
+    if ((Cin & 31) || (x_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)W_packed & 15)) return SRF_EUNSUPPORTED;
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return SRF_EINVAL;
+    const long long x_bytes = (long long)N * H * W * x_ld * 4;
+    if (x_bytes >= (1ll << 31)) return SRF_EUNSUPPORTED;
+    GemmArgs a;
+    a.x = x;
+    a.y = y;
+    a.Wp = reinterpret_cast<const f32x4 *>(W_packed);
+    a.scale = scale;
+    a.shift = shift;
+    a.x_ld = x_ld;
+    a.y_ld = y_ld;
+    a.M = (long long)N * Ho * Wo;
+    a.K = kh * kw * Cin;
+    a.Cout = Cout;
+    a.coutBlocks = srf_ceil_div(Cout, 256);
+    a.nchunk = a.K / 32;
+    a.relu = relu;
+    a.H = H;
+    a.W = W;
+    a.Ho = Ho;
+    a.Wo = Wo;
+    a.kw = kw;
+    a.stride = stride;
+    a.pad = pad;
+    a.cin_chunks = Cin / 32;
+    a.x_bytes = x_bytes;
+    a.mblocks = srf_ceil_div(a.M, 128);
+    const long long blocks = ((a.mblocks + 7) / 8) * 8 * a.coutBlocks * 2;
+    if (blocks >= (1ll << 31)) return SRF_EUNSUPPORTED;
+    hipLaunchKernelGGL((srf_conv1x1_nhwc_k<2, 2, 3, true>), dim3((unsigned)blocks), dim3(256), (8 * 128 + 8 * 128) * 16, (hipStream_t)stream, a);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// srf_stem_conv_nchw: the first layer of the image backbone, Conv2d(Cin <= 4, Cout, 3, stride 2, padding 1) + scale / shift
+// + ReLU, reading the NCHW camera images and writing channels-last (VoVNet stem_1: 3 -> 64 on 6 x 928 x 1600; 7.7 GFLOP,
+// HBM-bound: 107 MB in, 570 MB out).  256 threads = 16 output pixels x 16 channel quads (Cout == 64); the 27 x 64
+// weights sit in LDS; taps summed in (ci, ky, kx) order, one fma chain per output.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void srf_stem_conv_nchw_k(const float *__restrict__ x, int N, int Cin, int H, int W, int Ho, int Wo,
+                                                           const float *__restrict__ wt, const float *__restrict__ scale,
+                                                           const float *__restrict__ shift, int relu, float *__restrict__ y, long long y_ld)
+{
+    __shared__ f32x4 s_wt[36][16];  // [ci * 9 + ky * 3 + kx][channel quad]
+    const int tid = threadIdx.x;
+    for (int e = tid; e < Cin * 9 * 16; e += 256) {
+        const int t = e >> 4, cq = e & 15;
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = wt[(size_t)(cq * 4 + c) * Cin * 9 + t];
+        s_wt[t][cq] = v;
+    }
+    __syncthreads();
+    const int cq = tid & 15;
+    const long long p = (long long)blockIdx.x * 16 + (tid >> 4);
+    const long long total = (long long)N * Ho * Wo;
+    if (p >= total) return;
+    const int ox = (int)(p % Wo);
+    const long long r = p / Wo;
+    const int oy = (int)(r % Ho), n = (int)(r / Ho);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float *xc = x + ((size_t)n * Cin + ci) * H * W;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                const float v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xc[(size_t)iy * W + ix] : 0.f;
+                const f32x4 w4 = s_wt[ci * 9 + ky * 3 + kx][cq];
+                acc[0] = __fmaf_rn(v, w4[0], acc[0]);
+                acc[1] = __fmaf_rn(v, w4[1], acc[1]);
+                acc[2] = __fmaf_rn(v, w4[2], acc[2]);
+                acc[3] = __fmaf_rn(v, w4[3], acc[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float o = acc[c];
+        if (scale) o = __fmaf_rn(o, scale[cq * 4 + c], shift ? shift[cq * 4 + c] : 0.f);
+        else if (shift) o = __fadd_rn(o, shift[cq * 4 + c]);
+        if (relu) o = fmaxf(o, 0.f);
+        acc[c] = o;
+    }
+    *reinterpret_cast<f32x4 *>(y + p * y_ld + cq * 4) = acc;
+}
+
+extern "C" int srf_stem_conv_nchw(const float *x, int N, int Cin, int H, int W, const float *Wt, int Cout, const float *scale,
+                                  const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream)
+{
+    if (N < 0 || Cin <= 0 || H <= 0 || W <= 0 || y_ld < Cout) return SRF_EINVAL;
+    if (Cin > 4 || Cout != 64 || (y_ld & 3) || ((uintptr_t)y & 15)) return SRF_EUNSUPPORTED;
+    if (N == 0) return SRF_OK;
+    if (!x || !Wt || !y) return SRF_EINVAL;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo;
+    hipLaunchKernelGGL(srf_stem_conv_nchw_k, dim3(srf_ceil_div(total, 16)), dim3(256), 0, (hipStream_t)stream, x, N, Cin, H, W, Ho, Wo, Wt, scale,
+                       shift, relu, y, y_ld);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

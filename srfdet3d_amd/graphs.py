@@ -39,12 +39,23 @@ def _graph_safe_convs(safe=True):
     return torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True)
 
 
+VALIDATION_LOG = []  # one entry per capture whose 3-replay validation failed: (what, attempt, message); bench.py reports it
+
+
 def _capture_with_fallback(capture):
-    """capture(safe) -> entry; normal MIOpen algorithms first, deterministic ones if the replay check fails."""
+    """capture(safe) -> entry; normal MIOpen algorithms first, deterministic ones if the replay check fails.  Every failed
+    validation is logged (VALIDATION_LOG) and warned about: the retry must not hide that a capture went wrong."""
+    import warnings
     try:
         return capture(False)
-    except GraphValidationError:
-        return capture(True)
+    except GraphValidationError as err:
+        VALIDATION_LOG.append(("default algorithms", str(err)))
+        warnings.warn(f"srfdet3d_amd: hipGraph validation failed, recapturing with deterministic algorithms: {err}")
+        try:
+            return capture(True)
+        except GraphValidationError as err2:
+            VALIDATION_LOG.append(("deterministic algorithms", str(err2)))
+            raise
 
 
 class GraphValidationError(RuntimeError):

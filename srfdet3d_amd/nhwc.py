@@ -10,7 +10,8 @@ The torch modules stay the owners of the parameters (state_dict names untouched)
   torch.cat of vovnet.py:205-210 is never built;
 * eSE: pixel mean (`srf_nhwc_colmean`) -> fc + hard sigmoid (`srf_ese_gate`) -> gate multiply + identity add in one pass
   that writes straight into slice 0 of the next block's buffer (`srf_nhwc_affine`);
-* the two stride-2 stem convolutions stay on MIOpen (channels_last tensors in, channels_last out; 1.3 % of the FLOPs).
+* the stride-2 stem layers: stem_1 (3 -> 64) is a streaming kernel from the NCHW images to channels-last
+  (`srf_stem_conv_nchw`), stem_3 an implicit-im2col GEMM (`srf_conv_gemm_nhwc`); nothing of the branch runs on MIOpen.
 
 Tensors handed to the rest of the model are logical NCHW views with channels_last strides, so every consumer that only
 looks at shapes keeps working and the RoI gather finds its channels-last operand without a copy.
@@ -117,6 +118,11 @@ def vovnet_supported(net, x):
             return False
     if not (wino_ok(stem[3], stem[3].in_channels) and stem[3].bias is None):
         return False
+    c0, c6 = stem[0], stem[6]
+    if not (c0.kernel_size == (3, 3) and c0.stride == (2, 2) and c0.padding == (1, 1) and c0.groups == 1 and c0.in_channels <= 4
+            and c0.out_channels == 64 and c6.kernel_size == (3, 3) and c6.stride == (2, 2) and c6.padding == (1, 1)
+            and strided_ok(c6, c6.in_channels)):
+        return False
     for name in net.stage_names:
         for m in getattr(net, name).children():
             if isinstance(m, nn.MaxPool2d):
@@ -163,27 +169,17 @@ def vovnet_forward(net, x):
     from .plugin.vovnet import OSAModule
     out = OrderedDict()
     stem = list(net.stem.children())
-    # stem_1 (3 -> 64, stride 2) on MIOpen, BatchNorm + ReLU in place
-    y = stem[0](x.contiguous(memory_format=torch.channels_last))
-    if not is_channels_last(y):
-        y = y.contiguous(memory_format=torch.channels_last)
-    y = nhwc_view(y)
-    s, b = _affine_of(stem[0], stem[1])
-    ops.nhwc_affine(y, s, b, True, out=y)
-    # stem_2 (64 -> 64) Winograd, stem_3 (64 -> 128, stride 2) on MIOpen
+    # stem_1 (3 -> 64, stride 2): NCHW images -> channels-last, BatchNorm + ReLU in the same kernel
+    s1, b1 = _affine_of(stem[0], stem[1])
+    y = ops.stem_conv_nchw(x.contiguous(), stem[0].weight, s1, b1, True)
+    # stem_2 (64 -> 64) Winograd; stem_3 (64 -> 128, stride 2) implicit-im2col GEMM, written straight into the first block's buffer
     y = conv3x3(y, stem[3], stem[4], True)
-    y = stem[6](nchw_view(y))
-    if not is_channels_last(y):
-        y = y.contiguous(memory_format=torch.channels_last)
-    y = nhwc_view(y)
-    s3, b3 = _affine_of(stem[6], stem[7])
     cur = None          # finished NHWC tensor (stage output) when not already inside a block buffer
-    pending = (y, s3, b3)  # stem output still needs its BatchNorm + ReLU: applied while it is written into the first buffer
+    pending = y         # stem_2 output: stem_3 runs when the first buffer exists
     if "stem" in net._out_features:
-        ops.nhwc_affine(y, s3, b3, True, out=y)
+        cur = conv_strided(y, stem[6], stem[7], True)
         pending = None
-        cur = y
-        out["stem"] = nchw_view(y)
+        out["stem"] = nchw_view(cur)
     for name in net.stage_names:
         mods = list(getattr(net, name).children())
         blocks = [m for m in mods if isinstance(m, OSAModule)]
@@ -191,16 +187,15 @@ def vovnet_forward(net, x):
         first = blocks[0]
         cin = _cbr(first.layers[0])[0].in_channels
         width = sum(_cbr(l)[0].out_channels for l in first.layers)
-        if pending is not None:
-            src = pending[0]
-        else:
-            src = cur
+        src = pending if pending is not None else cur
         N, H, W, _ = src.shape
-        if pool:
+        if pending is not None:
+            H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1   # stem_3: 3x3, stride 2, padding 1
+        elif pool:
             H, W = ops.pool3s2_out(H), ops.pool3s2_out(W)
         buf = torch.empty((N, H, W, cin + width), dtype=torch.float32, device=src.device)
         if pending is not None:
-            ops.nhwc_affine(pending[0], pending[1], pending[2], True, out=buf[..., :cin])
+            conv_strided(pending, stem[6], stem[7], True, out=buf[..., :cin])
             pending = None
         elif pool:
             ops.nhwc_maxpool3s2_ceil(src, out=buf[..., :cin])
@@ -223,14 +218,80 @@ def vovnet_forward(net, x):
     return out
 
 
+def _strided_weights(conv):
+    w = conv.weight
+    return _cached(conv, "_srf_cgemm", (w._version, w.data_ptr()), lambda: ops.pack_conv_gemm_weights(w))
+
+
+def strided_ok(conv, cin):
+    return (isinstance(conv, nn.Conv2d) and conv.groups == 1 and conv.dilation == (1, 1) and conv.stride[0] == conv.stride[1]
+            and conv.padding[0] == conv.padding[1] and cin % 32 == 0)
+
+
+def conv_strided(x, conv, bn=None, relu=False, out=None):
+    """A convolution the Winograd kernel does not cover (stride 2) as an implicit-im2col GEMM on the f32 MFMA
+    (`srf_conv_gemm_nhwc`): deterministic, where MIOpen's channels-last choice is an atomic split-K kernel."""
+    scale, shift = _affine_of(conv, bn)
+    return ops.conv_gemm_nhwc(x, _strided_weights(conv), conv.out_channels, conv.kernel_size, conv.stride[0], conv.padding[0],
+                              scale, shift, relu, out=out)
+
+
+def to_nhwc(x):
+    """Contiguous NCHW f32 tensor -> NHWC tensor (LDS tile transpose)."""
+    return nhwc_view(ops.to_channels_last(x))
+
+
+# ---- SECONDCustom ----------------------------------------------------------------------------------------------------
+def second_supported(net, x):
+    if not (fusable(x) and x.dim() == 4 and x.shape[1] % 8 == 0):
+        return False
+    for stage in net.blocks:
+        mods = list(stage.children())
+        if len(mods) % 3:
+            return False
+        for j in range(0, len(mods), 3):
+            conv, bn, act = mods[j:j + 3]
+            if not (isinstance(conv, nn.Conv2d) and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.groups == 1
+                    and conv.dilation == (1, 1) and _foldable(bn) and isinstance(act, nn.ReLU)):
+                return False
+            if conv.stride == (1, 1) and conv.in_channels % 8:
+                return False
+            if conv.stride != (1, 1) and not strided_ok(conv, conv.in_channels):
+                return False
+    return True
+
+
+def second_forward(net, x):
+    """SECONDCustom.forward (second_custom.py:78-91) on channels-last maps: 3x3 / stride 1 layers on srf_wino3x3, the
+    stride-2 heads of the later blocks on srf_conv_gemm_nhwc."""
+    y = nhwc_view(x) if is_channels_last(x) else to_nhwc(x)
+    outs = []
+    for stage in net.blocks:
+        mods = list(stage.children())
+        for j in range(0, len(mods), 3):
+            conv, bn = mods[j], mods[j + 1]
+            y = conv3x3(y, conv, bn, True) if conv.stride == (1, 1) else conv_strided(y, conv, bn, True)
+        outs.append(nchw_view(y))
+    return tuple(outs)
+
+
 # ---- FPN -------------------------------------------------------------------------------------------------------------
 def fpn_supported(fpn, inputs):
     n = len(fpn.lateral_convs)
-    if fpn.num_outs != n or fpn.start_level != 0 or fpn.backbone_end_level != fpn.num_ins or len(inputs) != n:
+    if fpn.start_level != 0 or fpn.backbone_end_level != fpn.num_ins or len(inputs) != n:
         return False
+    if fpn.num_outs != n and not (fpn.num_outs > n and fpn.add_extra_convs == "on_output"):
+        return False
+    for cm in list(fpn.fpn_convs)[n:]:   # extra stride-2 convolutions: srf_conv_gemm_nhwc
+        if cm.with_norm and not _foldable(getattr(cm, cm.norm_name)):
+            return False
+        if not strided_ok(cm.conv, cm.conv.in_channels):
+            return False
+        if cm.with_activation and not isinstance(cm.activate, nn.ReLU):
+            return False
     if fpn.upsample_cfg.get("mode", "nearest") != "nearest" or len(fpn.upsample_cfg) != 1:
         return False
-    for x, lat, fc in zip(inputs, fpn.lateral_convs, fpn.fpn_convs):
+    for x, lat, fc in zip(inputs, fpn.lateral_convs, list(fpn.fpn_convs)[:n]):
         if not (fusable(x) and is_channels_last(x)):
             return False
         for cm in (lat, fc):
@@ -254,4 +315,11 @@ def fpn_forward(fpn, inputs):
     lats = [_cm(cm, nhwc_view(inputs[i]), conv1x1) for i, cm in enumerate(fpn.lateral_convs)]
     for i in range(len(lats) - 1, 0, -1):
         ops.nhwc_upsample_add(lats[i - 1], lats[i])
-    return tuple(nchw_view(_cm(cm, lats[i], conv3x3)) for i, cm in enumerate(fpn.fpn_convs))
+    n = len(lats)
+    outs = [_cm(cm, lats[i], conv3x3) for i, cm in enumerate(list(fpn.fpn_convs)[:n])]
+    for cm in list(fpn.fpn_convs)[n:]:   # add_extra_convs='on_output': stride-2 3x3 on the previous output
+        src = outs[-1]
+        if fpn.relu_before_extra_convs and len(outs) > n:
+            src = torch.relu(src)
+        outs.append(_cm(cm, src, conv_strided))
+    return tuple(nchw_view(o) for o in outs)

@@ -420,7 +420,7 @@ def spconv_fwd(feats, weight, nbr, alpha=None, beta=None, residual=None, relu=Fa
                                         _stream()), "spconv_fwd")
     if timing is not None:
         ev1.record()
-        timing["spconv"].append(_SpconvRecord(ev0, ev1, Cin, Cout, K, feats.shape[0], A_out, pair_counts))
+        timing["spconv"].append(_SpconvRecord(ev0, ev1, Cin, Cout, K, feats.shape[0], A_out, pair_counts, residual is not None))
     return out
 
 
@@ -428,15 +428,17 @@ class _SpconvRecord:
     """(start, end, Cin, Cout, K, algorithmic flops, algorithmic bytes) of one launch; the pair count is read from the
     rulebook's device counters only when the record is unpacked, after the timed region."""
 
-    def __init__(self, ev0, ev1, cin, cout, K, a_in, a_out, pair_counts):
+    def __init__(self, ev0, ev1, cin, cout, K, a_in, a_out, pair_counts, has_residual=False):
         self.v = (ev0, ev1, cin, cout, K)
-        self.a_in, self.a_out, self.pair_counts = a_in, a_out, pair_counts
+        self.a_in, self.a_out, self.pair_counts, self.has_residual = a_in, a_out, pair_counts, has_residual
 
     def __iter__(self):
         ev0, ev1, cin, cout, K = self.v
         pairs = int(self.pair_counts.sum().item()) if self.pair_counts is not None else 0
         flops = 2 * pairs * cin * cout
         byts = 4 * (self.a_in * cin + self.a_out * cout) + 4 * K * cin * cout + 8 * pairs
+        if self.has_residual:
+            byts += 4 * self.a_out * cout  # the residual rows are read once
         return iter((ev0, ev1, cin, cout, K, flops, byts))
 
 
@@ -872,6 +874,16 @@ def conv1x1(xs, packed_weight, Cout, scale=None, shift=None, relu=False):
 
 
 # ---- channels-last (NHWC) dense convolutions (csrc/conv.hip) ---------------------------------------------------------
+def _dense_timing(key):
+    """(start event, record list) when bench.py asked for per-launch times of the dense kernels (KERNEL_TIMING[key]), else None."""
+    t = KERNEL_TIMING
+    if t is None or key not in t or torch.cuda.is_current_stream_capturing():
+        return None
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    return ev0, t[key]
+
+
 def nhwc_ld(x):
     """Floats per pixel of an (N, H, W, C) f32 view whose channels are a slice of a pixel-major buffer; raises if the
     view is not of that form."""
@@ -917,10 +929,18 @@ def wino3x3(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None
     L = _lib.lib()
     if packed_weight.numel() * 4 != L.srf_wino3x3_packed_weight_bytes(Cout, Cin):
         raise ValueError("wino3x3: packed weight does not match (Cout, Cin)")
+    timing = _dense_timing("wino")
     check(L.srf_wino3x3(_ptr(x), N, H, W, Cin, x_ld, _ptr(packed_weight), Cout,
                         None if scale is None else _ptr(_dev(scale, "scale", torch.float32)),
                         None if shift is None else _ptr(_dev(shift, "shift", torch.float32)), int(bool(relu)),
                         _ptr(out), y_ld, _stream()), "wino3x3")
+    if timing is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        # direct-convolution FLOPs, FLOPs the Winograd kernel executes on the MFMA (16 of 36 products), bytes in + out + weights
+        direct = 2.0 * 9 * Cin * Cout * N * H * W
+        timing[1].append((timing[0], ev1, f"{Cin}->{Cout} @{N}x{H}x{W}", direct, direct / 2.25,
+                          4.0 * N * H * W * (Cin + Cout) + 4.0 * 16 * Cin * Cout))
     return out
 
 
@@ -950,10 +970,16 @@ def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out
     L = _lib.lib()
     if packed_weight.numel() * 4 != L.srf_conv1x1_nhwc_packed_weight_bytes(Cout, K):
         raise ValueError("conv1x1_nhwc: packed weight does not match (Cout, K)")
+    timing = _dense_timing("gemm")
     check(L.srf_conv1x1_nhwc(_ptr(x), N * H * W, K, x_ld, _ptr(packed_weight), Cout,
                              None if scale is None else _ptr(_dev(scale, "scale", torch.float32)),
                              None if shift is None else _ptr(_dev(shift, "shift", torch.float32)), int(bool(relu)),
                              _ptr(out), y_ld, _stream()), "conv1x1_nhwc")
+    if timing is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        fl = 2.0 * K * Cout * N * H * W
+        timing[1].append((timing[0], ev1, f"{K}->{Cout} @{N}x{H}x{W}", fl, fl, 4.0 * N * H * W * (K + Cout) + 4.0 * K * Cout))
     return out
 
 
@@ -1027,6 +1053,44 @@ def nhwc_dwconv3x3s2(x, weight, scale=None, shift=None, relu=False, out=None):
     w = _dev(weight.reshape(C, 9), "weight", torch.float32)
     check(_lib.lib().srf_nhwc_dwconv3x3s2(_ptr(x), x_ld, N, H, W, C, _ptr(w), _opt(scale, "scale"), _opt(shift, "shift"),
                                           int(bool(relu)), _ptr(out), nhwc_ld(out), _stream()), "nhwc_dwconv3x3s2")
+    return out
+
+
+def pack_conv_gemm_weights(weight):
+    """(Cout, Cin, kh, kw) -> packed operand of srf_conv_gemm_nhwc: k = (tap, input channel), tap slowest."""
+    Cout = weight.shape[0]
+    return pack_conv1x1_nhwc_weights(weight.detach().permute(0, 2, 3, 1).reshape(Cout, -1).contiguous())
+
+
+def conv_gemm_nhwc(x, packed_weight, Cout, ksize, stride, pad, scale=None, shift=None, relu=False, out=None):
+    """Conv2d on an NHWC slice as an implicit-im2col GEMM on the f32 MFMA (the strided 3x3 layers); -> (N, Ho, Wo, Cout)."""
+    x_ld = nhwc_ld(x)
+    N, H, W, Cin = x.shape
+    kh, kw = ksize
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    if out is None:
+        out = _empty((N, Ho, Wo, Cout), torch.float32, x.device)
+    elif tuple(out.shape) != (N, Ho, Wo, Cout):
+        raise ValueError("conv_gemm_nhwc: out has the wrong shape")
+    L = _lib.lib()
+    if packed_weight.numel() * 4 != L.srf_conv1x1_nhwc_packed_weight_bytes(Cout, kh * kw * Cin):
+        raise ValueError("conv_gemm_nhwc: packed weight does not match the layer")
+    check(L.srf_conv_gemm_nhwc(_ptr(x), N, H, W, Cin, x_ld, _ptr(packed_weight), Cout, kh, kw, stride, pad, _opt(scale, "scale"),
+                               _opt(shift, "shift"), int(bool(relu)), _ptr(out), nhwc_ld(out), _stream()), "conv_gemm_nhwc")
+    return out
+
+
+def stem_conv_nchw(x, weight, scale=None, shift=None, relu=False, out=None):
+    """Conv2d(Cin <= 4, 64, 3, stride 2, padding 1) + affine + ReLU from contiguous NCHW images to an NHWC tensor."""
+    x = _dev(x, "x", torch.float32)
+    N, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = _empty((N, Ho, Wo, Cout), torch.float32, x.device)
+    check(_lib.lib().srf_stem_conv_nchw(_ptr(x), N, Cin, H, W, _ptr(_dev(weight.detach(), "weight", torch.float32)), Cout,
+                                        _opt(scale, "scale"), _opt(shift, "shift"), int(bool(relu)), _ptr(out), nhwc_ld(out),
+                                        _stream()), "stem_conv_nchw")
     return out
 
 

@@ -1,5 +1,6 @@
 """`SECONDCustom` (mmdet3d_plugin/models/backbones/second_custom.py:10-91): dense conv3x3-BN-ReLU stacks on the
-BEV map.  Plain torch modules (MIOpen on ROCm); module names `blocks.{i}.{j}` as in the reference."""
+BEV map.  Plain torch modules own the parameters (module names `blocks.{i}.{j}` as in the reference); fp32 GPU inference
+runs them channels-last on the Winograd kernel of csrc/conv.hip (srfdet3d_amd/nhwc.py), everything else on MIOpen."""
 from torch import nn
 
 from ..compat.cnn import BaseModule, build_conv_layer, build_norm_layer
@@ -26,6 +27,9 @@ class SECONDCustom(BaseModule):
         self.blocks = nn.ModuleList(stages)
 
     def forward(self, x):
+        from .. import nhwc
+        if nhwc.enabled() and nhwc.second_supported(self, x):
+            return nhwc.second_forward(self, x)   # fp32 inference on the GPU: channels-last, 3x3 layers on srf_wino3x3
         outs = []
         for stage in self.blocks:
             x = run_sequential(stage, x)

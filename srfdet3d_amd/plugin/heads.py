@@ -525,21 +525,26 @@ class SRFDetHead(BaseModule):
         feats = (w * feats_w.view(1, E, P, -1)).sum(1)
         return boxes, feats
 
+    def _img_convs_only(self, img_feats):
+        """`img_convs` (3x3, feat_channels_img -> hidden_dim, bias) on every camera level (srfdet_head.py:404-416)."""
+        out = list(img_feats)
+        for i, f in enumerate(out):
+            bs, n_cam, C, H, W = f.shape
+            f4 = f.reshape(bs * n_cam, C, H, W)
+            conv = self.img_convs[i]
+            if nhwc.enabled() and fusable(f4) and nhwc.is_channels_last(f4) and nhwc.wino_ok(conv, C):
+                g = nhwc.nchw_view(nhwc.conv3x3(nhwc.nhwc_view(f4), conv))  # Winograd on the f32 MFMA, bias in the epilogue
+            else:
+                g = conv(f4)
+            out[i] = g.reshape(bs, n_cam, *g.shape[1:])
+        return out
+
     # ---- forward --------------------------------------------------------------------------------------------
     def forward(self, img_feats, point_feats, img_metas):
         """-> logits (#stage, bs, n_p, #cls), boxes (#stage, bs, n_p, D) with centres in metres, log sizes."""
         point_feats = list(point_feats)
         if self.use_img and self.hidden_dim != self.feat_channels_img:
-            img_feats = list(img_feats)
-            for i, f in enumerate(img_feats):
-                bs, n_cam, C, H, W = f.shape
-                f4 = f.reshape(bs * n_cam, C, H, W)
-                conv = self.img_convs[i]
-                if nhwc.enabled() and fusable(f4) and nhwc.is_channels_last(f4) and nhwc.wino_ok(conv, C):
-                    g = nhwc.nchw_view(nhwc.conv3x3(nhwc.nhwc_view(f4), conv))  # Winograd on the f32 MFMA, bias in the epilogue
-                else:
-                    g = conv(f4)
-                img_feats[i] = g.reshape(bs, n_cam, *g.shape[1:])
+            img_feats = self._img_convs_only(img_feats)
         boxes, prop_feats = self._get_init_proposals(img_feats, point_feats)
         boxes = boxes.contiguous()
         boxes[..., :3] = boxes[..., :3].sigmoid()

@@ -200,3 +200,37 @@ def test_vovnet_fpn_channels_last_path_matches_module_path(monkeypatch):
     for o, r in zip(out, ref):
         assert o.shape == r.shape
         assert (o - r).abs().max().item() <= 2e-4 * r.abs().max().item()
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad", [(2, 13, 18, 32, 48, 3, 2, 1), (1, 184, 184, 128, 256, 3, 2, 1),
+                                                         (6, 32, 48, 64, 128, 3, 2, 1), (1, 23, 23, 128, 128, 3, 2, 1),
+                                                         (1, 9, 11, 64, 40, 3, 1, 1)])
+def test_conv_gemm_nhwc_matches_torch(N, H, W, Cin, Cout, k, stride, pad):
+    """Implicit-im2col GEMM for the strided 3x3 layers; float64 CPU convolution as the reference; run twice: bitwise equal
+    (no atomics)."""
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(N, H, W, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (k * Cin ** 0.5)).to(DEV)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    pk = ops.pack_conv_gemm_weights(w)
+    y = ops.conv_gemm_nhwc(x, pk, Cout, (k, k), stride, pad, scale, shift, True)
+    y2 = ops.conv_gemm_nhwc(x, pk, Cout, (k, k), stride, pad, scale, shift, True)
+    assert torch.equal(y, y2)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).cpu().double(), w.cpu().double(), stride=stride, padding=pad)
+    ref = (ref * scale.cpu().double().view(1, -1, 1, 1) + shift.cpu().double().view(1, -1, 1, 1)).relu().permute(0, 2, 3, 1)
+    assert y.shape == ref.shape
+    assert (y.cpu().double() - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1.0)
+
+
+def test_stem_conv_nchw_matches_torch():
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 3, 37, 50, generator=g).to(DEV)
+    w = (torch.randn(64, 3, 3, 3, generator=g) / 5).to(DEV)
+    scale = (torch.rand(64, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(64, generator=g).to(DEV)
+    y = ops.stem_conv_nchw(x, w, scale, shift, True)
+    ref = (F.conv2d(x.cpu().double(), w.cpu().double(), stride=2, padding=1) * scale.cpu().double().view(1, -1, 1, 1)
+           + shift.cpu().double().view(1, -1, 1, 1)).relu().permute(0, 2, 3, 1)
+    assert y.shape == ref.shape
+    assert (y.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
