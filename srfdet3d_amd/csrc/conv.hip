@@ -38,7 +38,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define WN_LDS_BYTES ((4 * 2048 + 2 * 720) * 16)  // V[2], U[2]: 2048 float4 each; RAW[2]: 720 float4 each
+#define WN_RAW 924                               // float4 per patch buffer (the 32 x 2 tile block: 2 x 66 rows x 7)
+#define WN_LDS_BYTES ((4 * 2048 + 2 * WN_RAW) * 16)  // V[2], U[2]: 2048 float4 each; RAW[2]
 
 struct WinoArgs {
     const float *x;
@@ -91,10 +92,19 @@ __device__ __forceinline__ float4 wn_add(float4 a, float4 b) { return make_float
         ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((A).w, (B).w, ACC, 0, 0, 0);    \
     } while (0)
 
-template <int DBG>
+// TWL = log2 of the tile block's width: the 64 tiles of a workgroup form an 8 x 8, 16 x 4 or 32 x 2 (rows x columns) block --
+// the host picks the shape that covers the map with the fewest blocks (a 29 x 50 tile map: 28 / 26 / 25 blocks).
+template <int DBG, int TWL>
 __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 s_w[];  // V[2][2048] | U[2][2048] | RAW[2][720]
+    constexpr int TW = 1 << TWL, TH = 64 >> TWL;       // tiles per block row / column
+    constexpr int PR = 2 * TH + 2, PC = 2 * TW + 2;    // patch rows / columns (pixels)
+    constexpr int HP = TW + 1 + (TWL == 3 ? 1 : 0);    // float4 per (row, column parity)
+    constexpr int RP = TWL == 1 ? 7 : 2 * HP;          // row pitch: spreads the tiles of 16 lanes over the 16 bank slots
+    constexpr int NPIX = PR * PC * 2;                  // float4 per chunk (2 k quads)
+    constexpr int NL = (NPIX + 255) / 256;             // loads per thread
+    static_assert(2 * PR * RP <= WN_RAW && 2 * HP <= RP + 1, "patch buffer");
+    extern __shared__ __attribute__((aligned(16))) float4 s_w[];  // V[2][2048] | U[2][2048] | RAW[2][WN_RAW]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // workgroups b and b + 8 share an XCD (round-robin dispatch): the cout blocks of one spatial block sit on one L2
     const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
@@ -107,42 +117,44 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
     long long st0 = 0, st1 = 0, st2 = 0;
     if (DBG & 8) st0 = __builtin_amdgcn_s_memtime();
 
-    // ---- loader role: the 18 x 18 pixel patch of the block, 8 channels per chunk = 648 float4, <= 3 per thread.  Buffer
-    // loads: the descriptor covers image n; a pixel outside the image gets an offset beyond the range and the hardware
-    // returns zeros (the convolution's zero padding) -- no predicates, no selects.  LDS image of the patch:
-    // RAW[k quad][row][column parity][column / 2] with a row pitch of 20 float4, so that the tiles of a wave (column
-    // stride 2) read consecutive float4 and the 8 tile rows fall on alternating bank halves.
+    // ---- loader role: the (2 TH + 2) x (2 TW + 2) pixel patch of the block, 8 channels per chunk = NPIX float4, <= NL per
+    // thread.  Buffer loads: the descriptor covers image n; a pixel outside the image gets an offset beyond the range and the
+    // hardware returns zeros (the convolution's zero padding) -- no predicates, no selects.  LDS image of the patch:
+    // RAW[k quad][row][column parity][column / 2] with a row pitch RP chosen so that the tiles of a wave (column stride 2)
+    // read consecutive float4 and successive tile rows fall on different bank slots.
     __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.x) + (long long)n * a.H * a.W * a.x_ld, 0, (int)((long long)a.H * a.W * a.x_ld * 4), 0x00020000);
-    unsigned goff[3];
-    int gdst[3];
+    unsigned goff[4];
+    int gdst[4];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < 4; ++j) {
         const int i = tid + 256 * j;
         const int qq = i & 1, p = i >> 1;
-        const int py = p / 18, px = p - py * 18;
-        const int y = 16 * rb - 1 + py, x = 16 * cbk - 1 + px;
-        const bool ok = i < 648 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+        const int py = p / PC, px = p - py * PC;
+        const int y = 2 * TH * rb - 1 + py, x = 2 * TW * cbk - 1 + px;
+        const bool ok = i < NPIX && y >= 0 && y < a.H && x >= 0 && x < a.W;
         goff[j] = ok ? (unsigned)((((long long)y * a.W + x) * a.x_ld + qq * 4) * 4) : 0x80000000u;
-        gdst[j] = i < 648 ? 8192 + (qq * 18 + py) * 20 + (px & 1) * 10 + (px >> 1) : 8192 + 9;  // 9: a slot no pixel uses
+        // past the patch: a slot no pixel uses (behind the image if the buffer has room, else the spare slot of row 0)
+        gdst[j] = i < NPIX ? 8192 + (qq * PR + py) * RP + (px & 1) * HP + (px >> 1) : 8192 + (2 * PR * RP < WN_RAW ? 2 * PR * RP : RP - 1);
     }
     const float4 z4_ = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 gr_0 = z4_, gr_1 = z4_, gr_2 = z4_;
+    float4 gr_0 = z4_, gr_1 = z4_, gr_2 = z4_, gr_3 = z4_;
 #define WN_GL(J)                                                                                    \
-    if (!(DBG & 1)) {                                                                               \
+    if (!(DBG & 1) && (J) < NL) {                                                                   \
         auto v_ = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)goff[J], soff_, 0);             \
         gr_##J = *reinterpret_cast<float4 *>(&v_);                                                  \
     }
-#define WN_LOAD_RAW(CH)              \
-    do {                             \
-        const int soff_ = (CH) * 32; \
-        WN_GL(0) WN_GL(1) WN_GL(2)   \
+#define WN_LOAD_RAW(CH)                     \
+    do {                                    \
+        const int soff_ = (CH) * 32;        \
+        WN_GL(0) WN_GL(1) WN_GL(2) WN_GL(3) \
     } while (0)
 #define WN_STORE_RAW(RAWB)                             \
     do {                                               \
         s_w[gdst[0] + (RAWB)] = gr_0;                  \
         s_w[gdst[1] + (RAWB)] = gr_1;                  \
         s_w[gdst[2] + (RAWB)] = gr_2;                  \
+        if (NL > 3) s_w[gdst[3] + (RAWB)] = gr_3;      \
     } while (0)
 
     // ---- transform role: tile t = lane, k quad q, half hh of the 4 frequency rows ----
@@ -152,10 +164,10 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
     const float sgn = hh ? -1.f : 1.f;
     int rsrc_row[3];
     {
-        const int tx = lane & 7, ty = lane >> 3;
+        const int tx = lane & (TW - 1), ty = lane >> TWL;
         const int rsel[3] = {2 * hh, 1 + 2 * hh, 2 - hh};
 #pragma unroll
-        for (int r = 0; r < 3; ++r) rsrc_row[r] = 8192 + (q * 18 + 2 * ty + rsel[r]) * 20 + tx;
+        for (int r = 0; r < 3; ++r) rsrc_row[r] = 8192 + (q * PR + 2 * ty + rsel[r]) * RP + tx;
     }
     const float4 *Ug = a.U + (size_t)cb * 2048 + tid;
     const size_t u_chunk_stride = (size_t)a.coutBlocks * 2048;
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
     float4 pr_0, pr_1, pr_2, pr_3, pr_4, pr_5, pr_6, pr_7, pr_8, pr_9, pr_10, pr_11;
     float4 ur_0 = z4_, ur_1 = z4_, ur_2 = z4_, ur_3 = z4_, ur_4 = z4_, ur_5 = z4_, ur_6 = z4_, ur_7 = z4_;
     // pixel column 2 tx + c of the patch: parity c & 1, index tx + (c >> 1)
-#define WN_RD(R, C, I) pr_##I = s_w[rsrc_row[R] + (RAWB_) + ((C) & 1) * 10 + ((C) >> 1)];
+#define WN_RD(R, C, I) pr_##I = s_w[rsrc_row[R] + (RAWB_) + ((C) & 1) * HP + ((C) >> 1)];
 #define WN_READ_RAW(RAWB)                                               \
     do {                                                                \
         const int RAWB_ = (RAWB);                                       \
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
     WN_LOAD_U_HI(0);
     WN_STORE_RAW(0);
     WN_LOAD_RAW(last < 1 ? last : 1);
-    WN_STORE_RAW(720);
+    WN_STORE_RAW(WN_RAW);
     WN_STORE_U_LO(0);
     WN_STORE_U_HI(0);
     WN_LOAD_RAW(last < 2 ? last : 2);
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
     WN_STAGE1();
     WN_STAGE2(t0, 2 * hh, 0);
     WN_STAGE2(t1, 2 * hh + 1, 0);
-    WN_READ_RAW(720);
+    WN_READ_RAW(WN_RAW);
     WN_STAGE1();
     __syncthreads();
     WN_READ_GROUP(0, 0, 0);
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
     // behind the barrier, under the last group: chunk c + 2's patch RAW -> registers -> vertical stage.
     for (int c = 0; c < nchunk; ++c) {
         const int rbuf = (c & 1) * 2048, wbuf = 2048 - rbuf;
-        const int rawb = (c & 1) * 720;
+        const int rawb = (c & 1) * WN_RAW;
         const int c2 = c + 2 < nchunk ? c + 2 : last, c3 = c + 3 < nchunk ? c + 3 : last;
         WN_READ_GROUP(1, 1, rbuf);
         WN_FENCE();
@@ -351,13 +363,13 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
     const float sh = (co_ok && a.shift) ? a.shift[co] : 0.f;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-        const int oy = 2 * (rb * 8 + th * 4 + rg);
-        const bool row_ok = oy < a.H && co_ok;
-        float *yrow = a.y + (((long long)n * a.H + oy) * a.W) * a.y_ld + co;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int r = rg * 4 + rr;
-            const int ox = 2 * (cbk * 8 + rr + 4 * lh);
+            const int t = th * 32 + rr + 8 * rg + 4 * lh;   // tile of accumulator register r in this lane half
+            const int oy = 2 * (rb * TH + (t >> TWL)), ox = 2 * (cbk * TW + (t & (TW - 1)));
+            const bool row_ok = oy < a.H && co_ok;
+            float *yrow = a.y + (((long long)n * a.H + oy) * a.W) * a.y_ld + co;
             float s[4], d[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -668,8 +680,21 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
     a.H = H;
     a.W = W;
     a.Cout = Cout;
-    a.rowBlocks = srf_ceil_div(H, 16);
-    a.colBlocks = srf_ceil_div(W, 16);
+    // tile-block shape (rows x columns of 2 x 2-pixel tiles): the one that covers the map with the fewest 64-tile blocks
+    const int tilesY = (H + 1) / 2, tilesX = (W + 1) / 2;
+    int twl = 3;
+    long long best = (long long)srf_ceil_div(tilesY, 8) * srf_ceil_div(tilesX, 8);
+    for (int l = 2; l >= 1; --l) {
+        const long long nb = (long long)srf_ceil_div(tilesY, 64 >> l) * srf_ceil_div(tilesX, 1 << l);
+        if (nb < best) {
+            best = nb;
+            twl = l;
+        }
+    }
+    static const int force_twl = getenv("SRF_WINO_TWL") ? atoi(getenv("SRF_WINO_TWL")) : 0;  // developer A/B knob
+    if (force_twl >= 1 && force_twl <= 3) twl = force_twl;
+    a.rowBlocks = srf_ceil_div(tilesY, 64 >> twl);
+    a.colBlocks = srf_ceil_div(tilesX, 1 << twl);
     a.coutBlocks = srf_ceil_div(Cout, 64);
     a.nchunk = Cin / 8;
     const long long nspatial = (long long)N * a.rowBlocks * a.colBlocks;
@@ -684,22 +709,31 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
     if (dev < 0 || dev >= 64) return SRF_EUNSUPPORTED;
     static const int dbg = getenv("SRF_WINO_DBG") ? atoi(getenv("SRF_WINO_DBG")) : 0;  // timing ablations (developer knob)
     if (!attr_set[dev]) {
-        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
-        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
-        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
-        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
-        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
-        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<8>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
+#define WN_ATTR(D, L) SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<D, L>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES))
+        WN_ATTR(0, 1);
+        WN_ATTR(0, 2);
+        WN_ATTR(0, 3);
+        WN_ATTR(1, 3);
+        WN_ATTR(4, 3);
+        WN_ATTR(8, 3);
+#undef WN_ATTR
         attr_set[dev] = true;
     }
     const dim3 grid((unsigned)blocks), blk(256);
-    switch (dbg) {
-    case 1: hipLaunchKernelGGL(srf_wino3x3_k<1>, grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a); break;
-    case 2: hipLaunchKernelGGL(srf_wino3x3_k<2>, grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a); break;
-    case 3: hipLaunchKernelGGL(srf_wino3x3_k<3>, grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a); break;
-    case 4: hipLaunchKernelGGL(srf_wino3x3_k<4>, grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a); break;
-    case 8: hipLaunchKernelGGL(srf_wino3x3_k<8>, grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a); break;
-    default: hipLaunchKernelGGL(srf_wino3x3_k<0>, grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a); break;
+    if (dbg == 1 || dbg == 4 || dbg == 8) {   // ablation builds exist for the 8 x 8 shape only
+        a.rowBlocks = srf_ceil_div(tilesY, 8);
+        a.colBlocks = srf_ceil_div(tilesX, 8);
+        a.nspatial = N * a.rowBlocks * a.colBlocks;
+        const dim3 gd((unsigned)(((a.nspatial + 7) / 8) * 8 * a.coutBlocks));
+        if (dbg == 1) hipLaunchKernelGGL((srf_wino3x3_k<1, 3>), gd, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
+        else if (dbg == 4) hipLaunchKernelGGL((srf_wino3x3_k<4, 3>), gd, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((srf_wino3x3_k<8, 3>), gd, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
+    } else if (twl == 3) {
+        hipLaunchKernelGGL((srf_wino3x3_k<0, 3>), grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
+    } else if (twl == 2) {
+        hipLaunchKernelGGL((srf_wino3x3_k<0, 2>), grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL((srf_wino3x3_k<0, 1>), grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
     }
     SRF_LAUNCH_CHECK();
     return SRF_OK;
