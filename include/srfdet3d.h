@@ -368,6 +368,14 @@ size_t srf_conv1x1_nhwc_packed_weight_bytes(int Cout, int K);
 int srf_conv1x1_nhwc_pack_weights(const float *W, int Cout, int K, float *packed, srf_stream_t stream);
 int srf_conv1x1_nhwc(const float *x, long long M, int K, long long x_ld, const float *W_packed, int Cout, const float *scale,
                      const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream);
+/* srf_conv1x1_nhwc_pooled: the same convolution on N images of HW pixels (rows n HW .. (n + 1) HW - 1), which also returns
+ * mean[n][co] = the mean over the image's pixels of the stored outputs: VoVNet's eSE average pool (reference
+ * mmdet3d_plugin/models/backbones/vovnet.py:150-163 eSEModule.avg_pool on the output of vovnet.py:210 `concat`) without a
+ * second pass over the map.  Deterministic (per-block sums added in a fixed order).  workspace: _workspace_bytes(N, HW, Cout). */
+size_t srf_conv1x1_nhwc_pooled_workspace_bytes(int N, long long HW, int Cout);
+int srf_conv1x1_nhwc_pooled(const float *x, int N, long long HW, int K, long long x_ld, const float *W_packed, int Cout,
+                            const float *scale, const float *shift, int relu, float *y, long long y_ld, float *mean, void *workspace,
+                            size_t workspace_bytes, srf_stream_t stream);
 
 /* srf_conv_gemm_nhwc: Conv2d(Cin, Cout, (kh, kw), stride, padding) on channels-last activations as the GEMM of
  * srf_conv1x1_nhwc with an implicit im2col (rows = output pixels, k = (tap, input channel)): the stride-2 3x3 layers of the

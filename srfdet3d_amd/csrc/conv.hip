@@ -440,6 +440,12 @@ struct GemmArgs {
     // convolution mode (CONV): rows are OUTPUT pixels (n, oy, ox), k runs over (tap, input channel): implicit im2col
     int H, W, Ho, Wo, kw, stride, pad, cin_chunks;  // cin_chunks = Cin / 32
     long long x_bytes;                               // extent of the input tensor (buffer descriptor range)
+    // per-image row tiling + column sums of the stored outputs (eSE pooling fused into the OSA concat convolution):
+    // bpi > 0: M = N HW rows, image n owns row blocks [n bpi, (n + 1) bpi), block (n, lb) starts at row n HW + lb TM and
+    // ends with its image; colsum[(n bpi + lb) Cout + co] = sum over the block's rows of y[row][co]
+    float *colsum;
+    long long HW;
+    int bpi;
 };
 
 // W (Cout, K) row-major -> [chunk of 32][cout block of 256][channel 256][slot 8][4]; slot s of row co holds quad
@@ -481,13 +487,18 @@ __global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
     const long long mb = (long long)(jq / nct) * 8 + xcd;
     if (mb >= a.mblocks) return;
     if ((cb * 256 + cs * TN) >= a.Cout) return;
-    const long long p0 = mb * TM;
+    long long p0 = mb * TM, rows_blk = a.M - p0;
+    if (!CONV && a.bpi > 0) {
+        const long long n = mb / a.bpi, lb = mb - n * a.bpi;
+        p0 = n * a.HW + lb * TM;
+        rows_blk = a.HW - lb * TM;
+    }
 
     __amdgpu_buffer_rsrc_t xrsrc;
     if (CONV) {
         xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
     } else {
-        long long rows = a.M - p0;
+        long long rows = rows_blk;
         if (rows > TM) rows = TM;
         xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x) + p0 * a.x_ld, 0, (int)(rows * a.x_ld * 4), 0x00020000);
     }
@@ -617,7 +628,10 @@ __global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
     }
     const long long prow = p0 + wm * 32 * RM + 4 * lh;  // + i * 32 + (r & 3) + 8 * (r >> 2)
     float *yb = a.y + prow * a.y_ld + co0;
-    const long long rows_left = a.M - prow;
+    const long long rows_left = rows_blk - (wm * 32 * RM + 4 * lh);
+    float csum[RN];
+#pragma unroll
+    for (int j = 0; j < RN; ++j) csum[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < RM; ++i) {
 #pragma unroll
@@ -630,10 +644,30 @@ __global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
                     float v = __fmaf_rn(acc[i][j][r], sc[j], sh[j]);
                     if (a.relu) v = fmaxf(v, 0.f);
                     if (co_ok[j]) yp[j * 32] = v;
+                    csum[j] += v;
                 }
             }
         }
         WN_FENCE();
+    }
+    if (!CONV && a.colsum) {
+        // rows of a column: 2 lane halves x (4 / WN) waves; fixed order -> the sums are reproducible bit for bit
+        float *red = reinterpret_cast<float *>(s_g);  // [wm][TN]
+        __syncthreads();                               // the last chunk's fragment reads are done
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const float o = __shfl_xor(csum[j], 32);
+            if (lh == 0) red[wm * TN + wn * 32 * RN + j * 32 + li] = csum[j] + o;
+        }
+        __syncthreads();
+        constexpr int WM = 4 / (TN / (32 * RN));       // waves along the rows
+        if (tid < TN) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) s += red[w * TN + tid];
+            const int co = cb * 256 + cs * TN + tid;
+            if (co < a.Cout) a.colsum[mb * a.Cout + co] = s;
+        }
     }
 }
 
@@ -757,14 +791,10 @@ extern "C" int srf_conv1x1_nhwc_pack_weights(const float *W, int Cout, int K, fl
     return SRF_OK;
 }
 
-extern "C" int srf_conv1x1_nhwc(const float *x, long long M, int K, long long x_ld, const float *W_packed, int Cout, const float *scale,
-                                const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream)
+// shared launcher: bpi == 0 -> flat row tiling; bpi > 0 -> per-image tiling with column sums into `colsum`
+static int conv1x1_launch(const float *x, long long M, int K, long long x_ld, const float *W_packed, int Cout, const float *scale,
+                          const float *shift, int relu, float *y, long long y_ld, float *colsum, long long HW, hipStream_t stream)
 {
-    if (M < 0 || K <= 0 || Cout <= 0 || x_ld < K || y_ld < Cout) return SRF_EINVAL;
-    if (M == 0) return SRF_OK;
-    if (!x || !W_packed || !y) return SRF_EINVAL;
-    if ((K & 31) || (x_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)W_packed & 15)) return SRF_EUNSUPPORTED;
-    if (x_ld * 256 * 4 >= (1ll << 31)) return SRF_EUNSUPPORTED;
     GemmArgs a;
     a.x = x;
     a.y = y;
@@ -781,6 +811,8 @@ extern "C" int srf_conv1x1_nhwc(const float *x, long long M, int K, long long x_
     a.relu = relu;
     a.H = a.W = a.Ho = a.Wo = a.kw = a.stride = a.pad = a.cin_chunks = 0;
     a.x_bytes = 0;
+    a.colsum = colsum;
+    a.HW = HW;
     int dev = 0;
     SRF_HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return SRF_EUNSUPPORTED;
@@ -791,14 +823,73 @@ extern "C" int srf_conv1x1_nhwc(const float *x, long long M, int K, long long x_
         attr_set[dev] = true;
     }
     static const int big = getenv("SRF_GEMM_BIG") ? atoi(getenv("SRF_GEMM_BIG")) : 0;
-    const int TM = big ? 256 : 128, ncs = big ? 1 : 2;
-    a.mblocks = srf_ceil_div(M, TM);
+    const int TM = (big && !colsum) ? 256 : 128, ncs = (big && !colsum) ? 1 : 2;
+    if (colsum) {
+        a.bpi = (int)srf_ceil_div(HW, TM);
+        a.mblocks = (M / HW) * a.bpi;
+    } else {
+        a.bpi = 0;
+        a.mblocks = srf_ceil_div(M, TM);
+    }
     const long long blocks = ((a.mblocks + 7) / 8) * 8 * a.coutBlocks * ncs;
     if (blocks >= (1ll << 31)) return SRF_EUNSUPPORTED;
-    if (big)
-        hipLaunchKernelGGL((srf_conv1x1_nhwc_k<4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), LDS_BIG, (hipStream_t)stream, a);
+    if (TM == 256)
+        hipLaunchKernelGGL((srf_conv1x1_nhwc_k<4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), LDS_BIG, stream, a);
     else
-        hipLaunchKernelGGL((srf_conv1x1_nhwc_k<2, 2, 3, false>), dim3((unsigned)blocks), dim3(256), LDS_STD, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((srf_conv1x1_nhwc_k<2, 2, 3, false>), dim3((unsigned)blocks), dim3(256), LDS_STD, stream, a);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+extern "C" int srf_conv1x1_nhwc(const float *x, long long M, int K, long long x_ld, const float *W_packed, int Cout, const float *scale,
+                                const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream)
+{
+    if (M < 0 || K <= 0 || Cout <= 0 || x_ld < K || y_ld < Cout) return SRF_EINVAL;
+    if (M == 0) return SRF_OK;
+    if (!x || !W_packed || !y) return SRF_EINVAL;
+    if ((K & 31) || (x_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)W_packed & 15)) return SRF_EUNSUPPORTED;
+    if (x_ld * 256 * 4 >= (1ll << 31)) return SRF_EUNSUPPORTED;
+    return conv1x1_launch(x, M, K, x_ld, W_packed, Cout, scale, shift, relu, y, y_ld, nullptr, 0, (hipStream_t)stream);
+}
+
+// srf_conv1x1_nhwc_pooled: the same convolution on N images of HW pixels each, plus mean[n][co] = the mean over the
+// image's pixels of the stored outputs (after scale / shift / ReLU) -- VoVNet's eSE pooling (vovnet.py:150-163) without
+// a second pass over the map.  Row blocks end with their image; a workgroup leaves the column sums of its block in the
+// workspace, a second kernel adds the blocks of an image in a fixed order (deterministic, unlike an atomic reduction).
+#define PM_GROUPS 4
+__global__ __launch_bounds__(256) void srf_conv1x1_pool_finish_k(const float *__restrict__ partial, int bpi, int C, float inv,
+                                                                 float *__restrict__ mean)
+{
+    __shared__ float s[PM_GROUPS][64];
+    const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < C)
+        for (int b = g; b < bpi; b += PM_GROUPS) acc += partial[((long long)n * bpi + b) * C + c];
+    s[g][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (g == 0 && c < C) mean[(long long)n * C + c] = (((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x]) * inv;
+}
+
+extern "C" size_t srf_conv1x1_nhwc_pooled_workspace_bytes(int N, long long HW, int Cout)
+{
+    return (N <= 0 || HW <= 0 || Cout <= 0) ? 0 : (size_t)N * (size_t)srf_ceil_div(HW, 128) * Cout * 4;
+}
+
+extern "C" int srf_conv1x1_nhwc_pooled(const float *x, int N, long long HW, int K, long long x_ld, const float *W_packed, int Cout,
+                                       const float *scale, const float *shift, int relu, float *y, long long y_ld, float *mean, void *workspace,
+                                       size_t workspace_bytes, srf_stream_t stream)
+{
+    if (N < 0 || HW <= 0 || K <= 0 || Cout <= 0 || x_ld < K || y_ld < Cout) return SRF_EINVAL;
+    if (N == 0) return SRF_OK;
+    if (!x || !W_packed || !y || !mean || !workspace) return SRF_EINVAL;
+    if ((K & 31) || (x_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)W_packed & 15) || N > 65535) return SRF_EUNSUPPORTED;
+    if (x_ld * 256 * 4 >= (1ll << 31)) return SRF_EUNSUPPORTED;
+    if (workspace_bytes < srf_conv1x1_nhwc_pooled_workspace_bytes(N, HW, Cout)) return SRF_EWORKSPACE;
+    const int rc = conv1x1_launch(x, (long long)N * HW, K, x_ld, W_packed, Cout, scale, shift, relu, y, y_ld, (float *)workspace, HW,
+                                  (hipStream_t)stream);
+    if (rc != SRF_OK) return rc;
+    hipLaunchKernelGGL(srf_conv1x1_pool_finish_k, dim3(srf_ceil_div(Cout, 64), N), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)workspace, (int)srf_ceil_div(HW, 128), Cout, 1.0f / (float)HW, mean);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }
@@ -847,6 +938,9 @@ extern "C" int srf_conv_gemm_nhwc(const float *x, int N, int H, int W, int Cin, 
     a.pad = pad;
     a.cin_chunks = Cin / 32;
     a.x_bytes = x_bytes;
+    a.colsum = nullptr;
+    a.HW = 0;
+    a.bpi = 0;
     a.mblocks = srf_ceil_div(a.M, 128);
     const long long blocks = ((a.mblocks + 7) / 8) * 8 * a.coutBlocks * 2;
     if (blocks >= (1ll << 31)) return SRF_EUNSUPPORTED;

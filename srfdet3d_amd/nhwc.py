@@ -8,7 +8,7 @@ The torch modules stay the owners of the parameters (state_dict names untouched)
 * an OSA block owns ONE pixel-major buffer of Cin + 5 w channels: the block input sits in slice 0, each 3x3 branch writes
   its slice, and the 1x1 `concat` convolution (`srf_conv1x1_nhwc`) reads the buffer as a plain matrix -- the
   torch.cat of vovnet.py:205-210 is never built;
-* eSE: pixel mean (`srf_nhwc_colmean`) -> fc + hard sigmoid (`srf_ese_gate`) -> gate multiply + identity add in one pass
+* eSE: pixel mean (epilogue of the concat convolution, `srf_conv1x1_nhwc_pooled`) -> fc + hard sigmoid (`srf_ese_gate`) -> gate multiply + identity add in one pass
   that writes straight into slice 0 of the next block's buffer (`srf_nhwc_affine`);
 * the stride-2 stem layers: stem_1 (3 -> 64) is a streaming kernel from the NCHW images to channels-last
   (`srf_stem_conv_nchw`), stem_3 an implicit-im2col GEMM (`srf_conv_gemm_nhwc`); nothing of the branch runs on MIOpen.
@@ -84,9 +84,9 @@ def conv3x3(x, conv, bn=None, relu=False, out=None):
     return ops.wino3x3(x, _wino_weights(conv), conv.out_channels, scale, shift, relu, out=out)
 
 
-def conv1x1(x, conv, bn=None, relu=False, out=None):
+def conv1x1(x, conv, bn=None, relu=False, out=None, pool=False):
     scale, shift = _affine_of(conv, bn)
-    return ops.conv1x1_nhwc(x, _gemm_weights(conv), conv.out_channels, scale, shift, relu, out=out)
+    return ops.conv1x1_nhwc(x, _gemm_weights(conv), conv.out_channels, scale, shift, relu, out=out, pool=pool)
 
 
 def wino_ok(conv, cin):
@@ -157,8 +157,8 @@ def _osa_forward(m, buf, cin, dst):
         conv3x3(src, conv, bn, True, out=out)
         src, off = out, off + w
     conv, bn = _cbr(m.concat)
-    t = conv1x1(buf, conv, bn, True)
-    gate = ops.ese_gate(ops.nhwc_colmean(t), m.ese.fc.weight, m.ese.fc.bias)
+    t, mean = conv1x1(buf, conv, bn, True, pool=True)     # eSE average pool from the convolution's own epilogue
+    gate = ops.ese_gate(mean, m.ese.fc.weight, m.ese.fc.bias)
     ops.nhwc_affine(t, scale=gate, residual=buf[..., :cin] if m.identity else None, out=dst)
     return dst
 

@@ -957,9 +957,10 @@ def pack_conv1x1_nhwc_weights(weight):
     return packed
 
 
-def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None):
+def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None, pool=False):
     """1x1 convolution of the NHWC slice x (N, H, W, K) + per-channel scale / shift + ReLU into `out` ((N, H, W, Cout) slice
-    of an NHWC buffer; new contiguous tensor when None)."""
+    of an NHWC buffer; new contiguous tensor when None).  pool=True: returns (out, mean (N, Cout) over the pixels of each
+    image) from the same pass (`srf_conv1x1_nhwc_pooled`)."""
     x_ld = nhwc_ld(x)
     N, H, W, K = x.shape
     if out is None:
@@ -971,16 +972,24 @@ def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out
     if packed_weight.numel() * 4 != L.srf_conv1x1_nhwc_packed_weight_bytes(Cout, K):
         raise ValueError("conv1x1_nhwc: packed weight does not match (Cout, K)")
     timing = _dense_timing("gemm")
-    check(L.srf_conv1x1_nhwc(_ptr(x), N * H * W, K, x_ld, _ptr(packed_weight), Cout,
-                             None if scale is None else _ptr(_dev(scale, "scale", torch.float32)),
-                             None if shift is None else _ptr(_dev(shift, "shift", torch.float32)), int(bool(relu)),
-                             _ptr(out), y_ld, _stream()), "conv1x1_nhwc")
+    sc = None if scale is None else _ptr(_dev(scale, "scale", torch.float32))
+    sh = None if shift is None else _ptr(_dev(shift, "shift", torch.float32))
+    mean = None
+    if pool:
+        mean = _empty((N, Cout), torch.float32, x.device)
+        nbytes = L.srf_conv1x1_nhwc_pooled_workspace_bytes(N, H * W, Cout)
+        ws = _empty((max(nbytes, 4) // 4,), torch.float32, x.device)
+        check(L.srf_conv1x1_nhwc_pooled(_ptr(x), N, H * W, K, x_ld, _ptr(packed_weight), Cout, sc, sh, int(bool(relu)), _ptr(out), y_ld,
+                                        _ptr(mean), _ptr(ws), nbytes, _stream()), "conv1x1_nhwc_pooled")
+    else:
+        check(L.srf_conv1x1_nhwc(_ptr(x), N * H * W, K, x_ld, _ptr(packed_weight), Cout, sc, sh, int(bool(relu)), _ptr(out), y_ld,
+                                 _stream()), "conv1x1_nhwc")
     if timing is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
         fl = 2.0 * K * Cout * N * H * W
         timing[1].append((timing[0], ev1, f"{K}->{Cout} @{N}x{H}x{W}", fl, fl, 4.0 * N * H * W * (K + Cout) + 4.0 * K * Cout))
-    return out
+    return (out, mean) if pool else out
 
 
 def _opt(t, name):

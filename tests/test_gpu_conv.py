@@ -131,6 +131,25 @@ def test_conv1x1_nhwc_is_a_k_ordered_fma_chain():
     assert torch.all(dst[..., :8] == 7.0) and torch.all(dst[..., 32:] == 7.0)
 
 
+@pytest.mark.parametrize("N,H,W,K,Cout", [(2, 9, 15, 64, 96), (3, 16, 16, 32, 256), (1, 23, 29, 96, 40), (2, 1, 5, 32, 300)])
+def test_conv1x1_nhwc_pooled_mean_of_stored_outputs(N, H, W, K, Cout):
+    """Per-image row tiling: the outputs equal the flat kernel's bit for bit, the mean is the mean of what was stored
+    (blocks that end mid-tile with their image do not leak rows of the next image), and it repeats bit for bit."""
+    g = torch.Generator().manual_seed(N * H + W)
+    x = torch.randn(N, H, W, K, generator=g).to(DEV)
+    w = (torch.randn(Cout, K, generator=g) / K ** 0.5).to(DEV)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    pk = ops.pack_conv1x1_nhwc_weights(w)
+    y0 = ops.conv1x1_nhwc(x, pk, Cout, scale, shift, True)
+    y, mean = ops.conv1x1_nhwc(x, pk, Cout, scale, shift, True, pool=True)
+    assert torch.equal(y, y0)
+    ref = y.double().mean(dim=(1, 2))
+    assert (mean.double() - ref).abs().max().item() <= 1e-5 * max(ref.abs().max().item(), 1.0)
+    y2, mean2 = ops.conv1x1_nhwc(x, pk, Cout, scale, shift, True, pool=True)
+    assert torch.equal(mean, mean2) and torch.equal(y, y2)
+
+
 # ---- streaming NHWC layers ---------------------------------------------------------------------------------------------
 def test_nhwc_streaming_layers_match_torch():
     g = torch.Generator().manual_seed(11)
