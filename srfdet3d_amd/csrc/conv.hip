@@ -950,59 +950,90 @@ extern "C" int srf_conv_gemm_nhwc(const float *x, int N, int H, int W, int Cin, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// srf_stem_conv_nchw: the first layer of the image backbone, Conv2d(Cin <= 4, Cout, 3, stride 2, padding 1) + scale / shift
+// srf_stem_conv_nchw: the first layer of the image backbone, Conv2d(Cin <= 4, 64, 3, stride 2, padding 1) + scale / shift
 // + ReLU, reading the NCHW camera images and writing channels-last (VoVNet stem_1: 3 -> 64 on 6 x 928 x 1600; 7.7 GFLOP,
-// HBM-bound: 107 MB in, 570 MB out).  256 threads = 16 output pixels x 16 channel quads (Cout == 64); the 27 x 64
-// weights sit in LDS; taps summed in (ci, ky, kx) order, one fma chain per output.
+// HBM-bound: 107 MB in, 570 MB out).  A workgroup owns 256 consecutive output pixels: every thread gathers the 9 Cin taps
+// of its pixel once (the first version had 16 threads of a pixel each fetch all taps and spent its time in the texture
+// path) into an LDS im2col image A[k][pixel], then the 4 waves multiply their 64 pixels by the 64 channels on
+// v_mfma_f32_32x32x2_f32: k = ci * 9 + ky * 3 + kx ascending, one fma chain per output, zero taps add +0.
 // ---------------------------------------------------------------------------------------------------------------------
+#define ST_PIX 256
 __global__ __launch_bounds__(256) void srf_stem_conv_nchw_k(const float *__restrict__ x, int N, int Cin, int H, int W, int Ho, int Wo,
                                                            const float *__restrict__ wt, const float *__restrict__ scale,
                                                            const float *__restrict__ shift, int relu, float *__restrict__ y, long long y_ld)
 {
-    __shared__ f32x4 s_wt[36][16];  // [ci * 9 + ky * 3 + kx][channel quad]
-    const int tid = threadIdx.x;
-    for (int e = tid; e < Cin * 9 * 16; e += 256) {
-        const int t = e >> 4, cq = e & 15;
-        f32x4 v;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = wt[(size_t)(cq * 4 + c) * Cin * 9 + t];
-        s_wt[t][cq] = v;
+    __shared__ float s_a[36][ST_PIX];  // [k][pixel]
+    __shared__ float s_w[36][64];      // [k][channel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int K = Cin * 9, KP = (K + 1) & ~1;
+    for (int e = tid; e < KP * 64; e += 256) {
+        const int k = e >> 6, co = e & 63;
+        s_w[k][co] = k < K ? wt[(size_t)co * K + k] : 0.f;
     }
-    __syncthreads();
-    const int cq = tid & 15;
-    const long long p = (long long)blockIdx.x * 16 + (tid >> 4);
     const long long total = (long long)N * Ho * Wo;
-    if (p >= total) return;
-    const int ox = (int)(p % Wo);
-    const long long r = p / Wo;
-    const int oy = (int)(r % Ho), n = (int)(r / Ho);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int ci = 0; ci < Cin; ++ci) {
-        const float *xc = x + ((size_t)n * Cin + ci) * H * W;
+    const long long p = (long long)blockIdx.x * ST_PIX + tid;
+    {
+        const bool live = p < total;
+        const long long pp = live ? p : 0;
+        const int ox = (int)(pp % Wo);
+        const long long r = pp / Wo;
+        const int oy = (int)(r % Ho), n = (int)(r / Ho);
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float *xc = x + ((size_t)n * Cin + ci) * H * W;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = 2 * oy - 1 + ky;
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = 2 * oy - 1 + ky;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = 2 * ox - 1 + kx;
-                const float v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xc[(size_t)iy * W + ix] : 0.f;
-                const f32x4 w4 = s_wt[ci * 9 + ky * 3 + kx][cq];
-                acc[0] = __fmaf_rn(v, w4[0], acc[0]);
-                acc[1] = __fmaf_rn(v, w4[1], acc[1]);
-                acc[2] = __fmaf_rn(v, w4[2], acc[2]);
-                acc[3] = __fmaf_rn(v, w4[3], acc[3]);
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = 2 * ox - 1 + kx;
+                    s_a[ci * 9 + ky * 3 + kx][tid] = (live && iy >= 0 && iy < H && ix >= 0 && ix < W) ? xc[(size_t)iy * W + ix] : 0.f;
+                }
             }
         }
+        if (KP > K) s_a[K][tid] = 0.f;
     }
+    __syncthreads();
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        float o = acc[c];
-        if (scale) o = __fmaf_rn(o, scale[cq * 4 + c], shift ? shift[cq * 4 + c] : 0.f);
-        else if (shift) o = __fadd_rn(o, shift[cq * 4 + c]);
-        if (relu) o = fmaxf(o, 0.f);
-        acc[c] = o;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int ksteps = KP >> 1;
+    for (int s2 = 0; s2 < ksteps; ++s2) {
+        const int k = 2 * s2 + lh;
+        const float a0 = s_a[k][wave * 64 + li], a1 = s_a[k][wave * 64 + 32 + li];
+        const float b0 = s_w[k][li], b1 = s_w[k][32 + li];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
-    *reinterpret_cast<f32x4 *>(y + p * y_ld + cq * 4) = acc;
+    float sc[2], sh[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        sc[j] = scale ? scale[j * 32 + li] : 1.f;
+        sh[j] = shift ? shift[j * 32 + li] : 0.f;
+    }
+    const long long prow = (long long)blockIdx.x * ST_PIX + wave * 64 + 4 * lh;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long q = prow + i * 32 + (r & 3) + 8 * (r >> 2);
+            if (q < total) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float o = acc[i][j][r];
+                    if (scale) o = __fmaf_rn(o, sc[j], sh[j]);
+                    else if (shift) o = __fadd_rn(o, sh[j]);
+                    if (relu) o = fmaxf(o, 0.f);
+                    y[q * y_ld + j * 32 + li] = o;
+                }
+            }
+        }
 }
 
 extern "C" int srf_stem_conv_nchw(const float *x, int N, int Cin, int H, int W, const float *Wt, int Cout, const float *scale,
@@ -1014,7 +1045,7 @@ extern "C" int srf_stem_conv_nchw(const float *x, int N, int Cin, int H, int W, 
     if (!x || !Wt || !y) return SRF_EINVAL;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long total = (long long)N * Ho * Wo;
-    hipLaunchKernelGGL(srf_stem_conv_nchw_k, dim3(srf_ceil_div(total, 16)), dim3(256), 0, (hipStream_t)stream, x, N, Cin, H, W, Ho, Wo, Wt, scale,
+    hipLaunchKernelGGL(srf_stem_conv_nchw_k, dim3(srf_ceil_div(total, ST_PIX)), dim3(256), 0, (hipStream_t)stream, x, N, Cin, H, W, Ho, Wo, Wt, scale,
                        shift, relu, y, y_ld);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
