@@ -64,13 +64,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not replay the static tail as a hipGraph")
     ap.add_argument("--whole-frame", default="auto", choices=["auto", "on", "off"],
-                    help="replay voxelization + sparse encoder + tail as ONE hipGraph (capacity-padded static shapes). auto = on "
-                         "for the LiDAR-only workloads; off for LC, where it is worth 1.2 %% (12.63 instead of 12.48 frames/s) and "
-                         "would take the per-launch HIP events of `roofline` out of the timed region")
-    ap.add_argument("--img-overlap", action="store_true",
-                    help="LC only: replay the image-branch graph on a side stream beside the LiDAR half (about 3.8 %% "
-                         "more frames/s, but the sparse-conv kernels then share the chip and their per-launch times "
-                         "no longer describe the kernel; off by default so that `roofline` stays a kernel figure)")
+                    help="replay voxelization + sparse encoder + tail as hipGraphs with capacity-padded static shapes (one graph "
+                         "for the LiDAR-only workloads; with cameras two, the BEV half and the decoder half, so that the camera "
+                         "graph runs beside the first).  auto = on wherever the configuration is eligible.  The per-launch HIP "
+                         "events of `roofline` are then taken on eager frames right after the timed region")
+    ap.add_argument("--img-overlap", default="auto", choices=["auto", "on", "off"],
+                    help="LC only: replay the image-branch graph on a side stream beside the LiDAR half.  auto = on when the "
+                         "frame replays as graphs (the kernels of `roofline` are then timed on serial eager frames after the "
+                         "timed region, so sharing the chip does not distort them), off with --whole-frame off")
     ap.add_argument("--img-precomputed", action="store_true",
                     help="LC only: the camera features (VoVNet -> FPN) are computed once before the timed region and reused: the "
                          "'image features pre-computed' line of SURVEY.md 8d / BASELINE.md C3 (decoder + LiDAR path with the fusion "
@@ -108,8 +109,11 @@ def main():
     import copy
     model = copy.deepcopy(model_cpu).to(dev)
     if not args.eager:
-        whole = args.whole_frame == "on" or (args.whole_frame == "auto" and not model.use_img)
+        whole = args.whole_frame != "off"
+        args.img_overlap = model.use_img and (args.img_overlap == "on" or (args.img_overlap == "auto" and whole))
         model.enable_hip_graphs(img_overlap=args.img_overlap, whole_frame=whole)
+    else:
+        args.img_overlap = False
     if args.img_dtype != "fp32":
         model.img_autocast_dtype = dict(fp16=torch.float16, bf16=torch.bfloat16)[args.img_dtype]
         model.img_backbone.to(memory_format=torch.channels_last)

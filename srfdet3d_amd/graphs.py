@@ -282,32 +282,51 @@ class GraphedFrame:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad(), _graph_safe_convs(safe):
             for _ in range(self.warmup):
-                ref = self._run(static_pts, caps, sm.metas, img_feats)
+                ref_x, ref_counts = self._run_bev(static_pts, caps)
+                ref = self._run_head(ref_x, sm.metas, img_feats)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        ref = [ref[0].clone(), ref[1].clone(), ref[2][0].clone()]
+        ref_x = [t.clone() for t in ref_x]
+        ref = [ref[0].clone(), ref[1].clone(), ref_counts[0].clone()]
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), _graph_safe_convs(safe), torch.cuda.graph(graph):
-            scores, boxes, counts, sel = self._run(static_pts, caps, sm.metas, img_feats)
-        _validate(graph, [scores, boxes, counts[0]], ref, "whole-frame graph")
+        head_graph = None
+        if img_feats is None:
+            with torch.no_grad(), _graph_safe_convs(safe), torch.cuda.graph(graph):
+                x, counts = self._run_bev(static_pts, caps)
+                scores, boxes, sel = self._run_head(x, sm.metas, img_feats)
+            _validate(graph, [scores, boxes, counts[0]], ref, "whole-frame graph")
+        else:
+            # with cameras the frame is two graphs: everything up to the BEV pyramid needs no image feature and replays
+            # while the camera graph is still running on its own stream; the decoder graph follows the join
+            with torch.no_grad(), _graph_safe_convs(safe), torch.cuda.graph(graph):
+                x, counts = self._run_bev(static_pts, caps)
+            _validate(graph, list(x) + [counts[0]], ref_x + [ref[2]], "whole-frame graph (BEV half)")
+            head_graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), _graph_safe_convs(safe), torch.cuda.graph(head_graph, pool=graph.pool()):
+                scores, boxes, sel = self._run_head(x, sm.metas, img_feats)
+            _validate(head_graph, [scores, boxes], ref[:2], "whole-frame graph (decoder half)")
         self.stats["captures"] += 1
-        self.entry = dict(graph=graph, pts=static_pts, far=far, n_cap=n_cap, nf=pts.shape[1], caps=caps, scores=scores, boxes=boxes,
-                          counts=counts[0], limits=counts[1], sel=sel, metas=sm,
+        self.entry = dict(graph=graph, head_graph=head_graph, pts=static_pts, far=far, n_cap=n_cap, nf=pts.shape[1], caps=caps,
+                          scores=scores, boxes=boxes, counts=counts[0], limits=counts[1], sel=sel, metas=sm, bev=x,
                           img_key=None if img_feats is None else tuple(f.data_ptr() for f in img_feats))
         return self.entry
 
-    def _run(self, static_pts, caps, img_metas, img_feats=None):
+    def _run_bev(self, static_pts, caps):
         m = self.model
         bev, counts = m.extract_bev_static(static_pts, caps)
         x = m.pts_backbone(bev)
         if m.pts_neck is not None:
             x = m.pts_neck(x)
+        dev_counts = torch.cat([c[1].view(1) for c in counts])
+        limits = [c[2] for c in counts]
+        return tuple(x), (dev_counts, limits)
+
+    def _run_head(self, x, img_metas, img_feats=None):
+        m = self.model
         logits, boxes = m.bbox_head(img_feats, x, img_metas)
         scores, dec = m.bbox_head.decode(logits, boxes)
         sel = m.bbox_head.select_static(scores, dec) if getattr(m.bbox_head, "use_nms", False) else None
-        dev_counts = torch.cat([c[1].view(1) for c in counts])
-        limits = [c[2] for c in counts]
-        return scores, dec, (dev_counts, limits), sel
+        return scores, dec, sel
 
     def _eager(self, pts, img_metas, img_feats=None):
         m = self.model
@@ -320,12 +339,16 @@ class GraphedFrame:
         scores, dec = m.bbox_head.decode(logits, boxes)
         return scores, dec, sizes
 
-    def __call__(self, pts, img_metas, img_feats=None):
-        """img_feats: persistent image-feature buffers (GraphedImageBranch) already scheduled on the current stream."""
+    def __call__(self, pts, img_metas, img_feats=None, img_done=None):
+        """img_feats: persistent image-feature buffers of a GraphedImageBranch; img_done: the event its stream records when
+        they are complete (None: they are already ordered before the current stream)."""
         e = self.entry
+        cur = torch.cuda.current_stream()
         img_key = None if img_feats is None else tuple(f.data_ptr() for f in img_feats)
         if (e is None or pts.shape[0] > e["n_cap"] or pts.shape[1] != e["nf"] or e["img_key"] != img_key
                 or not e["metas"].refresh(img_metas)):
+            if img_done is not None:
+                cur.wait_event(img_done)
             scores, dec, sizes = self._eager(pts, img_metas, img_feats)
             if e is not None:  # keep the larger of the old and new requirements
                 sizes = {k: max(v, int(e["caps"][k] / self.HEADROOM)) for k, v in sizes.items()}
@@ -337,6 +360,10 @@ class GraphedFrame:
         if n < e["n_cap"]:
             e["pts"][n:].copy_(e["far"][n:])
         e["graph"].replay()
+        if img_done is not None:
+            cur.wait_event(img_done)   # the join: the camera graph ran beside the BEV half
+        if e["head_graph"] is not None:
+            e["head_graph"].replay()
         self.stats["replays"] += 1
         counts = e["counts"].tolist()  # the one read-back of the frame; the detections are complete by then
         if any(c > lim for c, lim in zip(counts, e["limits"])):

@@ -104,11 +104,10 @@ class SRFDet(BaseModule):
     def _test_bboxes_graphs(self, img, points, img_metas):
         if (self._graphed_frame is not None and not self.training and points is not None and len(points) == 1
                 and (img is None or self._graphed_img is not None)):
-            img_feats = None
+            img_feats = img_done = None
             if img is not None:
                 img_feats, img_done = self._graphed_img(img, img_metas)
-                torch.cuda.current_stream().wait_event(img_done)
-            return self._finish(*self._graphed_frame(points[0], img_metas, img_feats), img_metas)
+            return self._finish(*self._graphed_frame(points[0], img_metas, img_feats, img_done), img_metas)
         if self._graphed_tail is not None and not self.training and points is not None:
             img_static = False
             if img is not None and self._graphed_img is not None:
