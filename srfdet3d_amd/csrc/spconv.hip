@@ -787,7 +787,10 @@ __global__ __launch_bounds__(256) void srf_spconv_direct64_k(const float *__rest
 }
 
 // =====================================================================================================================
-// COUT = 128, Cin in {64, 128}, compacted offsets ("gs": gather rows, scatter into an LDS-resident output tile).
+// COUT = 128, Cin in {64, 128} and COUT = Cin = 64, compacted offsets ("gs": gather rows, scatter into an LDS-resident output
+// tile).  (COUT = 64: a wave owns one 16-column MFMA tile instead of two, the output tile is half as wide and up to 120 rows
+// tall; on the 64-channel level of a nuScenes sweep only 40 % of the (row, offset) pairs exist, and the output-stationary
+// srf_spconv_direct64_k spent 60 % of its MFMAs on zeros: 159 -> 107 us per layer.)
 // In the output-stationary kernels above a 32-row tile spends one full MFMA pass on every kernel offset any of its rows
 // uses, although only 16-20 of the 27 neighbours of a row exist: 40 % of the issued MFMAs multiply zeros (59 % useful at
 // the 128-channel level of a nuScenes sweep, 73 % on a Waymo sweep).  Here a workgroup owns up to 88 output rows whose
@@ -837,7 +840,10 @@ static bool srf_gs_enabled()
     }();
     return on;
 }
-static bool srf_gs_layout(int Cin, int Cout) { return srf_gs_enabled() && Cout == 128 && (Cin == 64 || Cin == 128); }
+static bool srf_gs_layout(int Cin, int Cout)
+{
+    return srf_gs_enabled() && ((Cout == 128 && (Cin == 64 || Cin == 128)) || (Cout == 64 && Cin == 64));
+}
 
 __global__ __launch_bounds__(256) void srf_pack_weights_gs_k(const float *__restrict__ W, int K, int Cin, int Cout, int nchunk,
                                                            float *__restrict__ P)
@@ -845,8 +851,10 @@ __global__ __launch_bounds__(256) void srf_pack_weights_gs_k(const float *__rest
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)K * nchunk * Cout * 32;
     if (t >= total) return;
-    const int i = (int)(t & 3), lane = (int)((t >> 2) & 63), g = (int)((t >> 8) & 3), wc = (int)((t >> 10) & 3);
-    const long long rest = t >> 12;
+    const int i = (int)(t & 3), lane = (int)((t >> 2) & 63), g = (int)((t >> 8) & 3);
+    const int per = Cout * 32;  // elements per (offset, chunk): Cout / 32 column blocks x 4 groups x 64 lanes x 4
+    const int wc = (int)((t % per) >> 10);
+    const long long rest = t / per;
     const int chunk = (int)(rest % nchunk), k = (int)(rest / nchunk);
     const int idx = 4 * g + i;
     const int col = wc * 32 + 16 * (idx >> 3) + (lane & 15);
@@ -871,7 +879,7 @@ __device__ __forceinline__ void srf_gs_gather(const float *__restrict__ in, cons
 
 // A image of one group: [chunk][row 0..15][32], channel 4q + j of a chunk at position j*8 + q (lane (row, j) of the
 // 16x16x4 MFMA reads its eight steps as two b128), 16-byte units XOR-swizzled by (row >> 1) & 7
-template <int NCH, int NA>
+template <int NCH, int NA, int CHS = SRF_GS_CHS>
 __device__ __forceinline__ void srf_gs_store(float *s_a, const f32x4 (&ra)[NA])
 {
     const int tid = threadIdx.x;
@@ -881,69 +889,101 @@ __device__ __forceinline__ void srf_gs_store(float *s_a, const f32x4 (&ra)[NA])
         const int r = e / (8 * NCH), qq = e % (8 * NCH);
         const int ch = qq >> 3, q = qq & 7;
         const int swz = (r >> 1) & 7;
-        float *img = s_a + ch * SRF_GS_CHS + r * 32 + (q & 3);
+        float *img = s_a + ch * CHS + r * 32 + (q & 3);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) img[((jj * 2 + (q >> 2)) ^ swz) << 2] = ra[j][jj];
     }
 }
 
-template <int NCH, int NA>
+// B operands of one (offset, chunk) for this wave.  COUT = 128: the wave owns 32 columns (two 16-column MFMA tiles, four
+// f32x4); COUT = 64: 16 columns (tile `wave & 1` of column block `wave >> 1`, two f32x4 of the same packed image)
+template <int NCH, int COUT>
+__device__ __forceinline__ void srf_gs_load_b(f32x4 (&b)[COUT / 32], const float *__restrict__ Wg, int k, int chunk, int wave, int lane)
+{
+    constexpr int NWC = COUT / 32;
+    const int wc = COUT == 128 ? wave : (wave >> 1), g0 = COUT == 128 ? 0 : 2 * (wave & 1);
+#pragma unroll
+    for (int g = 0; g < COUT / 32; ++g)
+        b[g] = *reinterpret_cast<const f32x4 *>(Wg + (((((size_t)k * NCH + chunk) * NWC + wc) * 4 + g0 + g) * 64 + lane) * 4);
+}
+
+// GP = groups of 16 rows per step (one gather / barrier per step).  COUT = 64 runs GP = 2: a wave's share of a group is
+// only 16 MFMAs (512 cycles), less than the L2 latency of the next gather, so a step carries two groups (two independent
+// accumulator chains) and the tile needs a third fewer steps.
+template <int NCH, int NA, int COUT, int LS, int OS, int TMAX, int GP>
 __device__ __forceinline__ void srf_gs_offset(const float *__restrict__ in, const float *__restrict__ Wg, int kc, int kn, bool more_k,
                                               const int *s_in, const unsigned char *s_slot, const int *s_cnt, float *s_out,
-                                              float *s_a, int &buf, f32x4 (&bc)[NCH][4], f32x4 (&bn)[NCH][4], f32x4 (&ra)[NA])
+                                              float *s_a, int &buf, f32x4 (&bc)[NCH][COUT / 32], f32x4 (&bn)[NCH][COUT / 32],
+                                              f32x4 (&ra)[NA])
 {
-    const int lane = threadIdx.x & 63, wc = threadIdx.x >> 6;
+    constexpr int NT = COUT / 64;  // 16-column MFMA tiles per wave
+    constexpr int RS = 16 * GP, CHS = RS * 32 + 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int colb = COUT == 128 ? wave * 32 : wave * 16;
     const int n = s_cnt[kc];
-    const int ng = (n + 15) >> 4;
+    const int ng = (n + RS - 1) / RS;
     const int ar = lane & 15, aj = lane >> 4;
     const int a_swz = (ar >> 1) & 7;
     for (int g = 0; g < ng; ++g) {
         const bool last = g + 1 == ng;
         const bool has_next = !last || more_k;
-        if (last && more_k) {  // B of the next offset, one whole group of MFMAs ahead, into the other register set
+        if (last && more_k) {  // B of the next offset, one whole step of MFMAs ahead, into the other register set
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) srf_dir_load_b<NCH>(bn[c], Wg, kn, c, wc, lane);
+            for (int c = 0; c < NCH; ++c) srf_gs_load_b<NCH, COUT>(bn[c], Wg, kn, c, wave, lane);
         }
-        if (has_next) srf_gs_gather<NCH, NA>(in, last ? s_in + kn * SRF_GS_LS : s_in + kc * SRF_GS_LS + (g + 1) * 16, ra);
-        // all A fragments of the group first (8 ds_read_b128 in flight together, one exposed LDS latency per group instead of
-        // one per chunk), then the accumulators of this group out of the output tile
-        const float *abase = s_a + buf * (NCH * SRF_GS_CHS) + ar * 32;
-        f32x4 af[NCH][2];
+        if (has_next) srf_gs_gather<NCH, NA>(in, last ? s_in + kn * LS : s_in + kc * LS + (g + 1) * RS, ra);
+        // all A fragments of the step first (ds_read_b128 in flight together, one exposed LDS latency per step instead of
+        // one per chunk), then the accumulators of its rows out of the output tile
+        f32x4 af[GP][NCH][2];
+        f32x4 acc[GP][NT];
+        int oaddr[GP][4];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            af[c][0] = *reinterpret_cast<const f32x4 *>(abase + c * SRF_GS_CHS + (((aj << 1) ^ a_swz) << 2));
-            af[c][1] = *reinterpret_cast<const f32x4 *>(abase + c * SRF_GS_CHS + ((((aj << 1) + 1) ^ a_swz) << 2));
+        for (int gp = 0; gp < GP; ++gp) {
+            const float *abase = s_a + buf * (NCH * CHS) + (gp * 16 + ar) * 32;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                af[gp][c][0] = *reinterpret_cast<const f32x4 *>(abase + c * CHS + (((aj << 1) ^ a_swz) << 2));
+                af[gp][c][1] = *reinterpret_cast<const f32x4 *>(abase + c * CHS + ((((aj << 1) + 1) ^ a_swz) << 2));
+            }
         }
-        // output slots of the group's 16 rows; padding rows of a last group name the spare row SRF_GS_TMAX
-        const unsigned sl4 = *reinterpret_cast<const unsigned *>(s_slot + kc * SRF_GS_LS + g * 16 + aj * 4);
-        f32x4 acc[2];
-        int oaddr[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            oaddr[jj] = (int)((sl4 >> (8 * jj)) & 255u) * SRF_GS_OS + wc * 32 + ar;
+        for (int gp = 0; gp < GP; ++gp) {
+            // output slots of the group's 16 rows; padding rows of a last step name the spare row TMAX
+            const unsigned sl4 = *reinterpret_cast<const unsigned *>(s_slot + kc * LS + (g * GP + gp) * 16 + aj * 4);
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[cb][jj] = s_out[oaddr[jj] + cb * 16];
+            for (int jj = 0; jj < 4; ++jj) {
+                oaddr[gp][jj] = (int)((sl4 >> (8 * jj)) & 255u) * OS + colb + ar;
+#pragma unroll
+                for (int cb = 0; cb < NT; ++cb) acc[gp][cb][jj] = s_out[oaddr[gp][jj] + cb * 16];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMA block
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const float a = af[c][s >> 2][s & 3];
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[c][s >> 2][s & 3], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[c][2 + (s >> 2)][s & 3], acc[1], 0, 0, 0);
+#pragma unroll
+                for (int gp = 0; gp < GP; ++gp) {
+                    const float a = af[gp][c][s >> 2][s & 3];
+                    acc[gp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[c][s >> 2][s & 3], acc[gp][0], 0, 0, 0);
+                    if (NT == 2)
+                        acc[gp][NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[c][COUT / 32 - 2 + (s >> 2)][s & 3], acc[gp][NT - 1], 0, 0, 0);
+                }
             }
         }
+        // a padding slot (spare row TMAX) may appear in both groups of a step: both write garbage there, never read back
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            s_out[oaddr[jj]] = acc[0][jj];
-            s_out[oaddr[jj] + 16] = acc[1][jj];
-        }
-        // every load issued in this group has landed before the next one starts.  Stated explicitly (s_waitcnt vmcnt(0)):
+        for (int gp = 0; gp < GP; ++gp)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                for (int cb = 0; cb < NT; ++cb) s_out[oaddr[gp][jj] + cb * 16] = acc[gp][cb][jj];
+            }
+        // every load issued in this step has landed before the next one starts.  Stated explicitly (s_waitcnt vmcnt(0)):
         // the compiler cannot tie "B was prefetched" to "the gather was waited for" across the two branches and would
-        // otherwise guard the next group's MFMAs with vmcnt waits that also catch that group's own fresh loads
+        // otherwise guard the next step's MFMAs with vmcnt waits that also catch that step's own fresh loads
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        if (has_next) srf_gs_store<NCH, NA>(s_a + (buf ^ 1) * (NCH * SRF_GS_CHS), ra);
+        if (has_next) srf_gs_store<NCH, NA, CHS>(s_a + (buf ^ 1) * (NCH * CHS), ra);
         __syncthreads();
         buf ^= 1;
     }
@@ -1095,7 +1135,7 @@ extern "C" int srf_spconv_tiles_build(const int *nbr, int nbr_stride, int K, int
     return SRF_OK;
 }
 
-template <int NCH>
+template <int NCH, int COUT>
 __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restrict__ in, const float *__restrict__ Wg, int K,
                                                         const int *__restrict__ nbr, int nbr_stride, int A_out,
                                                         const float *__restrict__ alpha, const float *__restrict__ beta,
@@ -1103,14 +1143,23 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
                                                         float *__restrict__ out, const int *__restrict__ rows_dev,
                                                         const int *__restrict__ tiles)
 {
-    constexpr int COUT = 128, NA = 16 * 8 * NCH / 256, LS = SRF_GS_LS, NKW = (SRF_KMAX + 3) / 4;
+    // COUT = 64 (Cin = 64): a wave owns one 16-column MFMA tile, the output tile is half as wide and may be taller
+    // groups of 16 rows per step (srf_gs_offset).  COUT = 64, nuScenes level 3 (59.6k rows, 10.9 pairs per row): 107 us with 1,
+    // 123 us with 2; 64-row tiles walked by two workgroups per range (four per CU) 118 us; B fetched a whole offset ahead 113 us.
+    // Ablations of the 107 us: without MFMAs 70, without the gathers 99, without barriers 100, prologue + epilogue alone 14.
+    constexpr int GP = 1;
+    constexpr int NA = 16 * GP * 8 * NCH / 256, NKW = (SRF_KMAX + 3) / 4, CHS = 16 * GP * 32 + 8;
+    constexpr int TMAX = COUT == 128 ? SRF_GS_TMAX : 120, LS = COUT == 128 ? SRF_GS_LS : 128, OS = COUT + 4;
+    constexpr int SPLIT = 1;  // workgroups per range of the row cut (2 with 64-row tiles was slower for COUT = 64: 118 vs 107 us)
+    static_assert(COUT == 128 || COUT == 64, "column tiling of the waves");
+    static_assert(TMAX <= 128 && TMAX <= LS && LS % (16 * GP) == 0, "two ballot segments of 64 rows; whole groups per list");
     static_assert(NA >= 1, "a group is at least one f32x4 per thread");
     __shared__ int s_in[SRF_KMAX * LS];                 // per offset: input rows of the outputs that have this neighbour
     __shared__ __attribute__((aligned(4))) unsigned char s_slot[SRF_KMAX * LS];  // ... and their slot in the output tile
     __shared__ int s_cnt[SRF_KMAX];
     __shared__ int s_klist[SRF_KMAX + 1];
-    __shared__ __attribute__((aligned(16))) float s_out[(SRF_GS_TMAX + 1) * SRF_GS_OS];  // + the spare row of padding slots
-    __shared__ __attribute__((aligned(16))) float s_a[2 * NCH * SRF_GS_CHS];
+    __shared__ __attribute__((aligned(16))) float s_out[(TMAX + 1) * OS];  // + the spare row of padding slots
+    __shared__ __attribute__((aligned(16))) float s_a[2 * NCH * CHS];
 
     const int A_cap = A_out;
     if (rows_dev) {  // static-shape levels: rows >= *rows_dev are padding; their tiles do nothing
@@ -1122,11 +1171,17 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
     int range0, range1;
     if (tiles) {
         const int T = srf_gs_ranges(A_cap);
-        if ((int)blockIdx.x >= T) return;
-        const int t = srf_xcd_tile(blockIdx.x, T);
+        if ((int)blockIdx.x >= T * SPLIT) return;
+        const int ts = srf_xcd_tile(blockIdx.x, T * SPLIT);
+        const int t = ts / SPLIT, part = ts - t * SPLIT;
         range0 = tiles[t];
         range1 = tiles[t + 1];
         range1 = range1 < A_out ? range1 : A_out;
+        if (SPLIT > 1 && range1 > range0) {  // this workgroup's share of the range: whole multiples of 8 rows
+            const int per = (((range1 - range0 + SPLIT - 1) / SPLIT) + 7) & ~7;
+            range0 += part * per;
+            range1 = range0 + per < range1 ? range0 + per : range1;
+        }
     } else {
         const int tm = srf_gs_tile_rows(A_out);
         const int n_tiles = (A_out + tm - 1) / tm;
@@ -1135,8 +1190,8 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
         range1 = range0 + tm < A_out ? range0 + tm : A_out;
     }
     if (range1 <= range0) return;
-    const int nsub = (range1 - range0 + SRF_GS_TMAX - 1) / SRF_GS_TMAX;
-    const int TM = (((range1 - range0 + nsub - 1) / nsub) + 7) & ~7;  // <= SRF_GS_TMAX (a multiple of 8)
+    const int nsub = (range1 - range0 + TMAX - 1) / TMAX;
+    const int TM = (((range1 - range0 + nsub - 1) / nsub) + 7) & ~7;  // <= TMAX (a multiple of 8)
     for (int row0 = range0; row0 < range1; row0 += TM) {
     const int row_end = row0 + TM < range1 ? row0 + TM : range1;  // rows of this sub-tile: [row0, row_end)
     // An opaque zero: the address arithmetic of the prologue / epilogue below is invariant across sub-tiles, and hoisted
@@ -1144,7 +1199,7 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
     // (11 MB of scratch write-back per launch).  Tied to this value it is recomputed per sub-tile instead.
     int zero = 0;
     asm volatile("" : "+s"(zero));
-    for (int e = tid; e < TM * SRF_GS_OS / 4; e += 256) reinterpret_cast<f32x4 *>(s_out)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < TM * OS / 4; e += 256) reinterpret_cast<f32x4 *>(s_out)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
     // compaction: the wave's offsets (wave, wave + 4, ...), rows in two segments of 64; all loads in flight together
     int nv[NKW][2];
 #pragma unroll
@@ -1161,10 +1216,10 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
         int *lin = s_in + (k + zero) * LS;
         unsigned char *lsl = s_slot + (k + zero) * LS;
         lin[lane] = 0;  // padding of the last group: input row 0 into the spare output row (same wave: ordered before the
-        lsl[lane] = (unsigned char)SRF_GS_TMAX;  // compacted stores below)
+        lsl[lane] = (unsigned char)TMAX;  // compacted stores below)
         if (lane < LS - 64) {
             lin[64 + lane] = 0;
-            lsl[64 + lane] = (unsigned char)SRF_GS_TMAX;
+            lsl[64 + lane] = (unsigned char)TMAX;
         }
         int base = 0;
 #pragma unroll
@@ -1190,14 +1245,14 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
     __syncthreads();
     const int ntap = s_klist[SRF_KMAX];
 
-    f32x4 b0[NCH][4], b1[NCH][4], ra[NA];
+    f32x4 b0[NCH][COUT / 32], b1[NCH][COUT / 32], ra[NA];
     int buf = 0;
     if (ntap > 0) {
         const int k0 = s_klist[0];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) srf_dir_load_b<NCH>(b0[c], Wg, k0, c, wave, lane);
+        for (int c = 0; c < NCH; ++c) srf_gs_load_b<NCH, COUT>(b0[c], Wg, k0, c, wave, lane);
         srf_gs_gather<NCH, NA>(in, s_in + k0 * LS, ra);
-        srf_gs_store<NCH, NA>(s_a, ra);
+        srf_gs_store<NCH, NA, CHS>(s_a, ra);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing is in flight when the first group starts (see srf_gs_offset)
     __syncthreads();
@@ -1205,26 +1260,27 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
         {
             const bool more = tk + 1 < ntap;
             const int kc = s_klist[tk], kn = more ? s_klist[tk + 1] : kc;
-            srf_gs_offset<NCH, NA>(in, Wg, kc, kn, more, s_in, s_slot, s_cnt, s_out, s_a, buf, b0, b1, ra);
+            srf_gs_offset<NCH, NA, COUT, LS, OS, TMAX, GP>(in, Wg, kc, kn, more, s_in, s_slot, s_cnt, s_out, s_a, buf, b0, b1, ra);
         }
         if (tk + 1 < ntap) {
             const bool more = tk + 2 < ntap;
             const int kc = s_klist[tk + 1], kn = more ? s_klist[tk + 2] : kc;
-            srf_gs_offset<NCH, NA>(in, Wg, kc, kn, more, s_in, s_slot, s_cnt, s_out, s_a, buf, b1, b0, ra);
+            srf_gs_offset<NCH, NA, COUT, LS, OS, TMAX, GP>(in, Wg, kc, kn, more, s_in, s_slot, s_cnt, s_out, s_a, buf, b1, b0, ra);
         }
     }
 
     // epilogue: every output row once, BN / residual / ReLU in registers, 512 B per row and store
-    const int c4 = ((tid & 31) + zero) * 4;
+    constexpr int CQ = COUT / 4;  // float4 per output row
+    const int c4 = ((tid & (CQ - 1)) + zero) * 4;
     f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
     if (alpha) {
         al = *reinterpret_cast<const f32x4 *>(alpha + c4);
         be = *reinterpret_cast<const f32x4 *>(beta + c4);
     }
-    for (int r = tid >> 5; r < TM; r += 8) {
+    for (int r = tid / CQ; r < TM; r += 256 / CQ) {
         const int row = row0 + r;
         if (row >= row_end) break;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(s_out + r * SRF_GS_OS + c4);
+        f32x4 v = *reinterpret_cast<const f32x4 *>(s_out + r * OS + c4);
         f32x4 rs = {0.f, 0.f, 0.f, 0.f};
         if (residual) rs = *reinterpret_cast<const f32x4 *>(residual + (size_t)row * COUT + c4);
 #pragma unroll
@@ -1259,6 +1315,12 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
                            0, st, SRF_ARGS);
         break;
     case 64:
+        if (srf_gs_layout(Cin, Cout)) {
+            const dim3 grid(tiles ? srf_gs_ranges(A_out) : SRF_GS_SLOTS * srf_gs_rounds(A_out));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gs_k<2, 64>), grid, dim3(256), 0, st, in, W_packed, K, nbr, nbr_stride, A_out,
+                               alpha, beta, residual, relu, out, rows_dev, tiles);
+            break;
+        }
         if (srf_direct_layout(Cin, Cout)) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_direct64_k<2>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0, st, in, W_packed,
                                K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev);
@@ -1272,10 +1334,10 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
             // >= the tiles of any live row count <= A_out / the ranges srf_spconv_tiles_build cut for this capacity
             const dim3 grid(tiles ? srf_gs_ranges(A_out) : SRF_GS_SLOTS * srf_gs_rounds(A_out));
             if (Cin == 128)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gs_k<4>), grid, dim3(256), 0, st, in, W_packed, K, nbr, nbr_stride,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gs_k<4, 128>), grid, dim3(256), 0, st, in, W_packed, K, nbr, nbr_stride,
                                    A_out, alpha, beta, residual, relu, out, rows_dev, tiles);
             else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gs_k<2>), grid, dim3(256), 0, st, in, W_packed, K, nbr, nbr_stride,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gs_k<2, 128>), grid, dim3(256), 0, st, in, W_packed, K, nbr, nbr_stride,
                                    A_out, alpha, beta, residual, relu, out, rows_dev, tiles);
             break;
         }

@@ -143,7 +143,8 @@ def test_spconv_tiles_cut_rows_by_pair_count(dev, n, live):
         assert per.max() - per.min() <= 2 * (27 + 12)
 
 
-def test_spconv_tiles_with_padded_rows(dev):
+@pytest.mark.parametrize("C", [128, 64])
+def test_spconv_tiles_with_padded_rows(dev, C):
     """static-shape level: capacity-sized rulebook whose tail rows are padding (-1), device row count -> same rows out."""
     rng = np.random.default_rng(5)
     idx = _level1(n=5000)
@@ -152,8 +153,8 @@ def test_spconv_tiles_with_padded_rows(dev):
     cap = A + 700
     nbr_pad = np.full((27, cap), -1, np.int32)
     nbr_pad[:, :A] = nbr
-    feats = rng.standard_normal((A, 128)).astype(np.float32)
-    W = (rng.standard_normal((27, 128, 128)) / 20).astype(np.float32)
+    feats = rng.standard_normal((A, C)).astype(np.float32)
+    W = (rng.standard_normal((27, C, C)) / 20).astype(np.float32)
     ref = O.spconv_fwd(feats, W, nbr)
     tt = lambda x: torch.from_numpy(x).to(dev)
     rows_dev = torch.tensor([A], dtype=torch.int32, device=dev)

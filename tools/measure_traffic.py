@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of the kernels bench.py's `roofline` names, from rocprofv3 PMC counters, collected as
+/opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE, WRITE_SIZE and the SQ counters in SEPARATE
+`--pmc` passes (each with --kernel-trace only), read bytes = 2 x FETCH_SIZE x 1024 on gfx950 (128-B requests are tallied
+as 64 B), WRITE_SIZE x 1024 exact.  Run on the GPU box from the repo root:
+
+    python tools/measure_traffic.py            # writes gpurun_out/traffic/r02_pmc_<name>_traffic.json
+
+and copy the files into profiles/ (bench.py reads profiles/r02_pmc_<name>_traffic.json -> roofline.traffic).
+This process never touches the GPU itself: every pass is `rocprofv3 ... -- python3 <tool>` started as a child.
+"""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out", "traffic")
+SQ = ("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS "
+      "SQ_LDS_BANK_CONFLICT").split()
+
+# name -> (program after `--`, kernel-name substring, description, algorithmic bytes note)
+TARGETS = {
+    "wino3x3": (["tools/prof_img_branch.py", "3"], "srf_wino3x3_k<0",
+                "every srf_wino3x3_k launch of 3 eager passes of the LC camera branch (89 per frame: VoVNet-99, image FPN, img_convs)"),
+    "conv1x1": (["tools/prof_img_branch.py", "3"], "srf_conv1x1_nhwc_k<2, 2, 3, false>",
+                "every srf_conv1x1_nhwc_k launch of the same passes (OSA concat convolutions + FPN laterals, 20 per frame)"),
+    "spconv128": (["tools/bench_spconv.py", "--levels", "4", "--reps", "8"], "srf_spconv_gs_k<4, 128>",
+                  "SubM 128->128 on the 5x184x184 level of frame 2000 (A=34992), BN + residual + ReLU epilogue"),
+    "spconv64": (["tools/bench_spconv.py", "--levels", "3", "--reps", "8"], "srf_spconv_gs_k<2, 64>",
+                 "SubM 64->64 on the 11x368x368 level of frame 2000, BN + residual + ReLU epilogue"),
+}
+
+
+def run_pass(tag, counters, prog):
+    d = os.path.join(OUT, tag)
+    cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", "python3", *prog]
+    env = dict(os.environ, TMPDIR="/tmp")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout[-3000:])
+        raise SystemExit(f"pass {tag} failed")
+    return d, " ".join(cmd[:-len(prog) - 1]).replace(ROOT + "/", "") + " python3 " + " ".join(prog)
+
+
+def counters_of(d, sub):
+    acc = defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if sub in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append((int(r.get("Dispatch_Id", 0)), float(r["Counter_Value"])))
+    return acc
+
+
+def durations_of(d, sub):
+    ts = []
+    for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+        ts += [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f)) if sub in r["Kernel_Name"]]
+    return ts
+
+
+def main():
+    want = sys.argv[1:] or list(TARGETS)
+    os.makedirs(OUT, exist_ok=True)
+    cache = {}
+    for name in want:
+        prog, sub, desc = TARGETS[name]
+        key = " ".join(prog)
+        if key not in cache:
+            tag = prog[0].split("/")[-1].replace(".py", "") + "_" + "_".join(p.strip("-") for p in prog[1:])
+            cache[key] = [run_pass(tag + "_fetch", ["FETCH_SIZE"], prog), run_pass(tag + "_write", ["WRITE_SIZE"], prog),
+                          run_pass(tag + "_sq", SQ, prog)]
+            print("collected", key, flush=True)
+        (df, cf), (dw, cw), (ds, cs) = cache[key]
+        fetch = [v for _, v in sorted(counters_of(df, sub)["FETCH_SIZE"])]
+        write = [v for _, v in sorted(counters_of(dw, sub)["WRITE_SIZE"])]
+        sq = {k: [v for _, v in sorted(vs)] for k, vs in counters_of(ds, sub).items()}
+        if not fetch or not write:
+            print(f"{name}: no dispatch of '{sub}' found", flush=True)
+            continue
+        # the first pass of a multi-pass target is cold (weight packing, first-touch): drop the first third when there are >= 3 passes
+        skip = len(fetch) // 3 if len(fetch) >= 3 else 0
+        n = len(fetch) - skip
+        f_kb, w_kb = sum(fetch[skip:]) / n, sum(write[skip:]) / n
+        dur = durations_of(ds, sub)
+        out = {
+            "kernel": sub, "workload": desc, "launches_averaged": n,
+            "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb,
+            "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B -> read bytes = 2 * FETCH_SIZE * 1024 "
+                          "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
+            "read_bytes_per_launch": int(2 * f_kb * 1024), "write_bytes_per_launch": int(w_kb * 1024),
+            "traffic_bytes_per_launch": int(2 * f_kb * 1024 + w_kb * 1024),
+            "sq_counters": {k: sum(v[skip:]) / max(1, len(v) - skip) for k, v in sq.items()},
+            "avg_duration_us_under_pmc": (sum(dur[skip:]) / max(1, len(dur) - skip)) / 1e3 if dur else None,
+            "commands": [cf, cw, cs],
+        }
+        s = out["sq_counters"]
+        if s.get("SQ_VALU_MFMA_BUSY_CYCLES") and s.get("SQ_BUSY_CYCLES"):
+            # SQ_BUSY_CYCLES is summed over the 32 shader engines, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
+            out["derived"] = {"mfma_busy_fraction_per_simd": round(s["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (s["SQ_BUSY_CYCLES"] / 32), 4)}
+        path = os.path.join(OUT, f"r02_pmc_{name}_traffic.json")
+        with open(path, "w") as fh:
+            json.dump(out, fh, indent=1)
+        print(name, json.dumps({k: out[k] for k in ("launches_averaged", "traffic_bytes_per_launch", "avg_duration_us_under_pmc")}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
