@@ -418,14 +418,18 @@ int srf_nhwc_dwconv3x3s2(const float *x, long long x_ld, int N, int H, int W, in
 /* srf_stage_tail: the row-local remainder of a stage in one launch (srfdet_head.py:1506-1520): FFN + residual + norm3,
  * classification tower + class_logits, regression tower + bboxes_delta + apply_deltas.  obj_in (R x C) is norm2's
  * output; outputs obj_out (R x C), logits (R x ncls), pred (R x Dd).  cls_/reg_ arrays are HOST arrays of n_cls / n_reg
- * device pointers (weights (C x C), LayerNorm gamma/beta) and host eps values.  C == 128, F in {128,...,512}. */
+ * device pointers (weights (C x C), LayerNorm gamma/beta) and host eps values.  C == 128, F in {128,...,512}.
+ * workspace (srf_stage_tail_workspace_bytes(R, C, F), may be NULL): with it the FFN runs as its own launch, one workgroup per
+ * (32 rows, 128 hidden units), and the tail adds the slices in a fixed order (deterministic; the sum of F / 128 partial chains
+ * instead of one chain over F, i.e. equal to the in-line FFN to rounding, not bit for bit); without it everything is one launch. */
+size_t srf_stage_tail_workspace_bytes(int R, int C, int F);
 int srf_stage_tail(const float *obj_in, int R, int C, int F, const float *w1, const float *b1, const float *w2,
                    const float *b2, const float *n3_g, const float *n3_b, float n3_eps, int n_cls,
                    const float *const *cls_w, const float *const *cls_g, const float *const *cls_b, const float *cls_eps,
                    int n_reg, const float *const *reg_w, const float *const *reg_g, const float *const *reg_b,
                    const float *reg_eps, const float *wl, const float *bl, int ncls, const float *wd, const float *bd,
                    int Dd, const float *boxes_m, const float *weights6, const float *pc_range, float scale_clamp,
-                   float *obj_out, float *logits, float *pred, srf_stream_t stream);
+                   float *obj_out, float *logits, float *pred, void *workspace, size_t workspace_bytes, srf_stream_t stream);
 int srf_apply_deltas(const float *deltas, const float *boxes, int R, int Dd, const float *weights6 /*host[6]*/,
                      const float *pc_range /*host[6]*/, float scale_clamp, float *out, srf_stream_t stream);
 

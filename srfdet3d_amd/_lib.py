@@ -101,7 +101,8 @@ SIGNATURES = {
     "srf_nhwc_dwconv3x3s2": (c_int, [_P, c_longlong, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_longlong, _P]),
     "srf_stage_tail": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, c_int, POINTER(c_void_p), POINTER(c_void_p),
                                POINTER(c_void_p), _HF, c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), _HF, _P, _P,
-                               c_int, _P, _P, c_int, _P, _HF, _HF, c_float, _P, _P, _P, _P]),
+                               c_int, _P, _P, c_int, _P, _HF, _HF, c_float, _P, _P, _P, _P, c_size_t, _P]),
+    "srf_stage_tail_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "srf_apply_deltas": (c_int, [_P, _P, c_int, c_int, _HF, _HF, c_float, _P, _P]),
     "srf_nms_rotated_workspace_bytes": (c_size_t, [c_int]),
     "srf_nms_rotated": (c_int, [_P, c_int, c_float, _P, _P, c_size_t, _P]),

@@ -573,11 +573,69 @@ __device__ __forceinline__ void srf_tail_to_image(float (*s_out)[LIN_TN + 4], fl
     }
 }
 
+// The FFN of a stage, one 128-wide slice of the hidden layer per workgroup (grid: row tiles x F / 128):
+//   partial[slice][row][:] = relu(obj W1[n0 : n0 + 128]^T + b1[n0 :]) W2[:, n0 : n0 + 128]^T
+// srf_stage_tail_k then adds the slices in a fixed order.  Inside one workgroup the FFN is a chain of 2 F / 128 dependent
+// weight blocks on ONE CU (7 row tiles at 200 proposals: 62 of the stage's 75 us with 242 CUs idle); split, every slice is
+// two blocks deep and the slices run side by side.
+__global__ __launch_bounds__(256) void srf_stage_ffn_k(const float *__restrict__ obj_in, int R, const float *__restrict__ w1,
+                                                     const float *__restrict__ b1, const float *__restrict__ w2, int F,
+                                                     float *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *img_obj = lds;
+    float *img_h = img_obj + 4 * 1024;
+    float *s_w = img_h + 4 * 1024;
+    float(*s_out)[LIN_TN + 4] = reinterpret_cast<float(*)[LIN_TN + 4]>(s_w + 4 * LIN_TN * 32);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * 32, n0 = blockIdx.y * LIN_TN;
+    const int C = TAIL_C;
+    TailBlock blk;
+    srf_tail_load(blk, w1, C, n0, F, 0);
+    {  // obj tile -> image
+        const int r = tid >> 3, q = tid & 7, row = row0 + r;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < R) v = *reinterpret_cast<const f32x4 *>(obj_in + (size_t)row * C + ch * 32 + q * 4);
+            srf_img_store(img_obj + ch * 1024, r, q, v);
+        }
+    }
+    const float bias = b1[n0 + (tid & (LIN_TN - 1))];  // the column this thread visits in the bias + ReLU pass below
+    srf_tail_commit(blk, s_w);
+    __syncthreads();
+    srf_tail_load(blk, w2, F, 0, C, n0);
+    f32x16 acc;
+    srf_tail_zero(acc);
+    srf_tail_mma(img_obj, s_w, acc);
+    srf_tail_spill(acc, s_out);
+    __syncthreads();
+    for (int e = tid; e < 32 * LIN_TN; e += 256) {  // e & 127 == tid & 127 for every e of this thread
+        const int r = e >> 7, c = e & (LIN_TN - 1);
+        const float v = s_out[r][c] + bias;
+        s_out[r][c] = v > 0.f ? v : 0.f;
+    }
+    __syncthreads();
+    srf_tail_to_image(s_out, img_h);
+    srf_tail_commit(blk, s_w);
+    __syncthreads();
+    srf_tail_zero(acc);
+    srf_tail_mma(img_h, s_w, acc);
+    float *dst = partial + (size_t)blockIdx.y * R * C;
+    const int kh = lane >> 5, col = wave * 32 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int row = row0 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+        if (row < R) dst[(size_t)row * C + col] = acc[j];
+    }
+}
+
 __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict__ obj_in, int R, TailWeights tw,
                                                       const float *__restrict__ boxes_m, DeltaGeomFwd g,
                                                       float *__restrict__ obj_out, float *__restrict__ logits,
-                                                      float *__restrict__ pred)
+                                                      float *__restrict__ pred, const float *__restrict__ partial)
 {
+    // partial != nullptr: the FFN ran in srf_stage_ffn_k; (F / 128) slices of (R, C) partial sums, added here in slice order
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *img_obj = lds;                 // 4 chunks: obj, then obj2
     float *img_h = img_obj + 4 * 1024;    // 4 chunks: one 128-wide slice of the FFN hidden layer / tower activations
@@ -598,7 +656,14 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
     float *p_tw = p_n3b + C;                                 // towers: [cls g, b] x 4, [reg g, b] x 4
     float *p_bl = p_tw + 4 * TAIL_MAX_TOWER * C, *p_bd = p_bl + 32;
     TailBlock blk;
-    srf_tail_load(blk, tw.w1, C, 0, F, 0);
+    if (!partial) srf_tail_load(blk, tw.w1, C, 0, F, 0);
+    else if (first_tower == 0) {
+        if (tw.n_cls > 0) srf_tail_load(blk, tw.cls_w[0], C, 0, C, 0);
+        else srf_tail_load(blk, tw.wl, C, 0, tw.ncls, 0);
+    } else {
+        if (tw.n_reg > 0) srf_tail_load(blk, tw.reg_w[0], C, 0, C, 0);
+        else srf_tail_load(blk, tw.wd, C, 0, tw.Dd, 0);
+    }
     for (int e = tid; e < F; e += 256) p_b1[e] = tw.b1[e];
     if (tid < C) {
         p_b2[tid] = tw.b2[tid];
@@ -629,7 +694,7 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
     f32x16 acc, acc2;
     srf_tail_zero(acc2);
     // ---- FFN, one 128-wide slice of the hidden layer at a time: h = relu(obj W1[n0:n0+128]^T + b1); acc2 += h W2[:, n0:]^T
-    for (int n0 = 0; n0 < F; n0 += LIN_TN) {
+    for (int n0 = 0; n0 < (partial ? 0 : F); n0 += LIN_TN) {
         srf_tail_commit(blk, s_w);                 // W1 slice
         __syncthreads();
         srf_tail_load(blk, tw.w2, F, 0, C, n0);    // W2 k-block, in flight during the MFMAs below
@@ -665,7 +730,30 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
         res[i][0] = row < R ? obj_in[(size_t)row * C + lane] : 0.f;
         res[i][1] = row < R ? obj_in[(size_t)row * C + lane + 64] : 0.f;
     }
-    srf_tail_spill(acc2, s_out);
+    if (!partial) {
+        srf_tail_spill(acc2, s_out);
+    } else {  // sum of the slices, slice 0 first: thread -> (row tid >> 3, 16 columns)
+        const int r = tid >> 3, c0 = (tid & 7) * 16, row = row0 + r;
+        const int ns = F / LIN_TN;
+        f32x4 sum[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < R) {
+            for (int sl = 0; sl < ns; ++sl) {
+                const float *src = partial + ((size_t)sl * R + row) * C + c0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * i);
+                    sum[i][0] = __fadd_rn(sum[i][0], v[0]);
+                    sum[i][1] = __fadd_rn(sum[i][1], v[1]);
+                    sum[i][2] = __fadd_rn(sum[i][2], v[2]);
+                    sum[i][3] = __fadd_rn(sum[i][3], v[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(&s_out[r][c0 + 4 * i]) = sum[i];
+    }
     __syncthreads();
     {
         RowEpilogue ep = {p_b2, nullptr, nullptr, obj_in, p_n3g, p_n3b, C, 0, 0, 0.f, tw.eps_n3};
@@ -1020,6 +1108,11 @@ __global__ __launch_bounds__(128) void srf_apply_deltas_k(const float *__restric
     for (int i = 6; i < Dd; ++i) o[i] = d[i];
 }
 
+extern "C" size_t srf_stage_tail_workspace_bytes(int R, int C, int F)
+{
+    return (R <= 0 || C <= 0 || F <= 0) ? 0 : (size_t)srf_ceil_div(F, LIN_TN) * R * C * sizeof(float);
+}
+
 extern "C" int srf_stage_tail(const float *obj_in, int R, int C, int F, const float *w1, const float *b1, const float *w2,
                               const float *b2, const float *n3_g, const float *n3_b, float n3_eps, int n_cls,
                               const float *const *cls_w, const float *const *cls_g, const float *const *cls_b,
@@ -1027,7 +1120,7 @@ extern "C" int srf_stage_tail(const float *obj_in, int R, int C, int F, const fl
                               const float *const *reg_b, const float *reg_eps, const float *wl, const float *bl, int ncls,
                               const float *wd, const float *bd, int Dd, const float *boxes_m, const float *weights6,
                               const float *pc_range, float scale_clamp, float *obj_out, float *logits, float *pred,
-                              srf_stream_t stream)
+                              void *workspace, size_t workspace_bytes, srf_stream_t stream)
 {
     if (R < 0 || C != TAIL_C || F <= 0 || F % LIN_TN || F > 4 * LIN_TN || n_cls < 0 || n_cls > TAIL_MAX_TOWER || n_reg < 0 ||
         n_reg > TAIL_MAX_TOWER || ncls <= 0 || ncls > 32 || Dd < 8 || Dd > 32)
@@ -1055,13 +1148,25 @@ extern "C" int srf_stage_tail(const float *obj_in, int R, int C, int F, const fl
     g.clamp = scale_clamp;
     const size_t sh = sizeof(float) * (4 * 1024 + 4 * 1024 + 4 * LIN_TN * 32 + 32 * (LIN_TN + 4) + 4 * LIN_TN + 3 * TAIL_C +
                                        4 * TAIL_MAX_TOWER * TAIL_C + 64);  // 125 KB
-    static bool attr_set = false;
-    if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in
+    const size_t sh_ffn = sizeof(float) * (4 * 1024 + 4 * 1024 + 4 * LIN_TN * 32 + 32 * (LIN_TN + 4));  // 113 KB
+    int dev = 0;
+    SRF_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return SRF_EUNSUPPORTED;
+    static bool attr_set[64] = {false};
+    if (!attr_set[dev]) {  // > 64 KB of dynamic LDS needs the opt-in (per device)
         SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_stage_tail_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        attr_set = true;
+        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_stage_ffn_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_ffn));
+        attr_set[dev] = true;
+    }
+    const float *partial = nullptr;
+    if (workspace) {  // FFN split over its hidden slices (srf_stage_ffn_k); without a workspace the tail kernel runs it in line
+        if (workspace_bytes < srf_stage_tail_workspace_bytes(R, C, F)) return SRF_EWORKSPACE;
+        partial = (const float *)workspace;
+        hipLaunchKernelGGL(srf_stage_ffn_k, dim3(srf_ceil_div(R, 32), F / LIN_TN), dim3(256), sh_ffn, (hipStream_t)stream, obj_in, R, w1, b1,
+                           w2, F, (float *)workspace);
     }
     hipLaunchKernelGGL(srf_stage_tail_k, dim3(srf_ceil_div(R, 32), 2), dim3(256), sh, (hipStream_t)stream, obj_in, R, tw, boxes_m, g,
-                       obj_out, logits, pred);
+                       obj_out, logits, pred, partial);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

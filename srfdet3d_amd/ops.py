@@ -1111,8 +1111,9 @@ def _ptr_array(tensors):
     return arr
 
 
-def stage_tail(obj, ffn, norm3, cls_layers, reg_layers, logits_fc, deltas_fc, boxes, weights6, pc_range, scale_clamp):
-    """FFN + residual + norm3, both towers, class_logits, bboxes_delta and apply_deltas in one launch per 32 rows.
+def stage_tail(obj, ffn, norm3, cls_layers, reg_layers, logits_fc, deltas_fc, boxes, weights6, pc_range, scale_clamp, split_ffn=True):
+    """FFN + residual + norm3, both towers, class_logits, bboxes_delta and apply_deltas: the FFN as one workgroup per (32 rows,
+    128 hidden units), everything after it in one launch per 32 rows (split_ffn=False: the FFN in line, a single launch).
     ffn = (linear1, linear2); cls_layers / reg_layers = [(Linear(bias=False), LayerNorm), ...].
     Returns obj_out (R,C), logits (R,ncls), pred (R,Dd)."""
     obj = _dev(obj, "obj", torch.float32)
@@ -1132,13 +1133,18 @@ def stage_tail(obj, ffn, norm3, cls_layers, reg_layers, logits_fc, deltas_fc, bo
               deltas_fc.weight, deltas_fc.bias] + cw + cg + cb + rw + rg + rb:
         if t.dtype != torch.float32 or not t.is_contiguous() or t.device != obj.device:
             raise ValueError("stage_tail: parameters must be contiguous float32 on the input's device")
-    check(_lib.lib().srf_stage_tail(
+    L = _lib.lib()
+    ws, ws_bytes = None, 0
+    if split_ffn:
+        ws_bytes = L.srf_stage_tail_workspace_bytes(R, C, F)
+        ws = _empty((max(ws_bytes, 4) // 4,), torch.float32, obj.device)
+    check(L.srf_stage_tail(
         _ptr(obj), R, C, F, _ptr(lin1.weight), _ptr(lin1.bias), _ptr(lin2.weight), _ptr(lin2.bias), _ptr(norm3.weight),
         _ptr(norm3.bias), float(norm3.eps), len(cls_layers), _ptr_array(cw), _ptr_array(cg), _ptr_array(cb),
         hf([n.eps for _, n in cls_layers] or [0.0]), len(reg_layers), _ptr_array(rw), _ptr_array(rg), _ptr_array(rb),
         hf([n.eps for _, n in reg_layers] or [0.0]), _ptr(logits_fc.weight), _ptr(logits_fc.bias), ncls, _ptr(deltas_fc.weight),
         _ptr(deltas_fc.bias), Dd, _ptr(boxes), hf(weights6), hf(pc_range), float(scale_clamp), _ptr(obj_out), _ptr(logits),
-        _ptr(pred), _stream()), "stage_tail")
+        _ptr(pred), None if ws is None else _ptr(ws), ws_bytes, _stream()), "stage_tail")
     return obj_out, logits, pred
 
 

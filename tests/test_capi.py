@@ -65,7 +65,7 @@ def test_host_side_helpers():
     assert L.srf_channel_affine(None, -1, 4, 16, 64, None, None, 0, None, 0, None, 64, None) == -1
     assert L.srf_nms_rotated_counted(None, 10, None, 0.4, None, None, 0, None) == -1
     assert L.srf_stage_tail(None, 10, 64, 512, *([None] * 6), 1e-5, 2, None, None, None, None, 3, None, None, None, None,
-                            None, None, 10, None, None, 10, None, None, None, 5.0, None, None, None, None) == -3  # C != 128
+                            None, None, 10, None, None, 10, None, None, None, 5.0, None, None, None, None, 0, None) == -3  # C != 128
 
 
 def test_ops_refuse_cpu_tensors():

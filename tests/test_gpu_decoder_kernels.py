@@ -97,8 +97,6 @@ def test_stage_tail_matches_per_op_chain(dev, R, F_, n_cls, n_reg, ncls, Dd):
                        torch.randn(R, Dd - 6, generator=g)], 1).to(dev)
     w6, rng, clamp = [2.0, 2.0, 2.0, 1.0, 1.0, 1.0], [-55.2, -55.2, -5.0, 55.2, 55.2, 3.0], 5.0
     with torch.no_grad():
-        got_obj, got_logits, got_pred = ops.stage_tail(obj, (lin1, lin2), norm3, cls_layers, reg_layers, logits_fc, deltas_fc,
-                                                        boxes, w6, rng, clamp)
         hid = ops.linear(obj, lin1.weight, lin1.bias, relu1=True)
         o2 = ops.linear(hid, lin2.weight, lin2.bias, residual=obj, ln2=norm3)
         cf, rf = o2, o2
@@ -108,10 +106,21 @@ def test_stage_tail_matches_per_op_chain(dev, R, F_, n_cls, n_reg, ncls, Dd):
             rf = ops.linear(rf, m.weight, None, ln1=n, relu1=True)
         lg = ops.linear(cf, logits_fc.weight, logits_fc.bias)
         pr = ops.apply_deltas(ops.linear(rf, deltas_fc.weight, deltas_fc.bias), boxes, w6, rng, clamp)
-        # same k-ordered fma chains -> the fused kernel reproduces the per-op chain to the last bits
+        # FFN in line: same k-ordered fma chains -> the fused kernel reproduces the per-op chain to the last bits
+        got_obj, got_logits, got_pred = ops.stage_tail(obj, (lin1, lin2), norm3, cls_layers, reg_layers, logits_fc, deltas_fc,
+                                                        boxes, w6, rng, clamp, split_ffn=False)
         torch.testing.assert_close(got_obj, o2, rtol=1e-6, atol=1e-6)
         torch.testing.assert_close(got_logits, lg, rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(got_pred, pr, rtol=1e-5, atol=1e-5)
+        # FFN split over its hidden slices (the default): F / 128 partial chains added in slice order -- equal to rounding,
+        # and the same bits on every run
+        got_obj, got_logits, got_pred = ops.stage_tail(obj, (lin1, lin2), norm3, cls_layers, reg_layers, logits_fc, deltas_fc,
+                                                        boxes, w6, rng, clamp)
+        torch.testing.assert_close(got_obj, o2, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(got_logits, lg, rtol=5e-5, atol=5e-5)
+        torch.testing.assert_close(got_pred, pr, rtol=5e-5, atol=5e-5)
+        again = ops.stage_tail(obj, (lin1, lin2), norm3, cls_layers, reg_layers, logits_fc, deltas_fc, boxes, w6, rng, clamp)
+        assert torch.equal(again[0], got_obj) and torch.equal(again[1], got_logits) and torch.equal(again[2], got_pred)
         # and torch float64
         d = lambda m: (m.weight.double(), None if m.bias is None else m.bias.double())
         x = obj.double()
