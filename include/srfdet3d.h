@@ -449,15 +449,19 @@ int srf_nms_rotated(const float *boxes, int n, float iou_threshold, int *keep, v
  * hipGraph replay: n is the capacity, the number of candidates above the score threshold is decided on the device. */
 int srf_nms_rotated_counted(const float *boxes_xywhr, int n, const int *n_dev, float iou_threshold, int *keep,
                             void *workspace, size_t workspace_bytes, srf_stream_t stream);
+/* class-aware: cls (n, int64) -- a box only suppresses boxes of its own class, i.e. the per-class loop of mmdet3d
+ * box3d_multiclass_nms (mmdet3d/core/post_processing/box3d_nms.py as called at srfdet_head.py:1276-1293) in one pass on the
+ * boxes' own coordinates (no class offsets added to x).  n_dev may be NULL (all n boxes are candidates). */
+int srf_nms_rotated_classes(const float *boxes_xywhr, const long long *cls, int n, const int *n_dev, float iou_threshold,
+                            int *keep, void *workspace, size_t workspace_bytes, srf_stream_t stream);
 
-/* The fixed-shape multi-class selection around srf_nms_rotated_counted: the static form of mmdet3d box3d_multiclass_nms as
+/* The fixed-shape multi-class selection around srf_nms_rotated_classes: the static form of mmdet3d box3d_multiclass_nms as
  * called at srfdet_head.py:1276-1293, without a host read-back (hipGraph replay).
  * srf_nms_select: boxes (n, D >= 7) [x, y, z, w, l, h, yaw, ...], scores (n, C) -> the L best (box, class) pairs above
- * score_thr in descending score: cand (L, D), top_s (L), cls (L, int64), bev (L, 5) = [x + class * span, y, w, l, yaw]
- * (classes pushed apart by span = (max|x,y| + max|w,l|) * 4 + 1 so that one NMS pass is the reference's per-class NMS),
- * *m (device int) = number of pairs above the threshold -- if it exceeds L the caller redoes the frame on the dynamic
+ * score_thr in descending score: cand (L, D), top_s (L), cls (L, int64), bev (L, 5) = [x, y, w, l, yaw] (with cls the
+ * operands of srf_nms_rotated_classes), *m (device int) = number of pairs above the threshold -- if it exceeds L the caller redoes the frame on the dynamic
  * path.  n * C <= 16384, L <= n * C.
- * srf_nms_finish: keep (L) from srf_nms_rotated_counted -> survivors first, class-major, descending score inside a class
+ * srf_nms_finish: keep (L) from srf_nms_rotated_classes -> survivors first, class-major, descending score inside a class
  * (the order of the reference's per-class loop): out_boxes (L, D), out_scores (L), out_labels (L, int64), *kept. */
 int srf_nms_select(const float *boxes, const float *scores, int n, int C, int D, float score_thr, int L, float *cand,
                    float *top_s, long long *cls, float *bev, int *m, srf_stream_t stream);

@@ -107,6 +107,7 @@ SIGNATURES = {
     "srf_nms_rotated_workspace_bytes": (c_size_t, [c_int]),
     "srf_nms_rotated": (c_int, [_P, c_int, c_float, _P, _P, c_size_t, _P]),
     "srf_nms_rotated_counted": (c_int, [_P, c_int, _P, c_float, _P, _P, c_size_t, _P]),
+    "srf_nms_rotated_classes": (c_int, [_P, _P, c_int, _P, c_float, _P, _P, c_size_t, _P]),
     "srf_nms_select": (c_int, [_P, _P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P]),
     "srf_nms_finish": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "srf_roi_extract_bwd": (c_int, [POINTER(FeatMap), POINTER(c_void_p), c_int, c_int, _P, c_int, c_int, c_int, c_float, _P,

@@ -1064,11 +1064,14 @@ extern "C" int srf_dynconv_mid(const float *F, const float *params, int R, int S
                            b2, eps2, out);
     } else if (C == 256 && D == 64) {
         const size_t sh = sizeof(float) * (64 * 257 + 256 * 65 + 64 * 65);
-        static bool attr_set = false;
-        if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in (idempotent; a race only repeats the call)
+        int dev = 0;
+        SRF_HIP_TRY(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64) return SRF_EUNSUPPORTED;
+        static bool attr_set[64] = {false};
+        if (!attr_set[dev]) {  // > 64 KB of dynamic LDS needs the opt-in, per device (idempotent; a race only repeats the call)
             SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_dynconv_mid_k<256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)sh));
-            attr_set = true;
+            attr_set[dev] = true;
         }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_dynconv_mid_k<256, 64>), dim3(R), dim3(256), sh, st, F, params, S, g1, b1, eps1, g2,
                            b2, eps2, out);

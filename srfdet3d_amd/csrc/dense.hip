@@ -270,11 +270,14 @@ extern "C" int srf_conv1x1(const float *const *srcs, const int *src_channels, in
     const size_t cap = (size_t)(160 * 1024) / best_occ;       // LDS per workgroup that leaves room for exactly best_occ
     if (lds < cap - 8 * 1024) lds = cap - 8 * 1024;           // (the next integer occupancy would need <= 160K / (occ + 1))
     if (best_occ == 2 && lds < 56 * 1024) lds = 56 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
+    int dev = 0;
+    SRF_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return SRF_EUNSUPPORTED;
+    static bool attr_set[64] = {false};  // per device
+    if (!attr_set[dev]) {
         SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_conv1x1_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_conv1x1_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     if (best_nq == 4)
         hipLaunchKernelGGL(srf_conv1x1_k<4>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, segs, HW, nchunk, W_packed,

@@ -93,9 +93,11 @@ __device__ float srf_rotated_iou(const float *a, const float *b)
     return area / (area1 + area2 - area);
 }
 
+// cls (may be null): class id per box; a box only suppresses boxes of its own class (the per-class loop of mmdet3d's
+// box3d_multiclass_nms in one pass, on the boxes' own coordinates)
 __global__ __launch_bounds__(64) void srf_nms_mask_k(const float *__restrict__ boxes, int n, float thr,
                                                    unsigned long long *__restrict__ mask, int words,
-                                                   const int *__restrict__ n_dev)
+                                                   const int *__restrict__ n_dev, const long long *__restrict__ cls)
 {
     const int rb = blockIdx.y, cb = blockIdx.x;
     if (n_dev) {  // static-shape call: only the first *n_dev boxes are candidates
@@ -104,9 +106,12 @@ __global__ __launch_bounds__(64) void srf_nms_mask_k(const float *__restrict__ b
     }
     if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;  // only later boxes can be suppressed
     __shared__ float sb[64 * 5];
+    __shared__ long long sc[64];
     const int ncol = min(n - cb * 64, 64);
-    if ((int)threadIdx.x < ncol)
+    if ((int)threadIdx.x < ncol) {
         for (int t = 0; t < 5; ++t) sb[threadIdx.x * 5 + t] = boxes[(size_t)(cb * 64 + threadIdx.x) * 5 + t];
+        sc[threadIdx.x] = cls ? cls[cb * 64 + threadIdx.x] : 0;
+    }
     __syncthreads();
     const int i = rb * 64 + threadIdx.x;
     if (i >= n) return;
@@ -114,8 +119,9 @@ __global__ __launch_bounds__(64) void srf_nms_mask_k(const float *__restrict__ b
     for (int t = 0; t < 5; ++t) me[t] = boxes[(size_t)i * 5 + t];
     unsigned long long bits = 0;
     const int start = rb == cb ? threadIdx.x + 1 : 0;
+    const long long mine = cls ? cls[i] : 0;
     for (int j = start; j < ncol; ++j)
-        if (srf_rotated_iou(me, sb + j * 5) > thr) bits |= 1ull << j;
+        if (sc[j] == mine && srf_rotated_iou(me, sb + j * 5) > thr) bits |= 1ull << j;
     mask[(size_t)i * words + cb] = bits;
 }
 
@@ -165,24 +171,32 @@ extern "C" size_t srf_nms_rotated_workspace_bytes(int n)
     return (size_t)n * ((n + 63) / 64) * 8;
 }
 
-static int srf_nms_launch(const float *boxes, int n, const int *n_dev, float iou_threshold, int *keep, void *workspace,
-                          size_t workspace_bytes, srf_stream_t stream);
+static int srf_nms_launch(const float *boxes, const long long *cls, int n, const int *n_dev, float iou_threshold, int *keep,
+                          void *workspace, size_t workspace_bytes, srf_stream_t stream);
 
 extern "C" int srf_nms_rotated(const float *boxes, int n, float iou_threshold, int *keep, void *workspace,
                                size_t workspace_bytes, srf_stream_t stream)
 {
-    return srf_nms_launch(boxes, n, nullptr, iou_threshold, keep, workspace, workspace_bytes, stream);
+    return srf_nms_launch(boxes, nullptr, n, nullptr, iou_threshold, keep, workspace, workspace_bytes, stream);
 }
 
 extern "C" int srf_nms_rotated_counted(const float *boxes, int n, const int *n_dev, float iou_threshold, int *keep,
                                        void *workspace, size_t workspace_bytes, srf_stream_t stream)
 {
     if (!n_dev) return SRF_EINVAL;
-    return srf_nms_launch(boxes, n, n_dev, iou_threshold, keep, workspace, workspace_bytes, stream);
+    return srf_nms_launch(boxes, nullptr, n, n_dev, iou_threshold, keep, workspace, workspace_bytes, stream);
 }
 
-static int srf_nms_launch(const float *boxes, int n, const int *n_dev, float iou_threshold, int *keep, void *workspace,
-                          size_t workspace_bytes, srf_stream_t stream)
+// class-aware form: boxes in descending score order with their class ids; n_dev may be null (all n boxes are live)
+extern "C" int srf_nms_rotated_classes(const float *boxes, const long long *cls, int n, const int *n_dev, float iou_threshold,
+                                       int *keep, void *workspace, size_t workspace_bytes, srf_stream_t stream)
+{
+    if (n > 0 && !cls) return SRF_EINVAL;
+    return srf_nms_launch(boxes, cls, n, n_dev, iou_threshold, keep, workspace, workspace_bytes, stream);
+}
+
+static int srf_nms_launch(const float *boxes, const long long *cls, int n, const int *n_dev, float iou_threshold, int *keep,
+                          void *workspace, size_t workspace_bytes, srf_stream_t stream)
 {
     if (n < 0 || n > 4096) return n < 0 ? SRF_EINVAL : SRF_EUNSUPPORTED;
     if (n == 0) return SRF_OK;
@@ -192,7 +206,7 @@ static int srf_nms_launch(const float *boxes, int n, const int *n_dev, float iou
     hipStream_t st = (hipStream_t)stream;
     SRF_HIP_TRY(srf_fill_bytes(workspace, 0, srf_nms_rotated_workspace_bytes(n), st));
     hipLaunchKernelGGL(srf_nms_mask_k, dim3(words, words), dim3(64), 0, st, boxes, n, iou_threshold,
-                       (unsigned long long *)workspace, words, n_dev);
+                       (unsigned long long *)workspace, words, n_dev, cls);
     hipLaunchKernelGGL(srf_nms_reduce_k, dim3(1), dim3(64), 0, st, (const unsigned long long *)workspace, n, words, keep, n_dev);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
@@ -205,9 +219,9 @@ static int srf_nms_launch(const float *boxes, int n, const int *n_dev, float iou
 // bitonic sort in LDS.
 //   srf_nms_select:  scores (n, C) -> the L = capacity best (box, class) pairs above score_thr in descending score
 //                    (ties: lower flat index first): their boxes `cand` (L, D), scores `top_s` (L), classes `cls` (L),
-//                    BEV boxes for the NMS `bev` (L, 5) = [x + class * span, y, w, l, yaw] with span = (max|x,y| +
-//                    max|w,l|) * 4 + 1 (classes pushed apart so that ONE rotated-NMS pass is the per-class NMS of the
-//                    reference), and *m = number of pairs above the threshold (may exceed L: the caller then falls back).
+//                    BEV boxes for the NMS `bev` (L, 5) = [x, y, w, l, yaw] (srf_nms_rotated_classes with `cls` is the
+//                    per-class NMS of the reference in ONE pass, on the boxes' own coordinates), and *m = number of pairs
+//                    above the threshold (may exceed L: the caller then falls back).
 //                    Rows >= min(*m, L) hold score -1 and an arbitrary valid box.
 //   srf_nms_finish:  survivors (keep != 0) first, class-major, descending score inside a class (the order of the
 //                    reference's per-class loop), stable; *kept = their number.
@@ -254,7 +268,6 @@ __global__ __launch_bounds__(SRF_SEL_THREADS) void srf_nms_select_k(const float 
     extern __shared__ __attribute__((aligned(16))) unsigned char sel_lds[];
     float *key = reinterpret_cast<float *>(sel_lds);
     int *idx = reinterpret_cast<int *>(key + P);
-    __shared__ float s_red[2][SRF_SEL_THREADS / 64];
     __shared__ int s_cnt[SRF_SEL_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int total = n * C;
@@ -270,34 +283,12 @@ __global__ __launch_bounds__(SRF_SEL_THREADS) void srf_nms_select_k(const float 
         key[t] = k;
         idx[t] = t;
     }
-    // span = (max |x|,|y| + max |w|,|l|) * 4 + 1 over all boxes
-    float mxy = 0.f, mwl = 0.f;
-    for (int b = tid; b < n; b += SRF_SEL_THREADS) {
-        const float *p = boxes + (size_t)b * D;
-        mxy = fmaxf(mxy, fmaxf(fabsf(p[0]), fabsf(p[1])));
-        mwl = fmaxf(mwl, fmaxf(fabsf(p[3]), fabsf(p[4])));
-    }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        mxy = fmaxf(mxy, __shfl_xor(mxy, d, 64));
-        mwl = fmaxf(mwl, __shfl_xor(mwl, d, 64));
-        cnt += __shfl_xor(cnt, d, 64);
-    }
-    if (lane == 0) {
-        s_red[0][wave] = mxy;
-        s_red[1][wave] = mwl;
-        s_cnt[wave] = cnt;
-    }
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+    if (lane == 0) s_cnt[wave] = cnt;
     __syncthreads();
-    mxy = 0.f;
-    mwl = 0.f;
     cnt = 0;
-    for (int w = 0; w < SRF_SEL_THREADS / 64; ++w) {
-        mxy = fmaxf(mxy, s_red[0][w]);
-        mwl = fmaxf(mwl, s_red[1][w]);
-        cnt += s_cnt[w];
-    }
-    const float span = __fadd_rn(__fmul_rn(__fadd_rn(mxy, mwl), 4.0f), 1.0f);
+    for (int w = 0; w < SRF_SEL_THREADS / 64; ++w) cnt += s_cnt[w];
     if (tid == 0) *m_out = cnt;
     srf_sel_sort(key, idx, P, true);
     for (int j = tid; j < L; j += SRF_SEL_THREADS) {
@@ -308,7 +299,7 @@ __global__ __launch_bounds__(SRF_SEL_THREADS) void srf_nms_select_k(const float 
         top_s[j] = key[j];
         cls[j] = ci;
         float *o = bev + (size_t)j * 5;
-        o[0] = __fadd_rn(p[0], __fmul_rn((float)ci, span));
+        o[0] = p[0];
         o[1] = p[1];
         o[2] = p[3];
         o[3] = p[4];
@@ -385,10 +376,13 @@ extern "C" int srf_nms_select(const float *boxes, const float *scores, int n, in
     const int P = srf_sel_pow2(n * C);
     const size_t sh = (size_t)P * 8;
     if (sh > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        int dev = 0;
+        SRF_HIP_TRY(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64) return SRF_EUNSUPPORTED;
+        static bool attr_set[64] = {false};  // the attribute belongs to the function ON A DEVICE
+        if (!attr_set[dev]) {
             SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_nms_select_k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            attr_set = true;
+            attr_set[dev] = true;
         }
     }
     hipLaunchKernelGGL(srf_nms_select_k, dim3(1), dim3(SRF_SEL_THREADS), sh, (hipStream_t)stream, boxes, scores, n, C, D, score_thr, L, P,

@@ -607,8 +607,9 @@ def box_rois(boxes, pc_range, voxel_size, mutate_centres=True, want_bev=True, li
 
 
 # ---------------------------------------------------------------------------------------------- NMS
-def nms_rotated(boxes_xywhr, scores, iou_threshold):
-    """Greedy rotated NMS; returns indices (into the input) of the kept boxes, in descending score order."""
+def nms_rotated(boxes_xywhr, scores, iou_threshold, classes=None):
+    """Greedy rotated NMS; returns indices (into the input) of the kept boxes, in descending score order.  classes (n,)
+    int64: a box only suppresses boxes of its own class (per-class NMS in one pass)."""
     boxes_xywhr = _dev(boxes_xywhr, "boxes", torch.float32)
     n = boxes_xywhr.shape[0]
     if n == 0:
@@ -619,14 +620,20 @@ def nms_rotated(boxes_xywhr, scores, iou_threshold):
     keep = _empty((n,), torch.int32, boxes_xywhr.device)
     ws_bytes = L.srf_nms_rotated_workspace_bytes(n)
     ws = _empty((ws_bytes,), torch.uint8, boxes_xywhr.device)
-    check(L.srf_nms_rotated(_ptr(sorted_boxes), n, float(iou_threshold), _ptr(keep), _ptr(ws), ws_bytes, _stream()),
-          "nms_rotated")
+    if classes is None:
+        check(L.srf_nms_rotated(_ptr(sorted_boxes), n, float(iou_threshold), _ptr(keep), _ptr(ws), ws_bytes, _stream()),
+              "nms_rotated")
+    else:
+        cls = _dev(classes, "classes", torch.int64)[order].contiguous()
+        check(L.srf_nms_rotated_classes(_ptr(sorted_boxes), _ptr(cls), n, None, float(iou_threshold), _ptr(keep), _ptr(ws), ws_bytes,
+                                        _stream()), "nms_rotated_classes")
     return order[keep.bool()]
 
 
-def nms_rotated_counted(sorted_boxes_xywhr, n_live, iou_threshold):
+def nms_rotated_counted(sorted_boxes_xywhr, n_live, iou_threshold, classes=None):
     """Greedy rotated NMS over the first n_live (device int32 scalar) rows of boxes already in descending score order;
-    returns keep flags (n,) int32, zero past n_live.  Fixed shapes, nothing read back: graph-capturable."""
+    returns keep flags (n,) int32, zero past n_live.  Fixed shapes, nothing read back: graph-capturable.  classes (n,) int64:
+    suppression only inside a class."""
     b = _dev(sorted_boxes_xywhr, "boxes", torch.float32)
     n = b.shape[0]
     keep = _empty((max(n, 1),), torch.int32, b.device)
@@ -635,8 +642,15 @@ def nms_rotated_counted(sorted_boxes_xywhr, n_live, iou_threshold):
     L = _lib.lib()
     ws_bytes = L.srf_nms_rotated_workspace_bytes(n)
     ws = _empty((ws_bytes,), torch.uint8, b.device)
-    check(L.srf_nms_rotated_counted(_ptr(b), n, _ptr(_dev(n_live, "n_live", torch.int32)), float(iou_threshold), _ptr(keep),
-                                    _ptr(ws), ws_bytes, _stream()), "nms_rotated_counted")
+    if classes is None:
+        check(L.srf_nms_rotated_counted(_ptr(b), n, _ptr(_dev(n_live, "n_live", torch.int32)), float(iou_threshold), _ptr(keep),
+                                        _ptr(ws), ws_bytes, _stream()), "nms_rotated_counted")
+    else:
+        cls = _dev(classes, "classes", torch.int64)
+        if cls.shape != (n,) or not cls.is_contiguous():
+            raise ValueError("nms_rotated_counted: classes must be a contiguous (n,) int64 tensor")
+        check(L.srf_nms_rotated_classes(_ptr(b), _ptr(cls), n, _ptr(_dev(n_live, "n_live", torch.int32)), float(iou_threshold),
+                                        _ptr(keep), _ptr(ws), ws_bytes, _stream()), "nms_rotated_classes")
     return keep
 
 

@@ -26,10 +26,8 @@ def box3d_multiclass_nms(boxes, scores, score_thr, max_num, nms_thr):
     order = torch.argsort(cand[:, 1] * n + cand[:, 0])
     bi, ci = cand[order, 0], cand[order, 1]
     s = scores[bi, ci]
-    bev = boxes[bi][:, [0, 1, 3, 4, 6]].clone()
-    span = (bev[:, :2].abs().max() + bev[:, 2:4].abs().max()) * 4 + 1
-    bev[:, 0] = bev[:, 0] + ci.to(bev.dtype) * span
-    keep = ops.nms_rotated(bev, s, nms_thr)
+    bev = boxes[bi][:, [0, 1, 3, 4, 6]].contiguous()
+    keep = ops.nms_rotated(bev, s, nms_thr, classes=ci)  # suppression inside a class only: the reference's per-class loop
     keep = keep.sort()[0]  # back to class-major / in-class score order is not needed before the top-k below
     # the reference appends, per class, boxes in descending score order
     k2 = torch.argsort(ci[keep] * 4 - s[keep].clamp(0, 1) * 2, stable=True)
@@ -80,7 +78,7 @@ def box3d_multiclass_nms_static(boxes, scores, score_thr, nms_thr, capacity=STAT
     if 0 < n * C <= 16384 and L <= 4096 and boxes.shape[1] >= 7:
         # two single-workgroup launches around the NMS (LDS bitonic sorts) instead of the ~25 small torch launches below
         cand, top_s, ci, bev, m = ops.nms_select(boxes, scores, score_thr, capacity)
-        keep = ops.nms_rotated_counted(bev, m, nms_thr)  # the kernels take min(*m, L) themselves
+        keep = ops.nms_rotated_counted(bev, m, nms_thr, classes=ci)  # the kernels take min(*m, L) themselves
         out_b, out_s, out_l, kept, packed, counts = ops.nms_finish(cand, top_s, ci, keep, m)
         if want_packed:
             return packed, counts
@@ -103,10 +101,9 @@ def _static_torch(boxes, scores, score_thr, nms_thr, L):
     m = valid.sum().to(torch.int32).view(1)
     bi, ci = torch.div(top_i, C, rounding_mode="floor"), top_i % C
     cand = boxes[bi]
-    span = (boxes[:, :2].abs().max() + boxes[:, 3:5].abs().max()) * 4 + 1
     # (a list index would upload an index tensor: not allowed while a stream is capturing)
-    bev = torch.stack([cand[:, 0] + ci.to(cand.dtype) * span, cand[:, 1], cand[:, 3], cand[:, 4], cand[:, 6]], dim=1)
-    keep = ops.nms_rotated_counted(bev, torch.clamp(m, max=L), nms_thr).bool()
+    bev = torch.stack([cand[:, 0], cand[:, 1], cand[:, 3], cand[:, 4], cand[:, 6]], dim=1)
+    keep = ops.nms_rotated_counted(bev, torch.clamp(m, max=L), nms_thr, classes=ci.contiguous()).bool()
     # survivors first, class-major, descending score inside a class (the per-class loop of the reference)
     key2 = torch.where(keep, ci.to(flat.dtype) * 4 - top_s.clamp(0, 1) * 2, torch.full_like(top_s, 1.0e9))
     o2 = torch.argsort(key2, stable=True)
