@@ -823,7 +823,8 @@ static int conv1x1_launch(const float *x, long long M, int K, long long x_ld, co
         attr_set[dev] = true;
     }
     static const int big = getenv("SRF_GEMM_BIG") ? atoi(getenv("SRF_GEMM_BIG")) : 0;
-    const int TM = (big && !colsum) ? 256 : 128, ncs = (big && !colsum) ? 1 : 2;
+    int TM = (big && !colsum) ? 256 : 128, ncs = (big && !colsum) ? 1 : 2;
+    if (!colsum && srf_ceil_div(M, 128) * srf_ceil_div(Cout, 128) < 384) TM = 64, ncs = 4;  // small problem: 64 x 64 tiles
     if (colsum) {
         a.bpi = (int)srf_ceil_div(HW, TM);
         a.mblocks = (M / HW) * a.bpi;
@@ -835,6 +836,8 @@ static int conv1x1_launch(const float *x, long long M, int K, long long x_ld, co
     if (blocks >= (1ll << 31)) return SRF_EUNSUPPORTED;
     if (TM == 256)
         hipLaunchKernelGGL((srf_conv1x1_nhwc_k<4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), LDS_BIG, stream, a);
+    else if (TM == 64)
+        hipLaunchKernelGGL((srf_conv1x1_nhwc_k<1, 1, 4, false>), dim3((unsigned)blocks), dim3(256), (8 * 64 + 8 * 64) * 16, stream, a);
     else
         hipLaunchKernelGGL((srf_conv1x1_nhwc_k<2, 2, 3, false>), dim3((unsigned)blocks), dim3(256), LDS_STD, stream, a);
     SRF_LAUNCH_CHECK();
@@ -942,9 +945,18 @@ extern "C" int srf_conv_gemm_nhwc(const float *x, int N, int H, int W, int Cin, 
     a.HW = 0;
     a.bpi = 0;
     a.mblocks = srf_ceil_div(a.M, 128);
-    const long long blocks = ((a.mblocks + 7) / 8) * 8 * a.coutBlocks * 2;
+    long long blocks = ((a.mblocks + 7) / 8) * 8 * a.coutBlocks * 2;
     if (blocks >= (1ll << 31)) return SRF_EUNSUPPORTED;
-    hipLaunchKernelGGL((srf_conv1x1_nhwc_k<2, 2, 3, true>), dim3((unsigned)blocks), dim3(256), (8 * 128 + 8 * 128) * 16, (hipStream_t)stream, a);
+    // count of 128-channel parts that hold real channels
+    const long long live = a.mblocks * srf_ceil_div(Cout, 128);
+    if (live < 384) {
+        // a small map (the stride-2 layers of the BEV FPN: 46 x 46 outputs = 17 tiles of 128 pixels, each a chain of
+        // 36 chunks on one CU with the rest of the chip idle): 64 x 64 tiles, four times the workgroups, a quarter of the chain
+        a.mblocks = srf_ceil_div(a.M, 64);
+        blocks = ((a.mblocks + 7) / 8) * 8 * a.coutBlocks * 4;
+        hipLaunchKernelGGL((srf_conv1x1_nhwc_k<1, 1, 4, true>), dim3((unsigned)blocks), dim3(256), (8 * 64 + 8 * 64) * 16, (hipStream_t)stream, a);
+    } else
+        hipLaunchKernelGGL((srf_conv1x1_nhwc_k<2, 2, 3, true>), dim3((unsigned)blocks), dim3(256), (8 * 128 + 8 * 128) * 16, (hipStream_t)stream, a);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

@@ -148,10 +148,38 @@ def install():
         F = ffn[0].weight.shape[0]
         fl = 2.0 * R * (2 * C * F + (len(cls_layers) + len(reg_layers)) * C * C + C * (lfc.weight.shape[0] + dfc.weight.shape[0]))
         return 4 * (2 * R * C + 2 * C * F + (len(cls_layers) + len(reg_layers)) * C * C), fl, None
-    _wrap("stage_tail", "mfma", w_tail)
+    _wrap("stage_tail", "mfma", w_tail)   # srf_stage_ffn_k + srf_stage_tail_k
     _wrap("apply_deltas", "latency", lambda a, k, o: (3 * n4(a[0]), 0, None))
     _wrap("channel_affine", "hbm", lambda a, k, o: (2 * n4(a[0]) + (n4(a[0]) if k.get("residual") is not None else 0), 0, None))
     _wrap("nms_rotated", "latency", lambda a, k, o: (n4(a[0]), 0, None))
+
+    # channels-last dense layers (csrc/conv.hip, csrc/nhwc.hip): x is an (N, H, W, C) slice
+    def w_wino(a, k, out):
+        N, H, W, Cin = a[0].shape
+        Cout = a[2]
+        direct = 2.0 * N * H * W * Cin * Cout * 9
+        return 4.0 * N * H * W * (Cin + Cout) + 4.0 * 16 * Cin * Cout, direct / 2.25, f"{Cin}->{Cout} @{H}x{W} (executed FLOPs = direct / 2.25)"
+    _wrap("wino3x3", "mfma", w_wino)
+
+    def w_g1(a, k, out):
+        N, H, W, K = a[0].shape
+        Cout = a[2]
+        return 4.0 * N * H * W * (K + Cout) + 4.0 * K * Cout, 2.0 * N * H * W * K * Cout, f"{K}->{Cout} @{H}x{W}"
+    _wrap("conv1x1_nhwc", "mfma", w_g1)
+
+    def w_gs(a, k, out):
+        N, H, W, Cin = a[0].shape
+        Cout, (kh, kw) = a[2], a[3]
+        No, Ho, Wo, _ = out.shape
+        return 4.0 * (N * H * W * Cin + No * Ho * Wo * Cout) + 4.0 * kh * kw * Cin * Cout, 2.0 * No * Ho * Wo * Cout * Cin * kh * kw, \
+            f"{Cin}->{Cout} k{kh} s{a[4]} @{H}x{W}"
+    _wrap("conv_gemm_nhwc", "mfma", w_gs)
+    _wrap("stem_conv_nchw", "hbm", lambda a, k, o: (n4(a[0]) + n4(o), 0, None))
+    _wrap("nhwc_affine", "hbm", lambda a, k, o: (n4(a[0]) + n4(o) + (n4(k["residual"]) if k.get("residual") is not None else 0), 0, None))
+    _wrap("nhwc_maxpool3s2_ceil", "hbm", lambda a, k, o: (n4(a[0]) + n4(o), 0, None))
+    _wrap("nhwc_upsample_add", "hbm", lambda a, k, o: (n4(a[0]) + n4(a[1]) + n4(o), 0, None))
+    _wrap("nhwc_dwconv3x3s2", "hbm", lambda a, k, o: (n4(a[0]) + n4(o), 0, None))
+    _wrap("ese_gate", "latency", lambda a, k, o: (n4(a[0]) * 2, 0, None))
 
 
 def dense_flops(module, x_shapes):
@@ -193,10 +221,11 @@ def main():
             model.simple_test(img, [frames[i % 4]], metas)
     torch.cuda.synchronize()
     install()
-    # dense (MIOpen / rocBLAS) stages: module-level events + conv FLOPs from hooks
-    dense = [("SECONDCustom (MIOpen)", model.pts_backbone), ("BEV FPN (MIOpen)", model.pts_neck)]
+    # whole dense modules: module-level events + direct conv FLOPs from hooks.  Their kernels are the wino3x3 / conv1x1_nhwc /
+    # conv_gemm_nhwc / nhwc_* rows above, so these rows are totals and stay out of the sum
+    dense = [("SECONDCustom (whole module)", model.pts_backbone), ("BEV FPN (whole module)", model.pts_neck)]
     if model.use_img:
-        dense += [("VoVNet (MIOpen)", model.img_backbone), ("image FPN (MIOpen)", model.img_neck)]
+        dense += [("VoVNet-99 (whole module)", model.img_backbone), ("image FPN (whole module)", model.img_neck)]
     for name, mod in dense:
         if mod is None:
             continue
@@ -209,7 +238,7 @@ def main():
             e0.record()
             out = _orig(*x, **k)
             e1.record()
-            _record(_name, "mfma", (e0, e1), 0.0, _tot[0] - f0)
+            _record(_name, "module", (e0, e1), 0.0, _tot[0] - f0)
             return out
         mod.forward = fwd
     e_all = []
@@ -225,7 +254,9 @@ def main():
     lines = [f"Per-stage roofline, `{wl['cfg']}`, np = {a.np}, {n_points} points, eager (no hipGraph), mean of {a.frames} frames; "
              f"frame = {frame_ms:.2f} ms eager.", "",
              "Peaks: HBM 8000 GB/s (spec), f32 MFMA 157.3 TFLOP/s.  `ms/frame` is HIP-event time around the operator wrapper "
-             "(kernels + its memsets + size read-backs); algorithmic work per SURVEY.md 8d.", "",
+             "(kernels + its memsets + size read-backs); algorithmic work per SURVEY.md 8d.  `(whole module)` rows time a dense "
+             "module end to end and count its DIRECT convolution FLOPs (a Winograd layer executes 1 / 2.25 of them): they are "
+             "totals of the wino3x3 / conv1x1_nhwc / conv_gemm_nhwc / nhwc_* rows and are left out of the sum.", "",
              "| stage (ops.* wrapper) | calls/frame | ms/frame | us/call | algorithmic MB/call | GFLOP/call | achieved | % of peak | bound |",
              "|---|---|---|---|---|---|---|---|---|"]
     tot_ms = 0.0
@@ -235,8 +266,9 @@ def main():
         per_call_us = ms / r["calls"] * 1e3
         mb = r["bytes"] / r["calls"] / 1e6
         gf = r["flops"] / r["calls"] / 1e9
-        tot_ms += ms / a.frames
-        if r["bound"] == "mfma" and gf > 0:
+        if r["bound"] != "module":
+            tot_ms += ms / a.frames
+        if r["bound"] in ("mfma", "module") and gf > 0:
             ach = gf / (per_call_us * 1e-6) / 1e3
             cell, pct = f"{ach:.1f} TFLOP/s", 100 * ach / MFMA_PEAK_TF
         elif r["bound"] == "hbm":
