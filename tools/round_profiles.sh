@@ -1,0 +1,44 @@
+#!/bin/bash
+# Collects the measurements of a round on the GPU box into gpurun_out/<round>/ (copy what is to be judged into profiles/).
+# usage (from the repo root, through gpurun):  bash tools/round_profiles.sh r02
+set -o pipefail
+R=${1:-r02}
+O=gpurun_out/$R
+mkdir -p $O
+export TMPDIR=/tmp
+run() { echo "== $*" >> $O/log.txt; "$@" >> $O/log.txt 2>&1; }
+line() { tail -1 "$1" > "$2"; }
+
+# bench lines (one JSON line each)
+python bench.py > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line.json
+python bench.py --workload nusc_L > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_nuscL.json
+python bench.py --np 900 --no-cpu-baseline > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_np900_LC.json
+python bench.py --workload nusc_L --np 900 --no-cpu-baseline > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_np900_nuscL.json
+python bench.py --img-precomputed --no-cpu-baseline > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_img_precomputed_LC.json
+python bench.py --workload waymo_L --steps 30 --warmup 5 --no-cpu-baseline > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_waymoL.json
+python bench.py --workload kitti_L --steps 30 --warmup 5 --no-cpu-baseline > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_kittiL.json
+python bench.py --whole-frame off --no-cpu-baseline > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_LC_tail_graph_only.json
+echo "bench lines done" >> $O/log.txt
+
+# kernel traces of the same commands
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lc -o lc -- python3 bench.py --no-cpu-baseline > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_under_rocprof_LC.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_l -o l -- python3 bench.py --workload nusc_L --no-cpu-baseline > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_under_rocprof_nuscL.json
+cp $O/prof_lc/lc_kernel_stats.csv $O/${R}_bench_nuscLC_np200_kernel_stats.csv
+cp $O/prof_l/l_kernel_stats.csv $O/${R}_bench_nuscL_np200_kernel_stats.csv
+rm -rf $O/prof_lc $O/prof_l $O/tmp.json
+echo "kernel traces done" >> $O/log.txt
+
+# per-stage tables, host-fed rates, the memset-node test
+python tools/stage_roofline.py --workload nusc_L --md $O/${R}_stage_roofline_nuscL.md >> $O/log.txt 2>&1
+python tools/stage_roofline.py --workload nusc_LC --frames 5 --md $O/${R}_stage_roofline_nuscLC.md >> $O/log.txt 2>&1
+python tools/stage_roofline.py --workload waymo_L --frames 5 --md $O/${R}_stage_roofline_waymoL.md >> $O/log.txt 2>&1
+python tools/feed_bench.py --workload nusc_LC > $O/${R}_feed_from_host_nuscLC.json 2>> $O/log.txt
+python tools/feed_bench.py --workload nusc_L --steps 100 > $O/${R}_feed_from_host_nuscL.json 2>> $O/log.txt
+[ -x tools/micro/graph_memset.bin ] && tools/micro/graph_memset.bin > $O/${R}_graph_memset_node_test.txt 2>&1
+echo "tables done" >> $O/log.txt
+
+# HBM traffic of the roofline kernels (three --pmc passes per target)
+python tools/measure_traffic.py >> $O/log.txt 2>&1
+cp gpurun_out/traffic/${R}_pmc_*_traffic.json $O/ 2>/dev/null
+echo "all done" >> $O/log.txt
+tail -3 $O/log.txt
