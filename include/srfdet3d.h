@@ -296,8 +296,8 @@ int srf_dynconv_mid(const float *feats, const float *params, int R, int S, int C
                     srf_stream_t stream);
 /* srf_channel_affine: y[n][c][:] = x[n][c][:] * scale + shift (+ residual[n][c][:]), optionally clamped at 0, in one
  * pass.  per_sample == 0: scale/shift are [C] -- eval-mode BatchNorm2d (+ ReLU) after the dense convolutions of
- * SECONDCustom / FPN / VoVNet (second_custom.py:41-63, vovnet.py:39-56).  per_sample == 1: scale/shift are [N*C] -- the
- * eSE channel gate, with the OSA block's identity input as `residual` (vovnet.py:136-150, :213-216).  shift and
+ * SECONDCustom / FPN / VoVNet (second_custom.py:41-63, vovnet.py:116-153).  per_sample == 1: scale/shift are [N*C] -- the
+ * eSE channel gate, with the OSA block's identity input as `residual` (vovnet.py:165-177, :225-228).  shift and
  * residual may be NULL.  x, y: NCHW f32 with plane size HW and their own batch strides (in floats), so y may be a
  * channel slice of a wider tensor; y == x is allowed; residual is contiguous (N, C, HW). */
 int srf_channel_affine(const float *x, int N, int C, int HW, long long x_batch_stride, const float *scale,
@@ -335,7 +335,7 @@ int srf_maxpool3s2_ceil(const float *x, int NC, int H, int W, float *y, srf_stre
 
 /* srf_conv1x1: 1x1 convolution over the channel concatenation of n_src (<= 8) NCHW f32 tensors of the same N and
  * H*W, followed by y = y * scale[co] + shift[co] (scale may be NULL: bias only; both NULL: none) and an optional ReLU --
- * the `concat` layer of VoVNet's OSA blocks (vovnet.py:182-216: torch.cat + conv1x1 + BN + ReLU) without the
+ * the `concat` layer of VoVNet's OSA blocks (vovnet.py:180-230: torch.cat + conv1x1 + BN + ReLU) without the
  * concatenated tensor, and the FPN lateral convolutions.  srcs / src_channels are HOST arrays (device pointers,
  * channel counts, each a multiple of 32); W_packed comes from srf_conv1x1_pack_weights(W (Cout x K row-major, K = sum
  * of the channel counts in concat order)); Cout % 128 == 0 and HW % 4 == 0, else SRF_EUNSUPPORTED.  out: (N, Cout, HW). */
@@ -346,12 +346,12 @@ int srf_conv1x1(const float *const *srcs, const int *src_channels, int n_src, in
 
 /* ---- channels-last (NHWC) dense convolutions on the f32 MFMA (csrc/conv.hip) --------------------------------------
  * Activations are (N, H, W, ld) f32, `ld` floats per pixel >= the channels used: x / y point at the first channel of
- * the slice a layer reads / writes inside its buffer, so the OSA concatenation of VoVNet (vovnet.py:205-210) is a set
+ * the slice a layer reads / writes inside its buffer, so the OSA concatenation of VoVNet (vovnet.py:222) is a set
  * of slices of one buffer and never a copy.
  *
  * srf_wino3x3: Conv2d(Cin, Cout, 3, stride 1, padding 1, bias folded into shift) as Winograd F(2x2, 3x3), followed by
  * y = y * scale[co] + shift[co] (either may be NULL) and an optional ReLU: the 3x3 layers of VoVNet's OSA blocks
- * (vovnet.py:116-133, :180-216), the image FPN outputs, `img_convs` (srfdet_head.py:404-416), SECONDCustom
+ * (vovnet.py:116-133, :180-230), the image FPN outputs, `img_convs` (srfdet_head.py:404-416), SECONDCustom
  * (second_custom.py:41-63) and the BEV FPN.  U_packed comes from srf_wino3x3_pack_weights(W (Cout, Cin, 3, 3)).
  * Cin % 8 == 0, x 16-byte aligned, x_ld % 4 == 0, 4 H W x_ld < 2^30, else SRF_EUNSUPPORTED. */
 size_t srf_wino3x3_packed_weight_bytes(int Cout, int Cin);
@@ -361,7 +361,7 @@ int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long long x_ld, co
 
 /* srf_conv1x1_nhwc: Conv2d(K, Cout, 1) on channels-last activations = the GEMM y[p][co] = sum_k x[p][k] W[co][k] over
  * M = N * H * W pixels, then y = y * scale[co] + shift[co] (either may be NULL) and an optional ReLU: the `concat` layer of
- * VoVNet's OSA blocks read straight from the block's concat buffer (vovnet.py:205-216) and the FPN lateral convolutions.
+ * VoVNet's OSA blocks read straight from the block's concat buffer (vovnet.py:222-223) and the FPN lateral convolutions.
  * W_packed comes from srf_conv1x1_nhwc_pack_weights(W (Cout, K) row-major).  K % 32 == 0, x 16-byte aligned, x_ld % 4 == 0,
  * else SRF_EUNSUPPORTED. */
 size_t srf_conv1x1_nhwc_packed_weight_bytes(int Cout, int K);
@@ -370,7 +370,7 @@ int srf_conv1x1_nhwc(const float *x, long long M, int K, long long x_ld, const f
                      const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream);
 /* srf_conv1x1_nhwc_pooled: the same convolution on N images of HW pixels (rows n HW .. (n + 1) HW - 1), which also returns
  * mean[n][co] = the mean over the image's pixels of the stored outputs: VoVNet's eSE average pool (reference
- * mmdet3d_plugin/models/backbones/vovnet.py:150-163 eSEModule.avg_pool on the output of vovnet.py:210 `concat`) without a
+ * mmdet3d_plugin/models/backbones/vovnet.py:165-177 eSEModule.avg_pool on the output of vovnet.py:223 `concat`) without a
  * second pass over the map.  Deterministic (per-block sums added in a fixed order).  workspace: _workspace_bytes(N, HW, Cout). */
 size_t srf_conv1x1_nhwc_pooled_workspace_bytes(int N, long long HW, int Cout);
 int srf_conv1x1_nhwc_pooled(const float *x, int N, long long HW, int K, long long x_ld, const float *W_packed, int Cout,
@@ -395,7 +395,7 @@ int srf_stem_conv_nchw(const float *x, int N, int Cin, int H, int W, const float
  * 16-byte aligned pointers, ld % 4 == 0 ---------------------------------------------------------------------------------
  * srf_nhwc_affine: y = x * scale[(per_sample ? n : 0)][c] + shift[c] (+ residual), optional ReLU; scale / shift / residual
  *   may be NULL; in place allowed: eval BatchNorm2d + ReLU behind a library convolution, and the eSE gate multiply + OSA
- *   identity add of VoVNet (vovnet.py:135-160, :212-216).  HW = pixels per sample.
+ *   identity add of VoVNet (vovnet.py:165-177, :225-228).  HW = pixels per sample.
  * srf_nhwc_colmean: mean[n][c] over the HW pixels (AdaptiveAvgPool2d(1) of the eSE module), deterministic two-level sum;
  *   C <= 1024.
  * srf_nhwc_maxpool3s2_ceil: MaxPool2d(3, stride 2, ceil_mode=True) (the VoVNet stage pooling) -> (N, Ho, Wo, C).

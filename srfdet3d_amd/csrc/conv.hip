@@ -1,14 +1,14 @@
 // conv.hip -- dense convolutions of the camera branch and the BEV backbone on the f32 MFMA, channels-last (NHWC).
 //
 // Reference call sites: the 3x3 / stride 1 Conv2d + BatchNorm2d + ReLU layers of VoVNet's OSA blocks
-// (mmdet3d_plugin/models/backbones/vovnet.py:116-133, :180-216), the 3x3 output convolutions of the image FPN
+// (mmdet3d_plugin/models/backbones/vovnet.py:116-133, :180-230), the 3x3 output convolutions of the image FPN
 // (configs/nus/srfdet_voxel_nusc_LC.py:55-64 -> mmdet FPN), `img_convs` of the head (srfdet_head.py:404-416), the dense
 // blocks of SECONDCustom (second_custom.py:41-63, :78-91) and the BEV FPN; the 1x1 `concat` convolution of every OSA block
 // and the FPN laterals.  The reference runs them as cuDNN calls through torch; round 1 of this repo ran them on MIOpen,
 // whose fp32 3x3 algorithm is a VALU Winograd kernel (57.8 % of the LC frame's kernel time).
 //
 // Layout: activations are (N, H, W, ld) f32 with `ld` >= channels floats per pixel: a layer reads a channel SLICE of its
-// source buffer and writes a slice of its destination buffer, so the OSA concatenation (vovnet.py:205-210: torch.cat of
+// source buffer and writes a slice of its destination buffer, so the OSA concatenation (vovnet.py:222: torch.cat of
 // the block input and the five branch outputs) is never built -- the six producers write side by side into one buffer
 // and the 1x1 convolution reads it as a plain (pixels x K) matrix.
 //
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
 
 // =====================================================================================================================
 // srf_conv1x1_nhwc: Y[p][co] = sum_k X[p][k] W[co][k] on channels-last activations -- the `concat` 1x1 convolution of the
-// OSA blocks over the whole concat buffer (vovnet.py:205-216) and the FPN laterals -- with scale / shift / ReLU as the
+// OSA blocks over the whole concat buffer (vovnet.py:222-223) and the FPN laterals -- with scale / shift / ReLU as the
 // epilogue.  A plain GEMM on v_mfma_f32_32x32x2_f32:
 //   * workgroup = 4 waves = 2 x 2 wave tiles of (32 RM) pixels x 128 channels; RM = 4: 256 pixels x 256 channels per
 //     workgroup, 16 accumulators per wave (one wave per SIMD), RM = 2 for small maps;
@@ -856,21 +856,28 @@ extern "C" int srf_conv1x1_nhwc(const float *x, long long M, int K, long long x_
 }
 
 // srf_conv1x1_nhwc_pooled: the same convolution on N images of HW pixels each, plus mean[n][co] = the mean over the
-// image's pixels of the stored outputs (after scale / shift / ReLU) -- VoVNet's eSE pooling (vovnet.py:150-163) without
+// image's pixels of the stored outputs (after scale / shift / ReLU) -- VoVNet's eSE pooling (vovnet.py:165-177) without
 // a second pass over the map.  Row blocks end with their image; a workgroup leaves the column sums of its block in the
 // workspace, a second kernel adds the blocks of an image in a fixed order (deterministic, unlike an atomic reduction).
-#define PM_GROUPS 4
+#define PM_GROUPS 16
+// 256 threads = 16 channels x 16 groups; group g adds the blocks g, g + 16, ... of its image, the 16 group sums are then added
+// in group order: a fixed order whatever the grid
 __global__ __launch_bounds__(256) void srf_conv1x1_pool_finish_k(const float *__restrict__ partial, int bpi, int C, float inv,
                                                                  float *__restrict__ mean)
 {
-    __shared__ float s[PM_GROUPS][64];
-    const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    __shared__ float s[PM_GROUPS][16];
+    const int n = blockIdx.y, cl = threadIdx.x & 15, c = blockIdx.x * 16 + cl, g = threadIdx.x >> 4;
     float acc = 0.f;
     if (c < C)
         for (int b = g; b < bpi; b += PM_GROUPS) acc += partial[((long long)n * bpi + b) * C + c];
-    s[g][threadIdx.x & 63] = acc;
+    s[g][cl] = acc;
     __syncthreads();
-    if (g == 0 && c < C) mean[(long long)n * C + c] = (((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x]) * inv;
+    if (g == 0 && c < C) {
+        float t = s[0][cl];
+#pragma unroll
+        for (int k = 1; k < PM_GROUPS; ++k) t += s[k][cl];
+        mean[(long long)n * C + c] = t * inv;
+    }
 }
 
 extern "C" size_t srf_conv1x1_nhwc_pooled_workspace_bytes(int N, long long HW, int Cout)
@@ -891,7 +898,7 @@ extern "C" int srf_conv1x1_nhwc_pooled(const float *x, int N, long long HW, int 
     const int rc = conv1x1_launch(x, (long long)N * HW, K, x_ld, W_packed, Cout, scale, shift, relu, y, y_ld, (float *)workspace, HW,
                                   (hipStream_t)stream);
     if (rc != SRF_OK) return rc;
-    hipLaunchKernelGGL(srf_conv1x1_pool_finish_k, dim3(srf_ceil_div(Cout, 64), N), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(srf_conv1x1_pool_finish_k, dim3(srf_ceil_div(Cout, 16), N), dim3(256), 0, (hipStream_t)stream,
                        (const float *)workspace, (int)srf_ceil_div(HW, 128), Cout, 1.0f / (float)HW, mean);
     SRF_LAUNCH_CHECK();
     return SRF_OK;

@@ -4,7 +4,7 @@
 // per channel (BatchNorm) or per (sample, channel) (the eSE gate of vovnet.py:136-150, with the OSA identity add as
 // the residual).  The BatchNorm case: -- the eval-mode
 // BatchNorm2d + ReLU that follows every convolution of SECONDCustom (second_custom.py:41-63), FPN and VoVNet
-// (vovnet.py:39-56), which torch runs as two kernels (MIOpen batch-norm, then a clamp).  HBM-bound: 8 bytes per
+// (vovnet.py:116-153), which torch runs as two kernels (MIOpen batch-norm, then a clamp).  HBM-bound: 8 bytes per
 // element.  The output may be a channel slice of a wider tensor (its own batch stride), so an OSA block's branch can be
 // written straight into the concatenation buffer.
 #include "common.hpp"
@@ -72,7 +72,7 @@ extern "C" int srf_channel_affine(const float *x, int N, int C, int HW, long lon
 
 // =====================================================================================================================
 // srf_conv1x1: 1x1 convolution over the CONCATENATION of up to 8 NCHW tensors, with the eval BatchNorm (or bias) and
-// ReLU as its epilogue -- the `concat` layer of every OSA block of VoVNet (vovnet.py:182-216: torch.cat of the block
+// ReLU as its epilogue -- the `concat` layer of every OSA block of VoVNet (vovnet.py:180-230: torch.cat of the block
 // input and its five 3x3 branches, then conv1x1 -> BN -> ReLU) without materialising the concatenation, and the
 // lateral convolutions of the FPN.  Per image it is the GEMM  Y[co][p] = sum_k W[co][k] X[k][p]  (p = pixel):
 //   * MFMA rows = output channels, columns = pixels: an accumulator register then holds 32 consecutive pixels of one

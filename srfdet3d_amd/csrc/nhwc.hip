@@ -4,7 +4,7 @@
 // whole 128-byte runs.
 //
 // Reference call sites: eval BatchNorm2d + ReLU behind the two stride-2 stem convolutions, the eSE gate multiply and
-// the OSA identity add (mmdet3d_plugin/models/backbones/vovnet.py:135-160, :212-216), the stage pooling
+// the OSA identity add (mmdet3d_plugin/models/backbones/vovnet.py:165-177, :225-228), the stage pooling
 // (MaxPool2d(3, 2, ceil_mode=True), vovnet.py `_OSA_stage`), the global average pool of the eSE module, the FPN top-down
 // step (mmdet FPN: lateral + nearest-upsampled coarser level), and the depthwise stride-2 stair of the proposal
 // generator (srfdet_head.py:265-320, :525-536).

@@ -1,5 +1,5 @@
 """Channels-last (NHWC) inference of the camera branch on the hand-written kernels of csrc/conv.hip and csrc/nhwc.hip:
-VoVNet (vovnet.py:268-374) -> FPN (configs/nus/srfdet_voxel_nusc_LC.py:55-64) -> `img_convs` (srfdet_head.py:404-416).
+VoVNet (vovnet.py:269-374) -> FPN (configs/nus/srfdet_voxel_nusc_LC.py:55-64) -> `img_convs` (srfdet_head.py:404-416).
 
 The torch modules stay the owners of the parameters (state_dict names untouched); this file only EXECUTES them:
 
@@ -7,7 +7,7 @@ The torch modules stay the owners of the parameters (state_dict names untouched)
   (or the bias) and the ReLU as its epilogue;
 * an OSA block owns ONE pixel-major buffer of Cin + 5 w channels: the block input sits in slice 0, each 3x3 branch writes
   its slice, and the 1x1 `concat` convolution (`srf_conv1x1_nhwc`) reads the buffer as a plain matrix -- the
-  torch.cat of vovnet.py:205-210 is never built;
+  torch.cat of vovnet.py:222 is never built;
 * eSE: pixel mean (epilogue of the concat convolution, `srf_conv1x1_nhwc_pooled`) -> fc + hard sigmoid (`srf_ese_gate`) -> gate multiply + identity add in one pass
   that writes straight into slice 0 of the next block's buffer (`srf_nhwc_affine`);
 * the stride-2 stem layers: stem_1 (3 -> 64) is a streaming kernel from the NCHW images to channels-last

@@ -1,4 +1,4 @@
-"""`VoVNet` image backbone (mmdet3d_plugin/models/backbones/vovnet.py:268-374): one-shot-aggregation stages with eSE
+"""`VoVNet` image backbone (mmdet3d_plugin/models/backbones/vovnet.py:269-374): one-shot-aggregation stages with eSE
 attention; V-99-eSE feeds the LC configs (configs/nus/srfdet_voxel_nusc_LC.py:44-54).
 
 Plain dense convolutions (torch -> MIOpen): SURVEY.md ranks it "next" (8f-2), not a hand-kernel target.  It is here
