@@ -481,7 +481,9 @@ __global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
     extern __shared__ __attribute__((aligned(16))) f32x4 s_g[];  // A[ASZ] | B[BSZ]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
-    const int nct = a.coutBlocks * NCS;
+    // column tiles that hold real channels only: a launch whose every second workgroup returned at once (Cout = 128 in a
+    // 256-channel packed block) ran at half occupancy -- the slots of the no-op workgroups are not refilled fast enough
+    const int nct = (a.Cout + TN - 1) / TN;
     const int ct = jq % nct;
     const int cb = ct / NCS, cs = ct - cb * NCS;
     const long long mb = (long long)(jq / nct) * 8 + xcd;
@@ -832,7 +834,7 @@ static int conv1x1_launch(const float *x, long long M, int K, long long x_ld, co
         a.bpi = 0;
         a.mblocks = srf_ceil_div(M, TM);
     }
-    const long long blocks = ((a.mblocks + 7) / 8) * 8 * a.coutBlocks * ncs;
+    const long long blocks = ((a.mblocks + 7) / 8) * 8 * srf_ceil_div(Cout, 256 / ncs);
     if (blocks >= (1ll << 31)) return SRF_EUNSUPPORTED;
     if (TM == 256)
         hipLaunchKernelGGL((srf_conv1x1_nhwc_k<4, 4, 1, false>), dim3((unsigned)blocks), dim3(256), LDS_BIG, stream, a);
@@ -952,7 +954,7 @@ extern "C" int srf_conv_gemm_nhwc(const float *x, int N, int H, int W, int Cin, 
     a.HW = 0;
     a.bpi = 0;
     a.mblocks = srf_ceil_div(a.M, 128);
-    long long blocks = ((a.mblocks + 7) / 8) * 8 * a.coutBlocks * 2;
+    long long blocks = ((a.mblocks + 7) / 8) * 8 * srf_ceil_div(Cout, 128);
     if (blocks >= (1ll << 31)) return SRF_EUNSUPPORTED;
     // count of 128-channel parts that hold real channels
     const long long live = a.mblocks * srf_ceil_div(Cout, 128);
@@ -960,7 +962,7 @@ extern "C" int srf_conv_gemm_nhwc(const float *x, int N, int H, int W, int Cin, 
         // a small map (the stride-2 layers of the BEV FPN: 46 x 46 outputs = 17 tiles of 128 pixels, each a chain of
         // 36 chunks on one CU with the rest of the chip idle): 64 x 64 tiles, four times the workgroups, a quarter of the chain
         a.mblocks = srf_ceil_div(a.M, 64);
-        blocks = ((a.mblocks + 7) / 8) * 8 * a.coutBlocks * 4;
+        blocks = ((a.mblocks + 7) / 8) * 8 * srf_ceil_div(Cout, 64);
         hipLaunchKernelGGL((srf_conv1x1_nhwc_k<1, 1, 4, true>), dim3((unsigned)blocks), dim3(256), (8 * 64 + 8 * 64) * 16, (hipStream_t)stream, a);
     } else
         hipLaunchKernelGGL((srf_conv1x1_nhwc_k<2, 2, 3, true>), dim3((unsigned)blocks), dim3(256), (8 * 128 + 8 * 128) * 16, (hipStream_t)stream, a);
