@@ -573,6 +573,49 @@ __device__ __forceinline__ void srf_tail_to_image(float (*s_out)[LIN_TN + 4], fl
     }
 }
 
+// s_out[32][0 .. 128) -> LayerNorm (two-pass, biased variance, as torch) -> ReLU -> operand image, in one pass: thread
+// (row = tid >> 3, q = tid & 7) owns the 16 columns ch * 32 + 4 q .. + 3 of its row (exactly what it writes into the image),
+// the 8 threads of a row are 8 adjacent lanes and combine their partial sums with three xor-shuffles.  Replaces a per-wave
+// loop over 8 rows (two 64-lane reductions per row), a write-back to s_out, a barrier and the separate image pass.
+__device__ __forceinline__ void srf_tail_ln_relu_to_image(float (*s_out)[LIN_TN + 4], const float *g, const float *b, float eps, float *img)
+{
+    const int r = threadIdx.x >> 3, q = threadIdx.x & 7;
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        v[ch] = *reinterpret_cast<const f32x4 *>(&s_out[r][ch * 32 + q * 4]);
+        s += (v[ch][0] + v[ch][1]) + (v[ch][2] + v[ch][3]);
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    const float mean = s / (float)LIN_TN;
+    float qq = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = v[ch][i] - mean;
+            qq += t * t;
+        }
+    qq += __shfl_xor(qq, 1, 64);
+    qq += __shfl_xor(qq, 2, 64);
+    qq += __shfl_xor(qq, 4, 64);
+    const float rstd = 1.0f / sqrtf(qq / (float)LIN_TN + eps);
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        const f32x4 gg = *reinterpret_cast<const f32x4 *>(g + ch * 32 + q * 4), bb = *reinterpret_cast<const f32x4 *>(b + ch * 32 + q * 4);
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float y = (v[ch][i] - mean) * rstd * gg[i] + bb[i];
+            o[i] = y > 0.f ? y : 0.f;
+        }
+        srf_img_store(img + ch * 1024, r, q, o);
+    }
+}
+
 // The FFN of a stage, one 128-wide slice of the hidden layer per workgroup (grid: row tiles x F / 128):
 //   partial[slice][row][:] = relu(obj W1[n0 : n0 + 128]^T + b1[n0 :]) W2[:, n0 : n0 + 128]^T
 // srf_stage_tail_k then adds the slices in a fixed order.  Inside one workgroup the FFN is a chain of 2 F / 128 dependent
@@ -800,15 +843,7 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
             __syncthreads();
             if (l < nl) {
                 const float *pg = p_tw + (2 * TAIL_MAX_TOWER * tower + 2 * l) * C;
-                RowEpilogue ep = {nullptr, pg, pg + C, nullptr, nullptr, nullptr, 0, 1, 0, tower == 0 ? tw.eps_cls[l] : tw.eps_reg[l], 0.f};
-                for (int r = wave * 8; r < wave * 8 + 8; ++r) {
-                    float v[2] = {s_out[r][lane], s_out[r][lane + 64]};
-                    srf_row_epilogue<2>(v, C, lane, row0 + r, ep);
-                    s_out[r][lane] = v[0];
-                    s_out[r][lane + 64] = v[1];
-                }
-                __syncthreads();
-                srf_tail_to_image(s_out, img_h);
+                srf_tail_ln_relu_to_image(s_out, pg, pg + C, tower == 0 ? tw.eps_cls[l] : tw.eps_reg[l], img_h);
                 src = img_h;
             } else if (tower == 0) {
                 for (int e = tid; e < 32 * N; e += 256) {
