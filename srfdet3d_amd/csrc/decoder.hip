@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
         p_bl[i] = i < tw.ncls ? tw.bl[i] : 0.f;
         p_bd[i] = i < tw.Dd ? tw.bd[i] : 0.f;
     }
-    {  // obj tile -> image
+    if (!partial) {  // obj tile -> image (the FFN's operand; with `partial` the FFN ran elsewhere)
         const int r = tid >> 3, q = tid & 7, row = row0 + r;
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
@@ -766,6 +766,68 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
         __syncthreads();
     }
     // ---- obj2 = LN3(obj + ffn + b2) ----------------------------------------------------------------------------------
+    if (partial) {
+        // FFN done by srf_stage_ffn_k: thread (row = tid >> 3, q = tid & 7) adds the slices of its 16 columns (ch * 32 + 4 q
+        // .. + 3, slice 0 first), then bias + residual + LayerNorm with the 8 lanes of the row, obj_out and the operand
+        // image of both towers -- one pass, nothing through s_out, no barrier before the image is complete
+        const int r = tid >> 3, q = tid & 7, row = row0 + r;
+        const int ns = F / LIN_TN;
+        const bool live = row < R;
+        f32x4 v[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) v[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();  // the bias / LayerNorm vectors in s_par are complete
+        if (live) {
+            for (int sl = 0; sl < ns; ++sl) {
+                const float *src = partial + ((size_t)sl * R + row) * C + q * 4;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    const f32x4 t = *reinterpret_cast<const f32x4 *>(src + ch * 32);
+                    v[ch][0] = __fadd_rn(v[ch][0], t[0]);
+                    v[ch][1] = __fadd_rn(v[ch][1], t[1]);
+                    v[ch][2] = __fadd_rn(v[ch][2], t[2]);
+                    v[ch][3] = __fadd_rn(v[ch][3], t[3]);
+                }
+            }
+        }
+        float sm = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(p_b2 + ch * 32 + q * 4);
+            f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+            if (live) rs = *reinterpret_cast<const f32x4 *>(obj_in + (size_t)row * C + ch * 32 + q * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[ch][i] = (v[ch][i] + bb[i]) + rs[i];
+            sm += (v[ch][0] + v[ch][1]) + (v[ch][2] + v[ch][3]);
+        }
+        sm += __shfl_xor(sm, 1, 64);
+        sm += __shfl_xor(sm, 2, 64);
+        sm += __shfl_xor(sm, 4, 64);
+        const float mean = sm / (float)TAIL_C;
+        float qq = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float t = v[ch][i] - mean;
+                qq += t * t;
+            }
+        qq += __shfl_xor(qq, 1, 64);
+        qq += __shfl_xor(qq, 2, 64);
+        qq += __shfl_xor(qq, 4, 64);
+        const float rstd = 1.0f / sqrtf(qq / (float)TAIL_C + tw.eps_n3);
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const f32x4 gg = *reinterpret_cast<const f32x4 *>(p_n3g + ch * 32 + q * 4), bb = *reinterpret_cast<const f32x4 *>(p_n3b + ch * 32 + q * 4);
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (v[ch][i] - mean) * rstd * gg[i] + bb[i];
+                if (first_tower == 0) *reinterpret_cast<f32x4 *>(obj_out + (size_t)row * C + ch * 32 + q * 4) = o;
+            }
+            srf_img_store(img_obj + ch * 1024, r, q, o);
+        }
+    } else {
     float res[8][2];  // the residual rows of this wave, all in flight before the spill below (not one L2 round trip per row)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -773,30 +835,7 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
         res[i][0] = row < R ? obj_in[(size_t)row * C + lane] : 0.f;
         res[i][1] = row < R ? obj_in[(size_t)row * C + lane + 64] : 0.f;
     }
-    if (!partial) {
-        srf_tail_spill(acc2, s_out);
-    } else {  // sum of the slices, slice 0 first: thread -> (row tid >> 3, 16 columns)
-        const int r = tid >> 3, c0 = (tid & 7) * 16, row = row0 + r;
-        const int ns = F / LIN_TN;
-        f32x4 sum[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (row < R) {
-            for (int sl = 0; sl < ns; ++sl) {
-                const float *src = partial + ((size_t)sl * R + row) * C + c0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * i);
-                    sum[i][0] = __fadd_rn(sum[i][0], v[0]);
-                    sum[i][1] = __fadd_rn(sum[i][1], v[1]);
-                    sum[i][2] = __fadd_rn(sum[i][2], v[2]);
-                    sum[i][3] = __fadd_rn(sum[i][3], v[3]);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(&s_out[r][c0 + 4 * i]) = sum[i];
-    }
+    srf_tail_spill(acc2, s_out);
     __syncthreads();
     {
         RowEpilogue ep = {p_b2, nullptr, nullptr, obj_in, p_n3g, p_n3b, C, 0, 0, 0.f, tw.eps_n3};
@@ -822,6 +861,7 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
     }
     __syncthreads();
     srf_tail_to_image(s_out, img_obj);  // img_obj now holds obj2, the input of both towers
+    }
     // ---- towers ---------------------------------------------------------------------------------------------------------
     for (int tower = first_tower; tower <= last_tower; ++tower) {
         const int nl = tower == 0 ? tw.n_cls : tw.n_reg;
