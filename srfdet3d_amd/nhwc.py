@@ -163,8 +163,10 @@ def _osa_forward(m, buf, cin, dst):
     return dst
 
 
-def vovnet_forward(net, x):
-    """x (N, 3, H, W) f32 -> OrderedDict of the requested stage outputs (logical NCHW, channels_last strides)."""
+def vovnet_forward(net, x, upto=None):
+    """x (N, 3, H, W) f32 -> OrderedDict of the requested stage outputs (logical NCHW, channels_last strides).
+    upto = a stage name: stop after that stage and return (outputs so far, that stage's NHWC output) -- the frozen prefix
+    of the backbone during training (`VoVNet.forward`)."""
     from collections import OrderedDict
     from .plugin.vovnet import OSAModule
     out = OrderedDict()
@@ -215,6 +217,8 @@ def vovnet_forward(net, x):
                 _osa_forward(m, buf, cin, cur)
         if name in net._out_features:
             out[name] = nchw_view(cur)
+        if upto is not None and name == upto:
+            return out, cur
     return out
 
 

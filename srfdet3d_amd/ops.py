@@ -801,7 +801,9 @@ def ese_gate(mean, weight, bias):
     N, C = mean.shape
     w = _dev(weight, "weight", torch.float32).reshape(C, C).contiguous()
     gate = _empty((N, C), torch.float32, mean.device)
-    check(_lib.lib().srf_ese_gate(_ptr(mean), N, C, _ptr(w), _ptr(bias), _ptr(gate), _stream()), "ese_gate")
+    for n0 in range(0, N, 8):   # the GEMV kernel takes up to 8 rows per launch (6 cameras; 12 images at batch size 2)
+        n1 = min(N, n0 + 8)
+        check(_lib.lib().srf_ese_gate(_ptr(mean[n0:n1]), n1 - n0, C, _ptr(w), _ptr(bias), _ptr(gate[n0:n1]), _stream()), "ese_gate")
     return gate
 
 

@@ -125,10 +125,16 @@ class VoVNet(BaseModule):
             # fp32 inference on the GPU: channels-last execution on the Winograd / GEMM kernels of csrc/conv.hip
             return nhwc.vovnet_forward(self, x)
         out = OrderedDict()
-        x = run_sequential(self.stem, x)
-        if "stem" in self._out_features:
-            out["stem"] = x
+        done = self._frozen_prefix(x, out)   # training: the frozen stages on the inference kernels, without autograd
+        if done is None:
+            x = run_sequential(self.stem, x)
+            if "stem" in self._out_features:
+                out["stem"] = x
+        else:
+            x = done
         for name in self.stage_names:
+            if done is not None and int(name[5:]) <= self.frozen_stages + 1:
+                continue
             for m in getattr(self, name).children():
                 if (isinstance(m, nn.MaxPool2d) and fusable(x) and m.kernel_size == 3 and m.stride == 2 and m.padding == 0
                         and m.ceil_mode and m.dilation == 1):
@@ -138,6 +144,28 @@ class VoVNet(BaseModule):
             if name in self._out_features:
                 out[name] = x
         return out
+
+    def _frozen_prefix(self, x, out):
+        """With `frozen_stages` >= 1 the stem and stage2 .. stage{frozen_stages + 1} carry no gradient and their BatchNorms are in
+        eval mode even while the rest trains (vovnet.py `_freeze_stages`, config `frozen_stages=2, norm_eval=True`): run
+        them channels-last on the Winograd / GEMM kernels under no_grad, as inference does, and hand NCHW copies to the
+        trainable remainder (module path, autograd).  Returns the last frozen stage's output or None (not applicable)."""
+        from .. import nhwc
+        if not (torch.is_grad_enabled() and self.frozen_stages >= 1 and nhwc.enabled() and not x.requires_grad):
+            return None
+        last = f"stage{self.frozen_stages + 1}"
+        if last not in self.stage_names:
+            return None
+        frozen = [self.stem] + [getattr(self, f"stage{i + 1}") for i in range(1, self.frozen_stages + 1)]
+        if any(p.requires_grad for m in frozen for p in m.parameters()) or any(m.training for m in frozen):
+            return None
+        with torch.no_grad():
+            if not nhwc.vovnet_supported(self, x):
+                return None
+            part, cur = nhwc.vovnet_forward(self, x, upto=last)
+            for k, v in part.items():
+                out[k] = v.contiguous()          # NCHW for the module path (MIOpen picks other kernels for channels_last)
+            return out[last] if last in out else nhwc.nchw_view(cur).contiguous()
 
     def _freeze_stages(self):
         if self.frozen_stages >= 0:

@@ -221,6 +221,33 @@ def test_vovnet_fpn_channels_last_path_matches_module_path(monkeypatch):
         assert (o - r).abs().max().item() <= 2e-4 * r.abs().max().item()
 
 
+def test_vovnet_training_runs_the_frozen_prefix_on_the_inference_kernels(monkeypatch):
+    """Config 4 trains with `frozen_stages=2, norm_eval=True` (configs/nus/srfdet_voxel_nusc_LC.py:44-54): stem, stage2 and
+    stage3 carry no gradient.  With autograd recording they run on the channels-last inference kernels under no_grad; the
+    stage outputs equal the all-module path within 2e-4 of the level's max and the trainable stages still get gradients."""
+    from srfdet3d_amd.plugin.vovnet import VoVNet
+    g = torch.Generator().manual_seed(4)
+    torch.manual_seed(4)
+    net = VoVNet("V-99-eSE", out_features=["stage2", "stage3", "stage4", "stage5"], frozen_stages=2, norm_eval=True)
+    _randomize_bn(net, g)
+    net = net.to(DEV).train()
+    assert not net.stage3.training and not any(p.requires_grad for p in net.stage3.parameters())
+    assert any(p.requires_grad for p in net.stage4.parameters())
+    x = torch.randn(2, 3, 96, 160, generator=g).to(DEV)
+    monkeypatch.setenv("SRF_IMG_NHWC", "0")
+    ref = net(x)
+    monkeypatch.setenv("SRF_IMG_NHWC", "1")
+    out = net(x)
+    for k in ref:
+        assert out[k].shape == ref[k].shape and out[k].is_contiguous()
+        assert (out[k] - ref[k]).abs().max().item() <= 2e-4 * ref[k].abs().max().item(), k
+    assert not out["stage3"].requires_grad and out["stage4"].requires_grad
+    out["stage5"].square().mean().backward()
+    gr = next(p for p in net.stage4.parameters() if p.requires_grad).grad
+    assert gr is not None and torch.isfinite(gr).all() and gr.abs().max() > 0
+    assert all(p.grad is None for p in net.stage2.parameters())
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad", [(2, 13, 18, 32, 48, 3, 2, 1), (1, 184, 184, 128, 256, 3, 2, 1),
                                                          (6, 32, 48, 64, 128, 3, 2, 1), (1, 23, 23, 128, 128, 3, 2, 1),
                                                          (1, 9, 11, 64, 40, 3, 1, 1)])
