@@ -199,15 +199,26 @@ def main():
             with open(path) as fh:
                 return json.load(fh).get("traffic_bytes_per_launch")
 
-        # the 128 -> 128, 27-offset SubM conv (4 launches per frame on the 5x184x184 level)
-        dom = [(s.elapsed_time(e), flops, byts) for (s, e, cin, cout, K, flops, byts) in records
-               if cin == 128 and cout == 128 and K == 27]
+        # the dominant sparse-conv shape = the (Cin, Cout, K) group with the most time: the 128 -> 128, 27-offset SubM conv on
+        # nuScenes / Waymo (4 launches per frame on the 5x184x184 level), 64 -> 64 on KITTI's narrower encoder
+        groups = {}
+        for (s, e, cin, cout, K, flops, byts) in records:
+            groups.setdefault((cin, cout, K), []).append((s.elapsed_time(e), flops, byts))
+        dom_key = max(groups, key=lambda k: sum(d[0] for d in groups[k])) if groups else None
+        if (128, 128, 27) in groups:
+            dom_key = (128, 128, 27)
+        dom = groups.get(dom_key, [])
+        per_frame = {}
+        for (s, e, cin, cout, K, flops, byts) in records:
+            per_frame[(cin, cout, K)] = per_frame.get((cin, cout, K), 0) + 1
         spconv128 = None
         if dom:
             ms = sum(d[0] for d in dom) / len(dom)
             flops = sum(d[1] for d in dom) / len(dom)
             achieved = flops / (ms * 1e-3) / 1e12
-            spconv128 = dict(kernel="srf_spconv_gs_k<4> (SubM 3x3x3, 128->128, last level of the sparse encoder)", bound="mfma",
+            kname = ("srf_spconv_gs_k<4, 128> (SubM 3x3x3, 128->128, last level of the sparse encoder)" if dom_key == (128, 128, 27)
+                     else f"sparse conv {dom_key[0]}->{dom_key[1]}, {dom_key[2]} offsets (the shape with the most time in this encoder)")
+            spconv128 = dict(kernel=kname, bound="mfma",
                              achieved=round(achieved, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                              frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                              traffic=_traffic("spconv128") if args.workload in ("nusc_L", "nusc_LC") else None,
@@ -217,7 +228,9 @@ def main():
         stage = None
         if records:
             rows = [(s.elapsed_time(e), flops, byts) for (s, e, cin, cout, K, flops, byts) in records]
-            nfr = max(1, len(dom) // 4) if dom else 1
+            # frames covered by the records: conv_input (first layer of the encoder) runs once per frame
+            first = next(iter(per_frame))
+            nfr = max(1, per_frame[first]) if per_frame else 1
             ms, fl, by = sum(r[0] for r in rows), sum(r[1] for r in rows), sum(r[2] for r in rows)
             stage = dict(name="sparse-conv stage: every srf_spconv_* launch of the encoder (21 per nuScenes frame)", launches=len(rows),
                          ms_per_frame=round(ms / nfr, 4), gflop_per_frame=round(fl / nfr / 1e9, 3), mbytes_per_frame=round(by / nfr / 1e6, 2),
