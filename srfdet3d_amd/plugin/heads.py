@@ -235,7 +235,7 @@ class _StageBase(BaseModule):
         qkv = ops.linear(q0, mha.in_proj_weight, mha.in_proj_bias)
         att = qkv.new_empty((R, C))
         for b in range(bs):  # attention is among the proposals of one sample
-            att[b * n_p:(b + 1) * n_p] = ops.self_attention(qkv[b * n_p:(b + 1) * n_p], mha.num_heads)
+            ops.self_attention(qkv[b * n_p:(b + 1) * n_p], mha.num_heads, out=att[b * n_p:(b + 1) * n_p])
         q1 = ops.linear(att, mha.out_proj.weight, mha.out_proj.bias, residual=q0, ln2=self.norm1_lidar)
         dc = self.inst_interact_lidar
         params = ops.linear(q1, dc.dynamic_layer.weight, dc.dynamic_layer.bias)
