@@ -50,7 +50,7 @@ def main():
     from bench import randomize_bn
     randomize_bn(model)
     model = model.to(dev)
-    model.enable_hip_graphs(whole_frame=not model.use_img)
+    model.enable_hip_graphs(img_overlap=model.use_img, whole_frame=True)   # the configuration bench.py runs by default
     pc_range = list(model.pts_voxel_layer.point_cloud_range) if hasattr(model, "pts_voxel_layer") else list(synthetic.NUSC_RANGE)
     V, H, W = 6, 900, 1600
     rng = np.random.default_rng(0)
