@@ -81,8 +81,43 @@ __global__ __launch_bounds__(256) void srf_wino3x3_pack_k(const float *__restric
     P[t] = r;
 }
 
-__device__ __forceinline__ float4 wn_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 wn_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// float4 arithmetic as two packed instructions each: hipcc packs only about half of the component-wise form (28 of the 64
+// transform operations of a chunk stayed scalar) and lowers a vector subtraction to four v_sub_f32
+typedef float wn_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ wn_v2 wn_pk_add(wn_v2 a, wn_v2 b)
+{
+    wn_v2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ wn_v2 wn_pk_sub(wn_v2 a, wn_v2 b)
+{
+    wn_v2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ wn_v2 wn_pk_fma(wn_v2 s, wn_v2 a, wn_v2 b)
+{
+    wn_v2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(s), "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float4 wn_sub(float4 a, float4 b)
+{
+    const wn_v2 lo = wn_pk_sub(wn_v2{a.x, a.y}, wn_v2{b.x, b.y}), hi = wn_pk_sub(wn_v2{a.z, a.w}, wn_v2{b.z, b.w});
+    return make_float4(lo[0], lo[1], hi[0], hi[1]);
+}
+__device__ __forceinline__ float4 wn_add(float4 a, float4 b)
+{
+    const wn_v2 lo = wn_pk_add(wn_v2{a.x, a.y}, wn_v2{b.x, b.y}), hi = wn_pk_add(wn_v2{a.z, a.w}, wn_v2{b.z, b.w});
+    return make_float4(lo[0], lo[1], hi[0], hi[1]);
+}
+__device__ __forceinline__ float4 wn_fma(float s, float4 a, float4 b)   // s a + b, one rounding per component
+{
+    const wn_v2 sv = {s, s};
+    const wn_v2 lo = wn_pk_fma(sv, wn_v2{a.x, a.y}, wn_v2{b.x, b.y}), hi = wn_pk_fma(sv, wn_v2{a.z, a.w}, wn_v2{b.z, b.w});
+    return make_float4(lo[0], lo[1], hi[0], hi[1]);
+}
 
 #define WN_MFMA4(ACC, A, B)                                                        \
     do {                                                                           \
@@ -169,8 +204,10 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
 #pragma unroll
         for (int r = 0; r < 3; ++r) rsrc_row[r] = 8192 + (q * PR + 2 * ty + rsel[r]) * RP + tx;
     }
-    const float4 *Ug = a.U + (size_t)cb * 2048 + tid;
-    const size_t u_chunk_stride = (size_t)a.coutBlocks * 2048;
+    const int u_chunk_bytes = a.coutBlocks * 2048 * 16;   // one chunk of all channel blocks (the host checks the total < 2^31)
+    __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float4 *>(a.U) + (size_t)cb * 2048, 0, (int)((long long)a.nchunk * u_chunk_bytes - (long long)cb * 2048 * 16), 0x00020000);
+    const int u_voff = tid * 16;
 
     // staging registers as named scalars (arrays indexed from macro loops were left in scratch by hipcc)
     float4 pr_0, pr_1, pr_2, pr_3, pr_4, pr_5, pr_6, pr_7, pr_8, pr_9, pr_10, pr_11;
@@ -184,15 +221,22 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
         WN_RD(1, 0, 4) WN_RD(1, 1, 5) WN_RD(1, 2, 6) WN_RD(1, 3, 7)     \
         WN_RD(2, 0, 8) WN_RD(2, 1, 9) WN_RD(2, 2, 10) WN_RD(2, 3, 11)   \
     } while (0)
+    // weights through a buffer descriptor: the chunk / slab part of the address is a scalar offset (no 64-bit vector adds
+    // in the loop: vector instructions take MFMA time away)
+#define WN_UL(I, J)                                                                                             \
+    {                                                                                                           \
+        auto v_ = __builtin_amdgcn_raw_buffer_load_b128(ursrc, u_voff, u_soff_ + (J) * 4096, 0);                 \
+        ur_##I = *reinterpret_cast<float4 *>(&v_);                                                              \
+    }
 #define WN_LOAD_U_LO(CH)                                              \
     do {                                                              \
-        const float4 *ub_ = Ug + (size_t)(CH) * u_chunk_stride;       \
-        if (!(DBG & 2)) { ur_0 = ub_[0]; ur_1 = ub_[256]; ur_2 = ub_[512]; ur_3 = ub_[768]; } \
+        const int u_soff_ = (CH) * u_chunk_bytes;                     \
+        if (!(DBG & 2)) { WN_UL(0, 0) WN_UL(1, 1) WN_UL(2, 2) WN_UL(3, 3) } \
     } while (0)
 #define WN_LOAD_U_HI(CH)                                              \
     do {                                                              \
-        const float4 *ub_ = Ug + (size_t)(CH) * u_chunk_stride;       \
-        if (!(DBG & 2)) { ur_4 = ub_[1024]; ur_5 = ub_[1280]; ur_6 = ub_[1536]; ur_7 = ub_[1792]; } \
+        const int u_soff_ = (CH) * u_chunk_bytes;                     \
+        if (!(DBG & 2)) { WN_UL(4, 4) WN_UL(5, 5) WN_UL(6, 6) WN_UL(7, 7) } \
     } while (0)
 #define WN_STORE_U_LO(WB)                                             \
     do {                                                              \
@@ -207,8 +251,7 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
     // vertical stage: the two frequency rows this half owns, for the 4 columns (register rows RA = 0-3, RB = 4-7, RC = 8-11)
 #define WN_S1(C, A, B, D)                                                                                           \
     t0_##C = wn_sub(pr_##A, pr_##D);                                                                                \
-    t1_##C = make_float4(__fmaf_rn(sgn, pr_##B.x, pr_##D.x), __fmaf_rn(sgn, pr_##B.y, pr_##D.y),                    \
-                         __fmaf_rn(sgn, pr_##B.z, pr_##D.z), __fmaf_rn(sgn, pr_##B.w, pr_##D.w));
+    t1_##C = wn_fma(sgn, pr_##B, pr_##D);
 #define WN_STAGE1()         \
     do {                    \
         WN_S1(0, 0, 4, 8)   \
@@ -735,6 +778,7 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
     a.nchunk = Cin / 8;
     const long long nspatial = (long long)N * a.rowBlocks * a.colBlocks;
     if (nspatial * a.coutBlocks >= (1ll << 30)) return SRF_EUNSUPPORTED;
+    if (srf_wino3x3_packed_weight_bytes(Cout, Cin) >= ((size_t)1 << 31)) return SRF_EUNSUPPORTED;  // buffer-descriptor range of U
     a.nspatial = (int)nspatial;
     a.relu = relu;
     a.stamps = g_wino_stamps;
