@@ -221,6 +221,45 @@ def test_vovnet_fpn_channels_last_path_matches_module_path(monkeypatch):
         assert (o - r).abs().max().item() <= 2e-4 * r.abs().max().item()
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(6, 232, 400, 128, 128), (6, 116, 200, 160, 160), (6, 58, 100, 192, 192),
+                                            (6, 29, 50, 224, 224), (1, 184, 184, 256, 128)])
+def test_winograd_equals_the_direct_convolution_at_full_layer_sizes(N, H, W, Cin, Cout):
+    """BASELINE.json's full sizes (six 928 x 1600 cameras -> the 232 x 400 ... 29 x 50 maps of VoVNet-99, the 184 x 184 BEV map):
+    the Winograd kernel against an INDEPENDENT kernel of this library, the implicit-im2col GEMM (`srf_conv_gemm_nhwc`, every
+    output one k-ordered fma chain, itself pinned to float64 at small sizes above) -- within 2e-5 of the map's maximum, with
+    scale / shift / ReLU, on every pixel incl. the borders and the partial tile blocks."""
+    g = torch.Generator().manual_seed(Cin + H)
+    x = torch.randn(N, H, W, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    yw = ops.wino3x3(x, ops.pack_wino3x3_weights(w), Cout, scale, shift, True)
+    yd = ops.conv_gemm_nhwc(x, ops.pack_conv_gemm_weights(w), Cout, (3, 3), 1, 1, scale, shift, True)
+    assert yw.shape == yd.shape
+    assert (yw - yd).abs().max().item() <= 2e-5 * yd.abs().max().item()
+    assert (yw > 0).float().mean().item() > 0.2          # the comparison is not between two all-zero maps
+
+
+@pytest.mark.parametrize("N,HW,K,Cout", [(6, 232 * 400, 768, 256), (6, 116 * 200, 1312, 512), (6, 58 * 100, 1728, 768),
+                                         (6, 29 * 50, 2144, 1024)])
+def test_conv1x1_at_full_layer_sizes_against_rocblas(N, HW, K, Cout):
+    """The OSA concat convolutions of an LC frame at their real sizes: outputs within 3e-5 of the map's maximum of torch.mm
+    (rocBLAS, another summation order), the fused eSE mean equal to the mean of what was stored, the same bits on a rerun."""
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(N, 1, HW, K, generator=g).to(DEV)
+    w = (torch.randn(Cout, K, generator=g) / K ** 0.5).to(DEV)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    pk = ops.pack_conv1x1_nhwc_weights(w)
+    y, mean = ops.conv1x1_nhwc(x, pk, Cout, scale, shift, True, pool=True)
+    ref = torch.relu(torch.mm(x.view(N * HW, K), w.t()) * scale + shift).view(N, 1, HW, Cout)
+    assert (y - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+    m_ref = y.double().mean(dim=(1, 2))
+    assert (mean.double() - m_ref).abs().max().item() <= 1e-5 * m_ref.abs().max().item()
+    y2, mean2 = ops.conv1x1_nhwc(x, pk, Cout, scale, shift, True, pool=True)
+    assert torch.equal(y, y2) and torch.equal(mean, mean2)
+
+
 def test_vovnet_training_runs_the_frozen_prefix_on_the_inference_kernels(monkeypatch):
     """Config 4 trains with `frozen_stages=2, norm_eval=True` (configs/nus/srfdet_voxel_nusc_LC.py:44-54): stem, stage2 and
     stage3 carry no gradient.  With autograd recording they run on the channels-last inference kernels under no_grad; the
