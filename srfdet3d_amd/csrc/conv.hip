@@ -839,7 +839,8 @@ extern "C" int srf_conv1x1_nhwc_pack_weights(const float *W, int Cout, int K, fl
 
 // shared launcher: bpi == 0 -> flat row tiling; bpi > 0 -> per-image tiling with column sums into `colsum`
 static int conv1x1_launch(const float *x, long long M, int K, long long x_ld, const float *W_packed, int Cout, const float *scale,
-                          const float *shift, int relu, float *y, long long y_ld, float *colsum, long long HW, hipStream_t stream)
+                          const float *shift, int relu, float *y, long long y_ld, float *colsum, long long HW, hipStream_t stream,
+                          int *bpi_out = nullptr)
 {
     GemmArgs a;
     a.x = x;
@@ -870,10 +871,14 @@ static int conv1x1_launch(const float *x, long long M, int K, long long x_ld, co
     }
     static const int big = getenv("SRF_GEMM_BIG") ? atoi(getenv("SRF_GEMM_BIG")) : 0;
     int TM = (big && !colsum) ? 256 : 128, ncs = (big && !colsum) ? 1 : 2;
-    if (!colsum && srf_ceil_div(M, 128) * srf_ceil_div(Cout, 128) < 384) TM = 64, ncs = 4;  // small problem: 64 x 64 tiles
+    // below ~0.8 rounds of 128 x 128 tiles at three per CU the 64 x 64 tiles win (stage 5 of VoVNet: 544 tiles, 417 -> 386 us);
+    // SRF_GEMM_SMALL overrides the threshold (developer A/B knob)
+    static const int small_thr = getenv("SRF_GEMM_SMALL") ? atoi(getenv("SRF_GEMM_SMALL")) : 640;
+    if (srf_ceil_div(M, 128) * srf_ceil_div(Cout, 128) < small_thr) TM = 64, ncs = 4;  // small problem: 64 x 64 tiles
     if (colsum) {
         a.bpi = (int)srf_ceil_div(HW, TM);
         a.mblocks = (M / HW) * a.bpi;
+        if (bpi_out) *bpi_out = a.bpi;
     } else {
         a.bpi = 0;
         a.mblocks = srf_ceil_div(M, TM);
@@ -928,7 +933,7 @@ __global__ __launch_bounds__(256) void srf_conv1x1_pool_finish_k(const float *__
 
 extern "C" size_t srf_conv1x1_nhwc_pooled_workspace_bytes(int N, long long HW, int Cout)
 {
-    return (N <= 0 || HW <= 0 || Cout <= 0) ? 0 : (size_t)N * (size_t)srf_ceil_div(HW, 128) * Cout * 4;
+    return (N <= 0 || HW <= 0 || Cout <= 0) ? 0 : (size_t)N * (size_t)srf_ceil_div(HW, 64) * Cout * 4;  // row blocks of >= 64
 }
 
 extern "C" int srf_conv1x1_nhwc_pooled(const float *x, int N, long long HW, int K, long long x_ld, const float *W_packed, int Cout,
@@ -941,11 +946,12 @@ extern "C" int srf_conv1x1_nhwc_pooled(const float *x, int N, long long HW, int 
     if ((K & 31) || (x_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)W_packed & 15) || N > 65535) return SRF_EUNSUPPORTED;
     if (x_ld * 256 * 4 >= (1ll << 31)) return SRF_EUNSUPPORTED;
     if (workspace_bytes < srf_conv1x1_nhwc_pooled_workspace_bytes(N, HW, Cout)) return SRF_EWORKSPACE;
+    int bpi = 0;
     const int rc = conv1x1_launch(x, (long long)N * HW, K, x_ld, W_packed, Cout, scale, shift, relu, y, y_ld, (float *)workspace, HW,
-                                  (hipStream_t)stream);
+                                  (hipStream_t)stream, &bpi);
     if (rc != SRF_OK) return rc;
     hipLaunchKernelGGL(srf_conv1x1_pool_finish_k, dim3(srf_ceil_div(Cout, 16), N), dim3(256), 0, (hipStream_t)stream,
-                       (const float *)workspace, (int)srf_ceil_div(HW, 128), Cout, 1.0f / (float)HW, mean);
+                       (const float *)workspace, bpi, Cout, 1.0f / (float)HW, mean);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }
