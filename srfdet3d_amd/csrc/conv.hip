@@ -49,6 +49,7 @@ struct WinoArgs {
     long long x_ld, y_ld;
     int N, H, W, Cout;
     int rowBlocks, colBlocks, coutBlocks, nchunk, nspatial, relu;
+    int cb0, ncb;       // channel blocks of this launch: cb0 .. cb0 + ncb - 1
     long long *stamps;  // developer timing hook (srf_dev_set_stamp_buffer): 4 s_memtime values per workgroup, else NULL
 };
 
@@ -129,7 +130,12 @@ __device__ __forceinline__ float4 wn_fma(float s, float4 a, float4 b)   // s a +
 
 // TWL = log2 of the tile block's width: the 64 tiles of a workgroup form an 8 x 8, 16 x 4 or 32 x 2 (rows x columns) block --
 // the host picks the shape that covers the map with the fewest blocks (a 29 x 50 tile map: 28 / 26 / 25 blocks).
-template <int DBG, int TWL>
+// HALFB: the launch covers ONE channel block that holds at most 32 real channels (Cout = 160, 224: the last block).  The four
+// waves then split (tile half) x (FREQUENCY half) instead of (tile half) x (channel half): 8 frequencies = 8 accumulator
+// tiles and 32 MFMAs per chunk and wave instead of 64 (the all-zero channel half is not multiplied); the waves of the
+// upper frequency half hand their 8 accumulator tiles (the frequency rows 2 and 3 of M) to the lower half through LDS,
+// which then runs the SAME output transform in the same order of operations as the full kernel: identical bits.
+template <int DBG, int TWL, bool HALFB = false>
 __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
 {
     constexpr int TW = 1 << TWL, TH = 64 >> TWL;       // tiles per block row / column
@@ -143,8 +149,8 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // workgroups b and b + 8 share an XCD (round-robin dispatch): the cout blocks of one spatial block sit on one L2
     const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
-    const int cb = jq % a.coutBlocks;
-    const int sp = (jq / a.coutBlocks) * 8 + xcd;
+    const int cb = a.cb0 + jq % a.ncb;
+    const int sp = (jq / a.ncb) * 8 + xcd;
     if (sp >= a.nspatial) return;
     const int per_img = a.rowBlocks * a.colBlocks;
     const int n = sp / per_img;
@@ -269,11 +275,11 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
         s_w[o_ + 384] = wn_sub(T##_1, T##_3);                                    \
     } while (0)
 
-    // ---- MFMA role: tile half th, channel half chh ----
-    const int th = wave & 1, chh = wave >> 1;
+    // ---- MFMA role: tile half th, channel half chh (HALFB: frequency half fh = wave >> 1, channels 0 .. 31 of the block) ----
+    const int th = wave & 1, chh = HALFB ? 0 : wave >> 1, fh = HALFB ? wave >> 1 : 0;
     const int li = lane & 31, lh = lane >> 5;
-    const int a_off = lh * 64 + th * 32 + li;          // + f * 128 (+ buffer)
-    const int b_off = 4096 + lh * 64 + chh * 32 + li;  // + f * 128 (+ buffer)
+    const int a_off = lh * 64 + th * 32 + li + fh * 1024;          // + f * 128 (+ buffer)
+    const int b_off = 4096 + lh * 64 + chh * 32 + li + fh * 1024;  // + f * 128 (+ buffer)
 #define WN_READ_GROUP(SET, G, RB)                                                 \
     do {                                                                          \
         _Pragma("unroll") for (int e_ = 0; e_ < 2; ++e_) {                        \
@@ -347,6 +353,43 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
     // multiplies); writes the patch of chunk c + 2 (registers -> RAW) and loads the one of chunk c + 3; finishes the
     // transform of chunk c + 1 (horizontal stage -> V) and stages its weights (-> U), loads the weights of chunk c + 2;
     // behind the barrier, under the last group: chunk c + 2's patch RAW -> registers -> vertical stage.
+    if (HALFB) {
+        // four groups (8 frequencies) per chunk and wave: the schedule of the full loop with the groups 4 .. 7 taken out
+        for (int c = 0; c < nchunk; ++c) {
+            const int rbuf = (c & 1) * 2048, wbuf = 2048 - rbuf;
+            const int rawb = (c & 1) * WN_RAW;
+            const int c2 = c + 2 < nchunk ? c + 2 : last, c3 = c + 3 < nchunk ? c + 3 : last;
+            WN_READ_GROUP(1, 1, rbuf);
+            WN_FENCE();
+            WN_STORE_RAW(rawb);
+            WN_LOAD_RAW(c3);
+            WN_MFMA_GROUP(0, 0);
+            WN_FENCE();
+            WN_READ_GROUP(0, 2, rbuf);
+            WN_FENCE();
+            WN_STAGE2(t0, 2 * hh, wbuf);
+            WN_STORE_U_LO(wbuf);
+            WN_LOAD_U_LO(c2);
+            WN_MFMA_GROUP(1, 1);
+            WN_FENCE();
+            WN_READ_GROUP(1, 3, rbuf);
+            WN_FENCE();
+            WN_STAGE2(t1, 2 * hh + 1, wbuf);
+            WN_STORE_U_HI(wbuf);
+            WN_LOAD_U_HI(c2);
+            WN_MFMA_GROUP(0, 2);
+            WN_FENCE();
+            __syncthreads();
+            WN_READ_GROUP(0, 0, wbuf);
+            WN_READ_RAW(rawb);
+            WN_FENCE();
+            WN_MFMA_HALF(1, 3, 0);
+            WN_FENCE();
+            WN_STAGE1();
+            WN_MFMA_HALF(1, 3, 1);
+            WN_FENCE();
+        }
+    } else {
     for (int c = 0; c < nchunk; ++c) {
         const int rbuf = (c & 1) * 2048, wbuf = 2048 - rbuf;
         const int rawb = (c & 1) * WN_RAW;
@@ -398,8 +441,24 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
         WN_FENCE();
     }
 
+    }
+
     // ---- epilogue: A^T m A, affine, ReLU, store ----
     if (DBG & 8) st2 = __builtin_amdgcn_s_memtime();
+    // HALFB: frequency rows 2 and 3 of M (the accumulator tiles of the waves with fh = 1) change hands through LDS:
+    // X[th][f 8][register 16][lane 64] floats = 64 KB over the V / U images, which nobody reads any more
+    float *xch = reinterpret_cast<float *>(s_w) + th * (8 * 16 * 64) + lane;
+    if (HALFB) {
+        __syncthreads();  // every wave is past the (unused) fragment / patch reads of the loop's last trip
+        if (fh == 1) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[(f * 16 + r) * 64] = acc[f][r];
+        }
+        __syncthreads();
+        if (fh == 1) return;
+    }
     const int co = cb * 64 + chh * 32 + li;
     const bool co_ok = co < a.Cout;
     const float sc = (co_ok && a.scale) ? a.scale[co] : 1.f;
@@ -416,7 +475,8 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
             float s[4], d[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float m0 = acc[j][r], m1 = acc[4 + j][r], m2 = acc[8 + j][r], m3 = acc[12 + j][r];
+                const float m0 = acc[j][r], m1 = acc[4 + j][r];
+                const float m2 = HALFB ? xch[(j * 16 + r) * 64] : acc[8 + j][r], m3 = HALFB ? xch[((4 + j) * 16 + r) * 64] : acc[12 + j][r];
                 s[j] = (m0 + m1) + m2;
                 d[j] = (m1 - m2) - m3;
             }
@@ -770,7 +830,8 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
             twl = l;
         }
     }
-    static const int force_twl = getenv("SRF_WINO_TWL") ? atoi(getenv("SRF_WINO_TWL")) : 0;  // developer A/B knob
+    const char *twl_env = getenv("SRF_WINO_TWL");             // developer A/B knob, read per call (the tests flip it)
+    const int force_twl = twl_env ? atoi(twl_env) : 0;
     if (force_twl >= 1 && force_twl <= 3) twl = force_twl;
     a.rowBlocks = srf_ceil_div(tilesY, 64 >> twl);
     a.colBlocks = srf_ceil_div(tilesX, 1 << twl);
@@ -789,17 +850,22 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
     if (dev < 0 || dev >= 64) return SRF_EUNSUPPORTED;
     static const int dbg = getenv("SRF_WINO_DBG") ? atoi(getenv("SRF_WINO_DBG")) : 0;  // timing ablations (developer knob)
     if (!attr_set[dev]) {
-#define WN_ATTR(D, L) SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<D, L>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES))
-        WN_ATTR(0, 1);
-        WN_ATTR(0, 2);
-        WN_ATTR(0, 3);
-        WN_ATTR(1, 3);
-        WN_ATTR(4, 3);
-        WN_ATTR(8, 3);
+#define WN_ATTR(D, L, HB) SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<D, L, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES))
+        WN_ATTR(0, 1, false);
+        WN_ATTR(0, 2, false);
+        WN_ATTR(0, 3, false);
+        WN_ATTR(0, 1, true);
+        WN_ATTR(0, 2, true);
+        WN_ATTR(0, 3, true);
+        WN_ATTR(1, 3, false);
+        WN_ATTR(4, 3, false);
+        WN_ATTR(8, 3, false);
 #undef WN_ATTR
         attr_set[dev] = true;
     }
-    const dim3 grid((unsigned)blocks), blk(256);
+    const dim3 blk(256);
+    a.cb0 = 0;
+    a.ncb = a.coutBlocks;
     if (dbg == 1 || dbg == 4 || dbg == 8) {   // ablation builds exist for the 8 x 8 shape only
         a.rowBlocks = srf_ceil_div(tilesY, 8);
         a.colBlocks = srf_ceil_div(tilesX, 8);
@@ -808,13 +874,44 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
         if (dbg == 1) hipLaunchKernelGGL((srf_wino3x3_k<1, 3>), gd, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
         else if (dbg == 4) hipLaunchKernelGGL((srf_wino3x3_k<4, 3>), gd, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((srf_wino3x3_k<8, 3>), gd, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
-    } else if (twl == 3) {
-        hipLaunchKernelGGL((srf_wino3x3_k<0, 3>), grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
-    } else if (twl == 2) {
-        hipLaunchKernelGGL((srf_wino3x3_k<0, 2>), grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
-    } else {
-        hipLaunchKernelGGL((srf_wino3x3_k<0, 1>), grid, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
+        SRF_LAUNCH_CHECK();
+        return SRF_OK;
     }
+    // A last channel block with at most 32 real channels (Cout = 160, 224, ...) can run on the half-block kernel, whose
+    // workgroups take ~0.62 of a full one, as a launch of its own.  Worth it when it saves rounds of 256 workgroups
+    // (SRF_WINO_HALF=0 / 1 forces the choice: developer A/B knob).
+    const long long sp8 = ((nspatial + 7) / 8) * 8;
+    const int rem = Cout - (a.coutBlocks - 1) * 64;
+    const char *fh_env = getenv("SRF_WINO_HALF");   // read per call: the tests flip it
+    const int force_half = fh_env ? atoi(fh_env) : -1;
+    bool split = false;
+    if (rem <= 32) {
+        int cus = 0;
+        SRF_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (cus <= 0) cus = 256;
+        const double now = (double)srf_ceil_div(sp8 * a.coutBlocks, cus);
+        const double then = (double)srf_ceil_div(sp8 * (a.coutBlocks - 1), cus) + 0.62 * (double)srf_ceil_div(sp8, cus);
+        split = force_half < 0 ? then < now : force_half != 0;
+    }
+#define WN_LAUNCH(HB, GRID)                                                                                                    \
+    do {                                                                                                                       \
+        if (twl == 3) hipLaunchKernelGGL((srf_wino3x3_k<0, 3, HB>), dim3((unsigned)(GRID)), blk, WN_LDS_BYTES, (hipStream_t)stream, a);      \
+        else if (twl == 2) hipLaunchKernelGGL((srf_wino3x3_k<0, 2, HB>), dim3((unsigned)(GRID)), blk, WN_LDS_BYTES, (hipStream_t)stream, a); \
+        else hipLaunchKernelGGL((srf_wino3x3_k<0, 1, HB>), dim3((unsigned)(GRID)), blk, WN_LDS_BYTES, (hipStream_t)stream, a);               \
+    } while (0)
+    if (split) {
+        if (a.coutBlocks > 1) {
+            a.cb0 = 0;
+            a.ncb = a.coutBlocks - 1;
+            WN_LAUNCH(false, sp8 * a.ncb);
+        }
+        a.cb0 = a.coutBlocks - 1;
+        a.ncb = 1;
+        WN_LAUNCH(true, sp8);
+    } else {
+        WN_LAUNCH(false, blocks);
+    }
+#undef WN_LAUNCH
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

@@ -260,6 +260,31 @@ def test_conv1x1_at_full_layer_sizes_against_rocblas(N, HW, K, Cout):
     assert torch.equal(y, y2) and torch.equal(mean, mean2)
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 37, 53, 64, 160), (1, 64, 64, 32, 32), (3, 20, 132, 40, 96), (1, 58, 100, 224, 224),
+                                            (2, 9, 11, 16, 20)])
+def test_winograd_half_block_kernel_gives_the_same_bits(monkeypatch, N, H, W, Cin, Cout):
+    """A last channel block with <= 32 real channels can run on the half-block kernel (waves split the frequencies instead
+    of the channels, the upper half hands its accumulators over through LDS): the output transform then performs the same
+    operations in the same order, so the results are bit-identical to the one-launch form, whichever the launcher picks."""
+    g = torch.Generator().manual_seed(Cout + W)
+    x = torch.randn(N, H, W, Cin, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    pk = ops.pack_wino3x3_weights(w)
+    outs = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("SRF_WINO_HALF", force)
+        for twl in ("1", "2", "3"):
+            monkeypatch.setenv("SRF_WINO_TWL", twl)   # 8 x 8, 16 x 4 and 32 x 2 tile blocks
+            outs.append(ops.wino3x3(x, pk, Cout, scale, shift, True))
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    ref = F.conv2d(x.permute(0, 3, 1, 2).cpu().double(), w.cpu().double(), padding=1)
+    ref = (ref * scale.cpu().double().view(1, -1, 1, 1) + shift.cpu().double().view(1, -1, 1, 1)).relu().permute(0, 2, 3, 1)
+    assert (outs[0].cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 def test_vovnet_training_runs_the_frozen_prefix_on_the_inference_kernels(monkeypatch):
     """Config 4 trains with `frozen_stages=2, norm_eval=True` (configs/nus/srfdet_voxel_nusc_LC.py:44-54): stem, stage2 and
     stage3 carry no gradient.  With autograd recording they run on the channels-last inference kernels under no_grad; the
