@@ -50,6 +50,7 @@ struct WinoArgs {
     int N, H, W, Cout;
     int rowBlocks, colBlocks, coutBlocks, nchunk, nspatial, relu;
     int cb0, ncb;       // channel blocks of this launch: cb0 .. cb0 + ncb - 1
+    int nfull;          // srf_wino3x3_mixed_k: workgroups of the full form (the half-block ones follow)
     long long *stamps;  // developer timing hook (srf_dev_set_stamp_buffer): 4 s_memtime values per workgroup, else NULL
 };
 
@@ -135,8 +136,8 @@ __device__ __forceinline__ float4 wn_fma(float s, float4 a, float4 b)   // s a +
 // tiles and 32 MFMAs per chunk and wave instead of 64 (the all-zero channel half is not multiplied); the waves of the
 // upper frequency half hand their 8 accumulator tiles (the frequency rows 2 and 3 of M) to the lower half through LDS,
 // which then runs the SAME output transform in the same order of operations as the full kernel: identical bits.
-template <int DBG, int TWL, bool HALFB = false>
-__global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
+template <int DBG, int TWL, bool HALFB>
+__device__ __forceinline__ void srf_wino3x3_body(const WinoArgs &a, const unsigned bid)
 {
     constexpr int TW = 1 << TWL, TH = 64 >> TWL;       // tiles per block row / column
     constexpr int PR = 2 * TH + 2, PC = 2 * TW + 2;    // patch rows / columns (pixels)
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
     extern __shared__ __attribute__((aligned(16))) float4 s_w[];  // V[2][2048] | U[2][2048] | RAW[2][WN_RAW]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // workgroups b and b + 8 share an XCD (round-robin dispatch): the cout blocks of one spatial block sit on one L2
-    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const int xcd = bid & 7, jq = bid >> 3;
     const int cb = a.cb0 + jq % a.ncb;
     const int sp = (jq / a.ncb) * 8 + xcd;
     if (sp >= a.nspatial) return;
@@ -506,11 +507,33 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
     }
     if ((DBG & 8) && a.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        long long *o = a.stamps + (size_t)blockIdx.x * 4;
+        long long *o = a.stamps + (size_t)bid * 4;
         o[0] = st0;
         o[1] = st1;
         o[2] = st2;
         o[3] = __builtin_amdgcn_s_memtime();
+    }
+}
+
+template <int DBG, int TWL, bool HALFB = false>
+__global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
+{
+    srf_wino3x3_body<DBG, TWL, HALFB>(a, blockIdx.x);
+}
+
+// One launch for a layer whose last channel block runs on the half-block form: the first a.nfull workgroups are full ones
+// (channel blocks 0 .. coutBlocks - 2), the rest half ones -- the short workgroups fill the tail of the long ones instead
+// of waiting for a launch of their own.
+template <int TWL>
+__global__ __launch_bounds__(256, 1) void srf_wino3x3_mixed_k(WinoArgs a)
+{
+    if (blockIdx.x < (unsigned)a.nfull) {
+        srf_wino3x3_body<0, TWL, false>(a, blockIdx.x);
+    } else {
+        WinoArgs h = a;
+        h.cb0 = a.coutBlocks - 1;
+        h.ncb = 1;
+        srf_wino3x3_body<0, TWL, true>(h, blockIdx.x - (unsigned)a.nfull);
     }
 }
 
@@ -857,6 +880,9 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
         WN_ATTR(0, 1, true);
         WN_ATTR(0, 2, true);
         WN_ATTR(0, 3, true);
+        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_mixed_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
+        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_mixed_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
+        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_mixed_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
         WN_ATTR(1, 3, false);
         WN_ATTR(4, 3, false);
         WN_ATTR(8, 3, false);
@@ -890,7 +916,10 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
         SRF_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (cus <= 0) cus = 256;
         const double now = (double)srf_ceil_div(sp8 * a.coutBlocks, cus);
-        const double then = (double)srf_ceil_div(sp8 * (a.coutBlocks - 1), cus) + 0.62 * (double)srf_ceil_div(sp8, cus);
+        // one mixed launch: the half workgroups (0.62 of a full one each) fill the tail of the full ones
+        const double work = (double)(sp8 * (a.coutBlocks - 1)) + 0.62 * (double)sp8;
+        const double then = a.coutBlocks > 1 ? std::max(work / cus + 0.3, (double)srf_ceil_div(sp8 * (a.coutBlocks - 1), cus))
+                                             : 0.62 * (double)srf_ceil_div(sp8, cus);
         split = force_half < 0 ? then < now : force_half != 0;
     }
 #define WN_LAUNCH(HB, GRID)                                                                                                    \
@@ -899,12 +928,16 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
         else if (twl == 2) hipLaunchKernelGGL((srf_wino3x3_k<0, 2, HB>), dim3((unsigned)(GRID)), blk, WN_LDS_BYTES, (hipStream_t)stream, a); \
         else hipLaunchKernelGGL((srf_wino3x3_k<0, 1, HB>), dim3((unsigned)(GRID)), blk, WN_LDS_BYTES, (hipStream_t)stream, a);               \
     } while (0)
-    if (split) {
-        if (a.coutBlocks > 1) {
-            a.cb0 = 0;
-            a.ncb = a.coutBlocks - 1;
-            WN_LAUNCH(false, sp8 * a.ncb);
-        }
+    a.nfull = 0;
+    if (split && a.coutBlocks > 1) {
+        a.cb0 = 0;
+        a.ncb = a.coutBlocks - 1;
+        a.nfull = (int)(sp8 * a.ncb);
+        const dim3 gm((unsigned)(sp8 * a.coutBlocks));
+        if (twl == 3) hipLaunchKernelGGL((srf_wino3x3_mixed_k<3>), gm, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
+        else if (twl == 2) hipLaunchKernelGGL((srf_wino3x3_mixed_k<2>), gm, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((srf_wino3x3_mixed_k<1>), gm, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
+    } else if (split) {
         a.cb0 = a.coutBlocks - 1;
         a.ncb = 1;
         WN_LAUNCH(true, sp8);
