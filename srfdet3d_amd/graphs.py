@@ -294,6 +294,7 @@ class GraphedFrame:
             with torch.no_grad(), _graph_safe_convs(safe), torch.cuda.graph(graph):
                 x, counts = self._run_bev(static_pts, caps)
                 scores, boxes, sel = self._run_head(x, sm.metas, img_feats)
+                host_pack = self._host_pack(sel, counts[0]) if sel is not None else None
             _validate(graph, [scores, boxes, counts[0]], ref, "whole-frame graph")
         else:
             # with cameras the frame is two graphs: everything up to the BEV pyramid needs no image feature and replays
@@ -304,10 +305,11 @@ class GraphedFrame:
             head_graph = torch.cuda.CUDAGraph()
             with torch.no_grad(), _graph_safe_convs(safe), torch.cuda.graph(head_graph, pool=graph.pool()):
                 scores, boxes, sel = self._run_head(x, sm.metas, img_feats)
+                host_pack = self._host_pack(sel, counts[0]) if sel is not None else None
             _validate(head_graph, [scores, boxes], ref[:2], "whole-frame graph (decoder half)")
         self.stats["captures"] += 1
         self.entry = dict(graph=graph, head_graph=head_graph, pts=static_pts, far=far, n_cap=n_cap, nf=pts.shape[1], caps=caps,
-                          scores=scores, boxes=boxes, counts=counts[0], limits=counts[1], sel=sel, metas=sm, bev=x,
+                          scores=scores, boxes=boxes, counts=counts[0], limits=counts[1], sel=sel, metas=sm, bev=x, host_pack=host_pack,
                           img_key=None if img_feats is None else tuple(f.data_ptr() for f in img_feats))
         return self.entry
 
@@ -327,6 +329,13 @@ class GraphedFrame:
         scores, dec = m.bbox_head.decode(logits, boxes)
         sel = m.bbox_head.select_static(scores, dec) if getattr(m.bbox_head, "use_nms", False) else None
         return scores, dec, sel
+
+    @staticmethod
+    def _host_pack(sel, dev_counts):
+        """Everything the host needs from a frame in ONE float32 vector (one device -> host copy, one synchronisation instead
+        of three): the packed detections, [survivors, candidates] per sample and the live row counts of the sparse levels
+        (integers below 2^24, exact as floats)."""
+        return torch.cat([sel[0].reshape(-1), sel[1].reshape(-1).to(torch.float32), dev_counts.to(torch.float32)])
 
     def _eager(self, pts, img_metas, img_feats=None):
         m = self.model
@@ -365,10 +374,17 @@ class GraphedFrame:
         if e["head_graph"] is not None:
             e["head_graph"].replay()
         self.stats["replays"] += 1
-        counts = e["counts"].tolist()  # the one read-back of the frame; the detections are complete by then
+        sel = e["sel"]
+        if e["host_pack"] is not None:
+            h = e["host_pack"].cpu()  # the one read-back of the frame: detections, their counts and the level counts
+            n_pk, n_c = e["sel"][0].numel(), e["sel"][1].numel()
+            sel = (h[:n_pk].view(e["sel"][0].shape), h[n_pk:n_pk + n_c].to(torch.int32).view(e["sel"][1].shape))
+            counts = h[n_pk + n_c:].to(torch.int64).tolist()
+        else:
+            counts = e["counts"].tolist()
         if any(c > lim for c, lim in zip(counts, e["limits"])):
             scores, dec, sizes = self._eager(pts, img_metas, img_feats)
             sizes = {k: max(v, int(e["caps"][k] / self.HEADROOM)) for k, v in sizes.items()}
             _capture_with_fallback(lambda safe: self._capture(pts, img_metas, sizes, e["n_cap"], img_feats, safe))
             return scores, dec, None
-        return e["scores"], e["boxes"], e["sel"]
+        return e["scores"], e["boxes"], sel   # sel is on the host already when the frame was packed
