@@ -24,7 +24,7 @@ SQ = ("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY S
 
 # name -> (program after `--`, kernel-name substring, description, algorithmic bytes note)
 TARGETS = {
-    "wino3x3": (["tools/prof_img_branch.py", "3"], "srf_wino3x3_k<0",
+    "wino3x3": (["tools/prof_img_branch.py", "3"], ("srf_wino3x3_k<", "srf_wino3x3_mixed_k<"),
                 "every srf_wino3x3_k launch of 3 eager passes of the LC camera branch (89 per frame: VoVNet-99, image FPN, img_convs)"),
     "conv1x1": (["tools/prof_img_branch.py", "3"], "srf_conv1x1_nhwc_k<2, 2, 3, false>",
                 "every srf_conv1x1_nhwc_k launch of the same passes (OSA concat convolutions + FPN laterals, 20 per frame)"),
@@ -46,11 +46,15 @@ def run_pass(tag, counters, prog):
     return d, " ".join(cmd[:-len(prog) - 1]).replace(ROOT + "/", "") + " python3 " + " ".join(prog)
 
 
+def _match(sub, name):
+    return any(x in name for x in sub) if isinstance(sub, tuple) else sub in name
+
+
 def counters_of(d, sub):
     acc = defaultdict(list)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if sub in r["Kernel_Name"]:
+            if _match(sub, r["Kernel_Name"]):
                 acc[r["Counter_Name"]].append((int(r.get("Dispatch_Id", 0)), float(r["Counter_Value"])))
     return acc
 
@@ -58,7 +62,7 @@ def counters_of(d, sub):
 def durations_of(d, sub):
     ts = []
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
-        ts += [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f)) if sub in r["Kernel_Name"]]
+        ts += [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f)) if _match(sub, r["Kernel_Name"])]
     return ts
 
 
@@ -79,7 +83,7 @@ def main():
         write = [v for _, v in sorted(counters_of(dw, sub)["WRITE_SIZE"])]
         sq = {k: [v for _, v in sorted(vs)] for k, vs in counters_of(ds, sub).items()}
         if not fetch or not write:
-            print(f"{name}: no dispatch of '{sub}' found", flush=True)
+            print(f"{name}: no dispatch of {sub!r} found", flush=True)
             continue
         # the first pass of a multi-pass target is cold (weight packing, first-touch): drop the first third when there are >= 3 passes
         skip = len(fetch) // 3 if len(fetch) >= 3 else 0
@@ -87,7 +91,7 @@ def main():
         f_kb, w_kb = sum(fetch[skip:]) / n, sum(write[skip:]) / n
         dur = durations_of(ds, sub)
         out = {
-            "kernel": sub, "workload": desc, "launches_averaged": n,
+            "kernel": " | ".join(sub) if isinstance(sub, tuple) else sub, "workload": desc, "launches_averaged": n,
             "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb,
             "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B -> read bytes = 2 * FETCH_SIZE * 1024 "
                           "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
