@@ -464,6 +464,13 @@ __device__ __forceinline__ void srf_wino3x3_body(const WinoArgs &a, const unsign
     const bool co_ok = co < a.Cout;
     const float sc = (co_ok && a.scale) ? a.scale[co] : 1.f;
     const float sh = (co_ok && a.shift) ? a.shift[co] : 0.f;
+    // stores through a buffer descriptor of image n: a pixel outside the map (or a channel past Cout) gets an offset beyond
+    // the range and the hardware drops the store -- no exec-mask branches, no 64-bit address arithmetic (the predicated
+    // global stores cost ~400 of the epilogue's ~1400 instructions)
+    __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + (long long)n * a.H * a.W * a.y_ld, 0,
+                                                                     (int)((long long)a.H * a.W * a.y_ld * 4), 0x00020000);
+    const unsigned px_b = (unsigned)(a.y_ld * 4), row_b = (unsigned)(a.W * a.y_ld * 4);
+    const unsigned OOB = 0x80000000u;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
 #pragma unroll
@@ -471,8 +478,8 @@ __device__ __forceinline__ void srf_wino3x3_body(const WinoArgs &a, const unsign
             const int r = rg * 4 + rr;
             const int t = th * 32 + rr + 8 * rg + 4 * lh;   // tile of accumulator register r in this lane half
             const int oy = 2 * (rb * TH + (t >> TWL)), ox = 2 * (cbk * TW + (t & (TW - 1)));
-            const bool row_ok = oy < a.H && co_ok;
-            float *yrow = a.y + (((long long)n * a.H + oy) * a.W) * a.y_ld + co;
+            const bool row_ok = oy < a.H && co_ok && ox < a.W;
+            const unsigned o00_ = (unsigned)((oy * a.W + ox) * (int)a.y_ld + co) * 4u;
             float s[4], d[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -493,16 +500,11 @@ __device__ __forceinline__ void srf_wino3x3_body(const WinoArgs &a, const unsign
                 o10 = fmaxf(o10, 0.f);
                 o11 = fmaxf(o11, 0.f);
             }
-            if (row_ok && ox < a.W) {
-                float *p = yrow + (long long)ox * a.y_ld;
-                p[0] = o00;
-                if (ox + 1 < a.W) p[a.y_ld] = o01;
-                if (oy + 1 < a.H) {
-                    float *p2 = p + (long long)a.W * a.y_ld;
-                    p2[0] = o10;
-                    if (ox + 1 < a.W) p2[a.y_ld] = o11;
-                }
-            }
+            const bool x1 = ox + 1 < a.W, y1 = oy + 1 < a.H;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o00), yrsrc, (int)(row_ok ? o00_ : OOB), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o01), yrsrc, (int)(row_ok && x1 ? o00_ + px_b : OOB), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o10), yrsrc, (int)(row_ok && y1 ? o00_ + row_b : OOB), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o11), yrsrc, (int)(row_ok && x1 && y1 ? o00_ + row_b + px_b : OOB), 0, 0);
         }
     }
     if ((DBG & 8) && a.stamps && tid == 0) {
@@ -829,7 +831,7 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
     if (!x || !U_packed || !y) return SRF_EINVAL;
     if ((Cin & 7) || (x_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)U_packed & 15)) return SRF_EUNSUPPORTED;
     // per-lane byte offsets inside one image must stay below 2^30 (the buffer descriptor covers one image)
-    if ((long long)H * W * x_ld * 4 >= (1ll << 30)) return SRF_EUNSUPPORTED;
+    if ((long long)H * W * x_ld * 4 >= (1ll << 30) || (long long)H * W * y_ld * 4 >= (1ll << 31)) return SRF_EUNSUPPORTED;
     WinoArgs a;
     a.x = x;
     a.y = y;
