@@ -756,9 +756,17 @@ __global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
         sc[j] = (co_ok[j] && a.scale) ? a.scale[co] : 1.f;
         sh[j] = (co_ok[j] && a.shift) ? a.shift[co] : 0.f;
     }
-    const long long prow = p0 + wm * 32 * RM + 4 * lh;  // + i * 32 + (r & 3) + 8 * (r >> 2)
-    float *yb = a.y + prow * a.y_ld + co0;
-    const long long rows_left = rows_blk - (wm * 32 * RM + 4 * lh);
+    // stores through a buffer descriptor over this block's rows: a row past the block (or the image) and a channel past Cout
+    // are offsets beyond the range, which the hardware drops -- no exec-mask branch per row, 32-bit offsets
+    const long long rows_here = rows_blk < TM ? rows_blk : TM;
+    __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + p0 * a.y_ld, 0, (int)(rows_here * a.y_ld * 4), 0x00020000);
+    const int row_base = wm * 32 * RM + 4 * lh;     // + i * 32 + (r & 3) + 8 * (r >> 2)
+    unsigned ybase[RN];
+#pragma unroll
+    for (int j = 0; j < RN; ++j) ybase[j] = co_ok[j] ? (unsigned)((row_base * a.y_ld + co0 + j * 32) * 4) : 0x80000000u;
+    const unsigned yrow_b = (unsigned)(a.y_ld * 4);
+    const long long rows_left = rows_blk - row_base;
+    const bool want_sum = !CONV && a.colsum != nullptr;
     float csum[RN];
 #pragma unroll
     for (int j = 0; j < RN; ++j) csum[j] = 0.f;
@@ -767,15 +775,12 @@ __global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
-            float *yp = yb + (long long)dr * a.y_ld;
-            if (dr < rows_left) {
 #pragma unroll
-                for (int j = 0; j < RN; ++j) {
-                    float v = __fmaf_rn(acc[i][j][r], sc[j], sh[j]);
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (co_ok[j]) yp[j * 32] = v;
-                    csum[j] += v;
-                }
+            for (int j = 0; j < RN; ++j) {
+                float v = __fmaf_rn(acc[i][j][r], sc[j], sh[j]);
+                if (a.relu) v = fmaxf(v, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrsrc, (int)(ybase[j] + (unsigned)dr * yrow_b), 0, 0);
+                if (want_sum) csum[j] += dr < rows_left ? v : 0.f;
             }
         }
         WN_FENCE();
