@@ -368,6 +368,14 @@ size_t srf_conv1x1_nhwc_packed_weight_bytes(int Cout, int K);
 int srf_conv1x1_nhwc_pack_weights(const float *W, int Cout, int K, float *packed, srf_stream_t stream);
 int srf_conv1x1_nhwc(const float *x, long long M, int K, long long x_ld, const float *W_packed, int Cout, const float *scale,
                      const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream);
+/* srf_conv1x1_nhwc_topdown: an FPN lateral convolution with the top-down step in its epilogue (mmdet FPN.forward:
+ * `laterals[i - 1] += F.interpolate(laterals[i], size=..., mode="nearest")`, necks of configs/nus/srfdet_voxel_nusc_LC.py:55-64
+ * and :67-76): y[n][py][px][co] = act(conv) + top[n][floor(py Ht / H)][floor(px Wt / W)][co].  x rows are the pixels of an
+ * (N, H, W) map; top is an (N, Ht, Wt, >= Cout) channels-last slice with top_ld floats per pixel.  Same bits as
+ * srf_conv1x1_nhwc followed by srf_nhwc_upsample_add. */
+int srf_conv1x1_nhwc_topdown(const float *x, int N, int H, int W, int K, long long x_ld, const float *W_packed, int Cout,
+                             const float *scale, const float *shift, int relu, const float *top, int Ht, int Wt, long long top_ld,
+                             float *y, long long y_ld, srf_stream_t stream);
 /* srf_conv1x1_nhwc_pooled: the same convolution on N images of HW pixels (rows n HW .. (n + 1) HW - 1), which also returns
  * mean[n][co] = the mean over the image's pixels of the stored outputs: VoVNet's eSE average pool (reference
  * mmdet3d_plugin/models/backbones/vovnet.py:165-177 eSEModule.avg_pool on the output of vovnet.py:223 `concat`) without a

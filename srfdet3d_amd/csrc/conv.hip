@@ -574,6 +574,12 @@ struct GemmArgs {
     float *colsum;
     long long HW;
     int bpi;
+    // FPN top-down step fused into the lateral convolution: y += top[n][floor(py sy)][floor(px sx)][co] (nearest upsampling by
+    // size, as F.interpolate / srf_nhwc_upsample_add); rows are the pixels (n, py, px) of an (N, mapH, mapW) map
+    const float *top;
+    long long top_ld;
+    int mapH, mapW, topH, topW;
+    float sy, sx;
 };
 
 // W (Cout, K) row-major -> [chunk of 32][cout block of 256][channel 256][slot 8][4]; slot s of row co holds quad
@@ -767,6 +773,26 @@ __global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
     const unsigned yrow_b = (unsigned)(a.y_ld * 4);
     const long long rows_left = rows_blk - row_base;
     const bool want_sum = !CONV && a.colsum != nullptr;
+    const bool want_top = !CONV && a.top != nullptr;
+    int *s_top = reinterpret_cast<int *>(s_g);  // [TM]: offset (floats) of the top-level pixel each row of this block adds
+    if (want_top) {
+        __syncthreads();  // the last chunk's fragment reads are done
+        if (tid < TM) {
+            const long long row = p0 + tid;
+            int off = 0;
+            if (row < a.M) {
+                const int hw = a.mapH * a.mapW;
+                const int n = (int)(row / hw), rem = (int)(row - (long long)n * hw);
+                const int yy = rem / a.mapW, xx = rem - yy * a.mapW;
+                int ys = (int)floorf((float)yy * a.sy), xs = (int)floorf((float)xx * a.sx);
+                if (ys > a.topH - 1) ys = a.topH - 1;
+                if (xs > a.topW - 1) xs = a.topW - 1;
+                off = (int)((((long long)n * a.topH + ys) * a.topW + xs) * a.top_ld);
+            }
+            s_top[tid] = off;
+        }
+        __syncthreads();
+    }
     float csum[RN];
 #pragma unroll
     for (int j = 0; j < RN; ++j) csum[j] = 0.f;
@@ -779,6 +805,7 @@ __global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
             for (int j = 0; j < RN; ++j) {
                 float v = __fmaf_rn(acc[i][j][r], sc[j], sh[j]);
                 if (a.relu) v = fmaxf(v, 0.f);
+                if (want_top && co_ok[j]) v = __fadd_rn(v, a.top[s_top[row_base + dr] + co0 + j * 32]);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrsrc, (int)(ybase[j] + (unsigned)dr * yrow_b), 0, 0);
                 if (want_sum) csum[j] += dr < rows_left ? v : 0.f;
             }
@@ -975,9 +1002,15 @@ extern "C" int srf_conv1x1_nhwc_pack_weights(const float *W, int Cout, int K, fl
 }
 
 // shared launcher: bpi == 0 -> flat row tiling; bpi > 0 -> per-image tiling with column sums into `colsum`
+struct TopDown {
+    const float *top;
+    long long top_ld;
+    int mapH, mapW, topH, topW;
+};
+
 static int conv1x1_launch(const float *x, long long M, int K, long long x_ld, const float *W_packed, int Cout, const float *scale,
                           const float *shift, int relu, float *y, long long y_ld, float *colsum, long long HW, hipStream_t stream,
-                          int *bpi_out = nullptr)
+                          int *bpi_out = nullptr, const TopDown *td = nullptr)
 {
     GemmArgs a;
     a.x = x;
@@ -997,6 +1030,14 @@ static int conv1x1_launch(const float *x, long long M, int K, long long x_ld, co
     a.x_bytes = 0;
     a.colsum = colsum;
     a.HW = HW;
+    a.top = td ? td->top : nullptr;
+    a.top_ld = td ? td->top_ld : 0;
+    a.mapH = td ? td->mapH : 0;
+    a.mapW = td ? td->mapW : 0;
+    a.topH = td ? td->topH : 0;
+    a.topW = td ? td->topW : 0;
+    a.sy = td ? (float)td->topH / (float)td->mapH : 0.f;
+    a.sx = td ? (float)td->topW / (float)td->mapW : 0.f;
     int dev = 0;
     SRF_HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return SRF_EUNSUPPORTED;
@@ -1041,6 +1082,24 @@ extern "C" int srf_conv1x1_nhwc(const float *x, long long M, int K, long long x_
     if ((K & 31) || (x_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)W_packed & 15)) return SRF_EUNSUPPORTED;
     if (x_ld * 256 * 4 >= (1ll << 31)) return SRF_EUNSUPPORTED;
     return conv1x1_launch(x, M, K, x_ld, W_packed, Cout, scale, shift, relu, y, y_ld, nullptr, 0, (hipStream_t)stream);
+}
+
+// srf_conv1x1_nhwc_topdown: the lateral 1x1 convolution of an FPN level with the top-down step in its epilogue:
+// y[n][py][px][co] = act(conv) + top[n][floor(py Ht / H)][floor(px Wt / W)][co] -- the `laterals[i - 1] += F.interpolate(
+// laterals[i], size=..., mode="nearest")` of mmdet's FPN.forward without a pass of its own over the finer level (the same
+// two floats are added as in srf_nhwc_upsample_add: identical bits).
+extern "C" int srf_conv1x1_nhwc_topdown(const float *x, int N, int H, int W, int K, long long x_ld, const float *W_packed, int Cout,
+                                        const float *scale, const float *shift, int relu, const float *top, int Ht, int Wt, long long top_ld,
+                                        float *y, long long y_ld, srf_stream_t stream)
+{
+    if (N < 0 || H <= 0 || W <= 0 || Ht <= 0 || Wt <= 0 || K <= 0 || Cout <= 0 || x_ld < K || y_ld < Cout || top_ld < Cout) return SRF_EINVAL;
+    if (N == 0) return SRF_OK;
+    if (!x || !W_packed || !y || !top) return SRF_EINVAL;
+    if ((K & 31) || (x_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)W_packed & 15)) return SRF_EUNSUPPORTED;
+    if (x_ld * 256 * 4 >= (1ll << 31) || (long long)N * Ht * Wt * top_ld >= (1ll << 31)) return SRF_EUNSUPPORTED;
+    const TopDown td = {top, top_ld, H, W, Ht, Wt};
+    return conv1x1_launch(x, (long long)N * H * W, K, x_ld, W_packed, Cout, scale, shift, relu, y, y_ld, nullptr, 0, (hipStream_t)stream,
+                          nullptr, &td);
 }
 
 // srf_conv1x1_nhwc_pooled: the same convolution on N images of HW pixels each, plus mean[n][co] = the mean over the
@@ -1140,6 +1199,10 @@ extern "C" int srf_conv_gemm_nhwc(const float *x, int N, int H, int W, int Cin, 
     a.colsum = nullptr;
     a.HW = 0;
     a.bpi = 0;
+    a.top = nullptr;
+    a.top_ld = 0;
+    a.mapH = a.mapW = a.topH = a.topW = 0;
+    a.sy = a.sx = 0.f;
     a.mblocks = srf_ceil_div(a.M, 128);
     long long blocks = ((a.mblocks + 7) / 8) * 8 * srf_ceil_div(Cout, 128);
     if (blocks >= (1ll << 31)) return SRF_EUNSUPPORTED;

@@ -84,9 +84,9 @@ def conv3x3(x, conv, bn=None, relu=False, out=None):
     return ops.wino3x3(x, _wino_weights(conv), conv.out_channels, scale, shift, relu, out=out)
 
 
-def conv1x1(x, conv, bn=None, relu=False, out=None, pool=False):
+def conv1x1(x, conv, bn=None, relu=False, out=None, pool=False, top=None):
     scale, shift = _affine_of(conv, bn)
-    return ops.conv1x1_nhwc(x, _gemm_weights(conv), conv.out_channels, scale, shift, relu, out=out, pool=pool)
+    return ops.conv1x1_nhwc(x, _gemm_weights(conv), conv.out_channels, scale, shift, relu, out=out, pool=pool, top=top)
 
 
 def wino_ok(conv, cin):
@@ -316,10 +316,14 @@ def _cm(cm, x, fn):
 
 
 def fpn_forward(fpn, inputs):
-    lats = [_cm(cm, nhwc_view(inputs[i]), conv1x1) for i, cm in enumerate(fpn.lateral_convs)]
-    for i in range(len(lats) - 1, 0, -1):
-        ops.nhwc_upsample_add(lats[i - 1], lats[i])
-    n = len(lats)
+    # laterals from the top level down: the top-down step (`laterals[i - 1] += upsample(laterals[i])`) is the epilogue of the
+    # lateral convolution of level i - 1 (srf_conv1x1_nhwc_topdown): no separate pass over the finer map
+    n = len(fpn.lateral_convs)
+    lats = [None] * n
+    for i in range(n - 1, -1, -1):
+        cm = fpn.lateral_convs[i]
+        bn = getattr(cm, cm.norm_name) if cm.with_norm else None
+        lats[i] = conv1x1(nhwc_view(inputs[i]), cm.conv, bn, cm.with_activation, top=lats[i + 1] if i + 1 < n else None)
     outs = [_cm(cm, lats[i], conv3x3) for i, cm in enumerate(list(fpn.fpn_convs)[:n])]
     for cm in list(fpn.fpn_convs)[n:]:   # add_extra_convs='on_output': stride-2 3x3 on the previous output
         src = outs[-1]

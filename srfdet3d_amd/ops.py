@@ -977,10 +977,11 @@ def pack_conv1x1_nhwc_weights(weight):
     return packed
 
 
-def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None, pool=False):
+def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None, pool=False, top=None):
     """1x1 convolution of the NHWC slice x (N, H, W, K) + per-channel scale / shift + ReLU into `out` ((N, H, W, Cout) slice
     of an NHWC buffer; new contiguous tensor when None).  pool=True: returns (out, mean (N, Cout) over the pixels of each
-    image) from the same pass (`srf_conv1x1_nhwc_pooled`)."""
+    image) from the same pass (`srf_conv1x1_nhwc_pooled`).  top: an (N, Ht, Wt, Cout) NHWC slice whose nearest-neighbour
+    upsampling to (H, W) is added to the result in the epilogue (`srf_conv1x1_nhwc_topdown`: the FPN top-down step)."""
     x_ld = nhwc_ld(x)
     N, H, W, K = x.shape
     if out is None:
@@ -995,7 +996,12 @@ def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out
     sc = None if scale is None else _ptr(_dev(scale, "scale", torch.float32))
     sh = None if shift is None else _ptr(_dev(shift, "shift", torch.float32))
     mean = None
-    if pool:
+    if top is not None:
+        if pool or top.dim() != 4 or top.shape[0] != N or top.shape[3] != Cout:
+            raise ValueError("conv1x1_nhwc: top must be (N, Ht, Wt, Cout) and excludes pool")
+        check(L.srf_conv1x1_nhwc_topdown(_ptr(x), N, H, W, K, x_ld, _ptr(packed_weight), Cout, sc, sh, int(bool(relu)), _ptr(top),
+                                         top.shape[1], top.shape[2], nhwc_ld(top), _ptr(out), y_ld, _stream()), "conv1x1_nhwc_topdown")
+    elif pool:
         mean = _empty((N, Cout), torch.float32, x.device)
         nbytes = L.srf_conv1x1_nhwc_pooled_workspace_bytes(N, H * W, Cout)
         ws = _empty((max(nbytes, 4) // 4,), torch.float32, x.device)

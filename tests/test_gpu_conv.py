@@ -285,6 +285,27 @@ def test_winograd_half_block_kernel_gives_the_same_bits(monkeypatch, N, H, W, Ci
     assert (outs[0].cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("N,H,W,Ht,Wt,K,Cout", [(2, 12, 20, 6, 10, 64, 96), (3, 29, 50, 15, 25, 128, 256), (1, 7, 9, 4, 5, 32, 40),
+                                                   (6, 116, 200, 58, 100, 512, 256)])
+def test_conv1x1_topdown_equals_conv_then_upsample_add(N, H, W, Ht, Wt, K, Cout):
+    """The FPN top-down step as the epilogue of the lateral convolution adds the same two floats as the separate pass:
+    identical bits (odd sizes: nearest upsampling by size, floor(py Ht / H))."""
+    g = torch.Generator().manual_seed(H * W + K)
+    x = torch.randn(N, H, W, K, generator=g).to(DEV)
+    top = torch.randn(N, Ht, Wt, Cout, generator=g).to(DEV)
+    w = (torch.randn(Cout, K, generator=g) / K ** 0.5).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    pk = ops.pack_conv1x1_nhwc_weights(w)
+    for relu in (False, True):
+        want = ops.conv1x1_nhwc(x, pk, Cout, None, shift, relu)
+        ops.nhwc_upsample_add(want, top)
+        got = ops.conv1x1_nhwc(x, pk, Cout, None, shift, relu, top=top)
+        assert torch.equal(got, want)
+    ref = F.interpolate(top.permute(0, 3, 1, 2), size=(H, W), mode="nearest").permute(0, 2, 3, 1)
+    plain = ops.conv1x1_nhwc(x, pk, Cout, None, shift, False)
+    assert torch.equal(ops.conv1x1_nhwc(x, pk, Cout, None, shift, False, top=top), plain + ref)
+
+
 def test_vovnet_training_runs_the_frozen_prefix_on_the_inference_kernels(monkeypatch):
     """Config 4 trains with `frozen_stages=2, norm_eval=True` (configs/nus/srfdet_voxel_nusc_LC.py:44-54): stem, stage2 and
     stage3 carry no gradient.  With autograd recording they run on the channels-last inference kernels under no_grad; the
