@@ -83,6 +83,12 @@ __global__ __launch_bounds__(256) void srf_wino3x3_pack_k(const float *__restric
     P[t] = r;
 }
 
+typedef float wn_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ wn_f32x16 wn_zero16()
+{
+    return wn_f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+}
+
 // float4 arithmetic as two packed instructions each: hipcc packs only about half of the component-wise form (28 of the 64
 // transform operations of a chunk stayed scalar) and lowers a vector subtraction to four v_sub_f32
 typedef float wn_v2 __attribute__((ext_vector_type(2)));
@@ -292,11 +298,13 @@ __device__ __forceinline__ void srf_wino3x3_body(const WinoArgs &a, const unsign
 // merged pairs of groups and waited for the NEXT group's fragments right after issuing their reads.  The first pin holds
 // the group's MFMAs behind this point (they consume the pinned fragments), the second keeps them in front of the
 // region's end (it consumes their accumulators).
-#define WN_MFMA_GROUP(SET, G)                                                                   \
+// FIRST (literal 0 / 1): the first chunk starts every accumulator chain from the inline constant 0 (srcC of the MFMA), so
+// the 256 accumulator registers are never zero-filled (256 v_accvgpr_write per workgroup before)
+#define WN_MFMA_GROUP(SET, G, FIRST)                                                            \
     do {                                                                                        \
         f32x4 pa0_ = fa[SET][0], pa1_ = fa[SET][1], pb0_ = fb[SET][0], pb1_ = fb[SET][1];       \
         asm volatile("" : "+v"(pa0_), "+v"(pa1_), "+v"(pb0_), "+v"(pb1_));                      \
-        f32x16 c0_ = acc[(G) * 2], c1_ = acc[(G) * 2 + 1];                                      \
+        f32x16 c0_ = (FIRST) ? wn_zero16() : acc[(G) * 2], c1_ = (FIRST) ? wn_zero16() : acc[(G) * 2 + 1]; \
         if (!(DBG & 4)) {                                                                       \
             WN_MFMA4(c0_, pa0_, pb0_);                                                          \
             WN_MFMA4(c1_, pa1_, pb1_);                                                          \
@@ -305,22 +313,18 @@ __device__ __forceinline__ void srf_wino3x3_body(const WinoArgs &a, const unsign
         acc[(G) * 2] = c0_;                                                                     \
         acc[(G) * 2 + 1] = c1_;                                                                 \
     } while (0)
-#define WN_MFMA_HALF(SET, G, E)                                                                 \
+#define WN_MFMA_HALF(SET, G, E, FIRST)                                                          \
     do {                                                                                        \
         f32x4 pa_ = fa[SET][E], pb_ = fb[SET][E];                                               \
         asm volatile("" : "+v"(pa_), "+v"(pb_));                                                \
-        f32x16 c_ = acc[(G) * 2 + (E)];                                                         \
+        f32x16 c_ = (FIRST) ? wn_zero16() : acc[(G) * 2 + (E)];                                 \
         if (!(DBG & 4)) WN_MFMA4(c_, pa_, pb_);                                                 \
         asm volatile("" : "+a"(c_));                                                            \
         acc[(G) * 2 + (E)] = c_;                                                                \
     } while (0)
 #define WN_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-    f32x16 acc[16];
-#pragma unroll
-    for (int f = 0; f < 16; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+    f32x16 acc[16];   // written by the first chunk (FIRST = 1), never zero-filled
     f32x4 fa[2][2], fb[2][2];  // fragments of two groups (2 frequencies each): one in use, one in flight
     float4 t0_0, t0_1, t0_2, t0_3, t1_0, t1_1, t1_2, t1_3;
     const int nchunk = a.nchunk;
@@ -354,94 +358,101 @@ __device__ __forceinline__ void srf_wino3x3_body(const WinoArgs &a, const unsign
     // multiplies); writes the patch of chunk c + 2 (registers -> RAW) and loads the one of chunk c + 3; finishes the
     // transform of chunk c + 1 (horizontal stage -> V) and stages its weights (-> U), loads the weights of chunk c + 2;
     // behind the barrier, under the last group: chunk c + 2's patch RAW -> registers -> vertical stage.
+    // one chunk of the main loop (FIRST: see WN_MFMA_GROUP)
+#define WN_CHUNK_FULL(FIRST, c)                                                                                       \
+    do {                                                                                                              \
+        const int rbuf = (c & 1) * 2048, wbuf = 2048 - rbuf;                                                          \
+        const int rawb = (c & 1) * WN_RAW;                                                                            \
+        const int c2 = c + 2 < nchunk ? c + 2 : last, c3 = c + 3 < nchunk ? c + 3 : last;                             \
+        WN_READ_GROUP(1, 1, rbuf);                                                                                    \
+        WN_FENCE();                                                                                                   \
+        WN_STORE_RAW(rawb);                                                                                           \
+        WN_LOAD_RAW(c3);                                                                                              \
+        WN_MFMA_GROUP(0, 0, FIRST);                                                                                   \
+        WN_FENCE();                                                                                                   \
+        WN_READ_GROUP(0, 2, rbuf);                                                                                    \
+        WN_FENCE();                                                                                                   \
+        WN_STAGE2(t0, 2 * hh, wbuf);                                                                                  \
+        WN_MFMA_GROUP(1, 1, FIRST);                                                                                   \
+        WN_FENCE();                                                                                                   \
+        WN_READ_GROUP(1, 3, rbuf);                                                                                    \
+        WN_FENCE();                                                                                                   \
+        WN_STORE_U_LO(wbuf);                                                                                          \
+        WN_LOAD_U_LO(c2);                                                                                             \
+        WN_MFMA_GROUP(0, 2, FIRST);                                                                                   \
+        WN_FENCE();                                                                                                   \
+        WN_READ_GROUP(0, 4, rbuf);                                                                                    \
+        WN_FENCE();                                                                                                   \
+        WN_STAGE2(t1, 2 * hh + 1, wbuf);                                                                              \
+        WN_MFMA_GROUP(1, 3, FIRST);                                                                                   \
+        WN_FENCE();                                                                                                   \
+        WN_READ_GROUP(1, 5, rbuf);                                                                                    \
+        WN_FENCE();                                                                                                   \
+        WN_STORE_U_HI(wbuf);                                                                                          \
+        WN_LOAD_U_HI(c2);                                                                                             \
+        WN_MFMA_GROUP(0, 4, FIRST);                                                                                   \
+        WN_FENCE();                                                                                                   \
+        WN_READ_GROUP(0, 6, rbuf);                                                                                    \
+        WN_FENCE();                                                                                                   \
+        WN_MFMA_GROUP(1, 5, FIRST);                                                                                   \
+        WN_FENCE();                                                                                                   \
+        WN_READ_GROUP(1, 7, rbuf);                                                                                    \
+        WN_FENCE();                                                                                                   \
+        WN_MFMA_GROUP(0, 6, FIRST);                                                                                   \
+        WN_FENCE();                                                                                                   \
+        __syncthreads();                                                                                              \
+        WN_READ_GROUP(0, 0, wbuf);                                                                                    \
+        WN_READ_RAW(rawb);                                                                                            \
+        WN_FENCE();                                                                                                   \
+        WN_MFMA_HALF(1, 7, 0, FIRST);                                                                                 \
+        WN_FENCE();                                                                                                   \
+        WN_STAGE1();                                                                                                  \
+        WN_MFMA_HALF(1, 7, 1, FIRST);                                                                                 \
+        WN_FENCE();                                                                                                   \
+    } while (0)
+#define WN_CHUNK_HALF(FIRST, c)                                                                                       \
+    do {                                                                                                              \
+            const int rbuf = (c & 1) * 2048, wbuf = 2048 - rbuf;                                                      \
+            const int rawb = (c & 1) * WN_RAW;                                                                        \
+            const int c2 = c + 2 < nchunk ? c + 2 : last, c3 = c + 3 < nchunk ? c + 3 : last;                         \
+            WN_READ_GROUP(1, 1, rbuf);                                                                                \
+            WN_FENCE();                                                                                               \
+            WN_STORE_RAW(rawb);                                                                                       \
+            WN_LOAD_RAW(c3);                                                                                          \
+            WN_MFMA_GROUP(0, 0, FIRST);                                                                               \
+            WN_FENCE();                                                                                               \
+            WN_READ_GROUP(0, 2, rbuf);                                                                                \
+            WN_FENCE();                                                                                               \
+            WN_STAGE2(t0, 2 * hh, wbuf);                                                                              \
+            WN_STORE_U_LO(wbuf);                                                                                      \
+            WN_LOAD_U_LO(c2);                                                                                         \
+            WN_MFMA_GROUP(1, 1, FIRST);                                                                               \
+            WN_FENCE();                                                                                               \
+            WN_READ_GROUP(1, 3, rbuf);                                                                                \
+            WN_FENCE();                                                                                               \
+            WN_STAGE2(t1, 2 * hh + 1, wbuf);                                                                          \
+            WN_STORE_U_HI(wbuf);                                                                                      \
+            WN_LOAD_U_HI(c2);                                                                                         \
+            WN_MFMA_GROUP(0, 2, FIRST);                                                                               \
+            WN_FENCE();                                                                                               \
+            __syncthreads();                                                                                          \
+            WN_READ_GROUP(0, 0, wbuf);                                                                                \
+            WN_READ_RAW(rawb);                                                                                        \
+            WN_FENCE();                                                                                               \
+            WN_MFMA_HALF(1, 3, 0, FIRST);                                                                             \
+            WN_FENCE();                                                                                               \
+            WN_STAGE1();                                                                                              \
+            WN_MFMA_HALF(1, 3, 1, FIRST);                                                                             \
+            WN_FENCE();                                                                                               \
+    } while (0)
     if (HALFB) {
         // four groups (8 frequencies) per chunk and wave: the schedule of the full loop with the groups 4 .. 7 taken out
-        for (int c = 0; c < nchunk; ++c) {
-            const int rbuf = (c & 1) * 2048, wbuf = 2048 - rbuf;
-            const int rawb = (c & 1) * WN_RAW;
-            const int c2 = c + 2 < nchunk ? c + 2 : last, c3 = c + 3 < nchunk ? c + 3 : last;
-            WN_READ_GROUP(1, 1, rbuf);
-            WN_FENCE();
-            WN_STORE_RAW(rawb);
-            WN_LOAD_RAW(c3);
-            WN_MFMA_GROUP(0, 0);
-            WN_FENCE();
-            WN_READ_GROUP(0, 2, rbuf);
-            WN_FENCE();
-            WN_STAGE2(t0, 2 * hh, wbuf);
-            WN_STORE_U_LO(wbuf);
-            WN_LOAD_U_LO(c2);
-            WN_MFMA_GROUP(1, 1);
-            WN_FENCE();
-            WN_READ_GROUP(1, 3, rbuf);
-            WN_FENCE();
-            WN_STAGE2(t1, 2 * hh + 1, wbuf);
-            WN_STORE_U_HI(wbuf);
-            WN_LOAD_U_HI(c2);
-            WN_MFMA_GROUP(0, 2);
-            WN_FENCE();
-            __syncthreads();
-            WN_READ_GROUP(0, 0, wbuf);
-            WN_READ_RAW(rawb);
-            WN_FENCE();
-            WN_MFMA_HALF(1, 3, 0);
-            WN_FENCE();
-            WN_STAGE1();
-            WN_MFMA_HALF(1, 3, 1);
-            WN_FENCE();
-        }
+        WN_CHUNK_HALF(1, 0);
+        for (int c = 1; c < nchunk; ++c) WN_CHUNK_HALF(0, c);
     } else {
-    for (int c = 0; c < nchunk; ++c) {
-        const int rbuf = (c & 1) * 2048, wbuf = 2048 - rbuf;
-        const int rawb = (c & 1) * WN_RAW;
-        const int c2 = c + 2 < nchunk ? c + 2 : last, c3 = c + 3 < nchunk ? c + 3 : last;
-        WN_READ_GROUP(1, 1, rbuf);
-        WN_FENCE();
-        WN_STORE_RAW(rawb);
-        WN_LOAD_RAW(c3);
-        WN_MFMA_GROUP(0, 0);
-        WN_FENCE();
-        WN_READ_GROUP(0, 2, rbuf);
-        WN_FENCE();
-        WN_STAGE2(t0, 2 * hh, wbuf);
-        WN_MFMA_GROUP(1, 1);
-        WN_FENCE();
-        WN_READ_GROUP(1, 3, rbuf);
-        WN_FENCE();
-        WN_STORE_U_LO(wbuf);
-        WN_LOAD_U_LO(c2);
-        WN_MFMA_GROUP(0, 2);
-        WN_FENCE();
-        WN_READ_GROUP(0, 4, rbuf);
-        WN_FENCE();
-        WN_STAGE2(t1, 2 * hh + 1, wbuf);
-        WN_MFMA_GROUP(1, 3);
-        WN_FENCE();
-        WN_READ_GROUP(1, 5, rbuf);
-        WN_FENCE();
-        WN_STORE_U_HI(wbuf);
-        WN_LOAD_U_HI(c2);
-        WN_MFMA_GROUP(0, 4);
-        WN_FENCE();
-        WN_READ_GROUP(0, 6, rbuf);
-        WN_FENCE();
-        WN_MFMA_GROUP(1, 5);
-        WN_FENCE();
-        WN_READ_GROUP(1, 7, rbuf);
-        WN_FENCE();
-        WN_MFMA_GROUP(0, 6);
-        WN_FENCE();
-        __syncthreads();
-        WN_READ_GROUP(0, 0, wbuf);
-        WN_READ_RAW(rawb);
-        WN_FENCE();
-        WN_MFMA_HALF(1, 7, 0);  // 4 MFMAs cover the latency of the 12 patch reads the vertical stage waits for
-        WN_FENCE();
-        WN_STAGE1();
-        WN_MFMA_HALF(1, 7, 1);
-        WN_FENCE();
-    }
-
+        // 4 MFMAs of group 7 cover the latency of the 12 patch reads the vertical stage waits for
+        WN_CHUNK_FULL(1, 0);
+        for (int c = 1; c < nchunk; ++c) WN_CHUNK_FULL(0, c);
     }
 
     // ---- epilogue: A^T m A, affine, ReLU, store ----
