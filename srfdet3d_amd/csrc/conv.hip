@@ -49,7 +49,7 @@ struct WinoArgs {
     long long x_ld, y_ld;
     int N, H, W, Cout;
     int rowBlocks, colBlocks, coutBlocks, nchunk, nspatial, relu;
-    int cb0, ncb;       // channel blocks of this launch: cb0 .. cb0 + ncb - 1
+    int cb0, ncb;       // channel blocks of this launch: cb0 .. cb0 + ncb - 1 (half-block form: in units of 32 channels)
     int nfull;          // srf_wino3x3_mixed_k: workgroups of the full form (the half-block ones follow)
     long long *stamps;  // developer timing hook (srf_dev_set_stamp_buffer): 4 s_memtime values per workgroup, else NULL
 };
@@ -156,7 +156,8 @@ __device__ __forceinline__ void srf_wino3x3_body(const WinoArgs &a, const unsign
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // workgroups b and b + 8 share an XCD (round-robin dispatch): the cout blocks of one spatial block sit on one L2
     const int xcd = bid & 7, jq = bid >> 3;
-    const int cb = a.cb0 + jq % a.ncb;
+    const int cbi = a.cb0 + jq % a.ncb;               // HALFB: index of a 32-channel half of a block
+    const int cb = HALFB ? cbi >> 1 : cbi;
     const int sp = (jq / a.ncb) * 8 + xcd;
     if (sp >= a.nspatial) return;
     const int per_img = a.rowBlocks * a.colBlocks;
@@ -283,7 +284,7 @@ __device__ __forceinline__ void srf_wino3x3_body(const WinoArgs &a, const unsign
     } while (0)
 
     // ---- MFMA role: tile half th, channel half chh (HALFB: frequency half fh = wave >> 1, channels 0 .. 31 of the block) ----
-    const int th = wave & 1, chh = HALFB ? 0 : wave >> 1, fh = HALFB ? wave >> 1 : 0;
+    const int th = wave & 1, chh = HALFB ? (cbi & 1) : wave >> 1, fh = HALFB ? wave >> 1 : 0;
     const int li = lane & 31, lh = lane >> 5;
     const int a_off = lh * 64 + th * 32 + li + fh * 1024;          // + f * 128 (+ buffer)
     const int b_off = 4096 + lh * 64 + chh * 32 + li + fh * 1024;  // + f * 128 (+ buffer)
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(256, 1) void srf_wino3x3_mixed_k(WinoArgs a)
         srf_wino3x3_body<0, TWL, false>(a, blockIdx.x);
     } else {
         WinoArgs h = a;
-        h.cb0 = a.coutBlocks - 1;
+        h.cb0 = 2 * (a.coutBlocks - 1);
         h.ncb = 1;
         srf_wino3x3_body<0, TWL, true>(h, blockIdx.x - (unsigned)a.nfull);
     }
@@ -585,6 +586,11 @@ struct GemmArgs {
     float *colsum;
     long long HW;
     int bpi;
+    // row range of this launch (the mixed launch gives the head of the rows to 128 x 128 tiles and the tail to 64 x 64 ones):
+    // row0 = first row (flat tiling) / first row inside every image (per-image tiling); the column sums of block lb of image n
+    // go to slot n * slots + slot0 + lb
+    long long row0;
+    int slot0, slots;
     // FPN top-down step fused into the lateral convolution: y += top[n][floor(py sy)][floor(px sx)][co] (nearest upsampling by
     // size, as F.interpolate / srf_nhwc_upsample_add); rows are the pixels (n, py, px) of an (N, mapH, mapW) map
     const float *top;
@@ -614,8 +620,8 @@ __global__ __launch_bounds__(256) void srf_conv1x1_nhwc_pack_k(const float *__re
 //           workgroups per CU: the waves of different workgroups fill each other's barrier / staging gaps (an f32 MFMA
 //           overlaps with another wave's vector and LDS instructions, not with its own wave's);
 //   <4, 4>: 256 x 256, 16 accumulators per wave, one workgroup per CU (kept for A/B timing: SRF_GEMM_BIG=1).
-template <int RM, int RN, int WPE, bool CONV>
-__global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
+template <int RM, int RN, bool CONV>
+__device__ __forceinline__ void srf_gemm_body(const GemmArgs &a, const unsigned bid)
 {
     constexpr int TM = 64 * RM, TN = 64 * RN;
     constexpr int ASZ = 8 * TM;          // float4 per A stage
@@ -625,7 +631,7 @@ __global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
     constexpr int NCS = 256 / TN;        // channel sub-blocks per packed block
     extern __shared__ __attribute__((aligned(16))) f32x4 s_g[];  // A[ASZ] | B[BSZ]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const int xcd = bid & 7, jq = bid >> 3;
     // column tiles that hold real channels only: a launch whose every second workgroup returned at once (Cout = 128 in a
     // 256-channel packed block) ran at half occupancy -- the slots of the no-op workgroups are not refilled fast enough
     const int nct = (a.Cout + TN - 1) / TN;
@@ -634,11 +640,13 @@ __global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
     const long long mb = (long long)(jq / nct) * 8 + xcd;
     if (mb >= a.mblocks) return;
     if ((cb * 256 + cs * TN) >= a.Cout) return;
-    long long p0 = mb * TM, rows_blk = a.M - p0;
+    long long p0 = (CONV ? 0 : a.row0) + mb * TM, rows_blk = a.M - p0;
+    long long slot = mb;
     if (!CONV && a.bpi > 0) {
         const long long n = mb / a.bpi, lb = mb - n * a.bpi;
-        p0 = n * a.HW + lb * TM;
-        rows_blk = a.HW - lb * TM;
+        p0 = n * a.HW + a.row0 + lb * TM;
+        rows_blk = a.HW - a.row0 - lb * TM;
+        slot = n * a.slots + a.slot0 + lb;
     }
 
     __amdgpu_buffer_rsrc_t xrsrc;
@@ -839,9 +847,25 @@ __global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
 #pragma unroll
             for (int w = 0; w < WM; ++w) s += red[w * TN + tid];
             const int co = cb * 256 + cs * TN + tid;
-            if (co < a.Cout) a.colsum[mb * a.Cout + co] = s;
+            if (co < a.Cout) a.colsum[slot * a.Cout + co] = s;
         }
     }
+}
+
+template <int RM, int RN, int WPE, bool CONV>
+__global__ __launch_bounds__(256, WPE) void srf_conv1x1_nhwc_k(GemmArgs a)
+{
+    srf_gemm_body<RM, RN, CONV>(a, blockIdx.x);
+}
+
+// One launch, two tile sizes: the first `nbig` workgroups run 128 x 128 tiles over the head of the rows (whole rounds of three
+// workgroups per CU), the rest cover the tail of the rows with 64 x 64 tiles.  A last, partly filled round of 128 x 128 tiles
+// costs the full latency of a tile (~100 us at K = 1728: 2.125 rounds took 812 us against 720 us for 2.0); the small tiles
+// start as the big ones retire and are a quarter as long.  Every output is the same k-ordered fma chain in either tile.
+__global__ __launch_bounds__(256, 3) void srf_conv1x1_nhwc_mixed_k(GemmArgs big, GemmArgs tail, unsigned nbig)
+{
+    if (blockIdx.x < nbig) srf_gemm_body<2, 2, false>(big, blockIdx.x);
+    else srf_gemm_body<1, 1, false>(tail, blockIdx.x - nbig);
 }
 
 static long long *g_wino_stamps = nullptr;
@@ -955,17 +979,26 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
     const int rem = Cout - (a.coutBlocks - 1) * 64;
     const char *fh_env = getenv("SRF_WINO_HALF");   // read per call: the tests flip it
     const int force_half = fh_env ? atoi(fh_env) : -1;
-    bool split = false;
+    bool split = false, all_half = false;
+    int cus = 0;
+    SRF_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus <= 0) cus = 256;
+    double rounds_best = (double)srf_ceil_div(sp8 * a.coutBlocks, cus);   // rounds of full workgroups
     if (rem <= 32) {
-        int cus = 0;
-        SRF_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        if (cus <= 0) cus = 256;
-        const double now = (double)srf_ceil_div(sp8 * a.coutBlocks, cus);
         // one mixed launch: the half workgroups (0.62 of a full one each) fill the tail of the full ones
         const double work = (double)(sp8 * (a.coutBlocks - 1)) + 0.62 * (double)sp8;
         const double then = a.coutBlocks > 1 ? std::max(work / cus + 0.3, (double)srf_ceil_div(sp8 * (a.coutBlocks - 1), cus))
                                              : 0.62 * (double)srf_ceil_div(sp8, cus);
-        split = force_half < 0 ? then < now : force_half != 0;
+        split = force_half < 0 ? then < rounds_best : force_half == 1;
+        if (split) rounds_best = then;
+    }
+    // a small map (VoVNet stage 5: 36 spatial blocks x 3.5 channel blocks on 256 CUs) leaves CUs idle for the length of a full
+    // workgroup: every block as two half-block workgroups (32 channels each, the waves split the frequencies) is one shorter round
+    const int nhb = srf_ceil_div(Cout, 32);
+    {
+        const double halves = 0.62 * (double)srf_ceil_div(nspatial * nhb, cus);
+        all_half = force_half < 0 ? halves < rounds_best - 0.05 : force_half == 2;
+        if (all_half) split = false;
     }
 #define WN_LAUNCH(HB, GRID)                                                                                                    \
     do {                                                                                                                       \
@@ -974,7 +1007,7 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
         else hipLaunchKernelGGL((srf_wino3x3_k<0, 1, HB>), dim3((unsigned)(GRID)), blk, WN_LDS_BYTES, (hipStream_t)stream, a);               \
     } while (0)
     a.nfull = 0;
-    if (split && a.coutBlocks > 1) {
+    if (split && !all_half && a.coutBlocks > 1) {
         a.cb0 = 0;
         a.ncb = a.coutBlocks - 1;
         a.nfull = (int)(sp8 * a.ncb);
@@ -983,9 +1016,13 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
         else if (twl == 2) hipLaunchKernelGGL((srf_wino3x3_mixed_k<2>), gm, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((srf_wino3x3_mixed_k<1>), gm, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
     } else if (split) {
-        a.cb0 = a.coutBlocks - 1;
+        a.cb0 = 2 * (a.coutBlocks - 1);
         a.ncb = 1;
         WN_LAUNCH(true, sp8);
+    } else if (all_half) {
+        a.cb0 = 0;
+        a.ncb = nhb;
+        WN_LAUNCH(true, sp8 * nhb);
     } else {
         WN_LAUNCH(false, blocks);
     }
@@ -1064,13 +1101,56 @@ static int conv1x1_launch(const float *x, long long M, int K, long long x_ld, co
     // SRF_GEMM_SMALL overrides the threshold (developer A/B knob)
     static const int small_thr = getenv("SRF_GEMM_SMALL") ? atoi(getenv("SRF_GEMM_SMALL")) : 640;
     if (srf_ceil_div(M, 128) * srf_ceil_div(Cout, 128) < small_thr) TM = 64, ncs = 4;  // small problem: 64 x 64 tiles
+    a.row0 = 0;
+    a.slot0 = 0;
+    const long long nimg = colsum ? M / HW : 1;
     if (colsum) {
         a.bpi = (int)srf_ceil_div(HW, TM);
-        a.mblocks = (M / HW) * a.bpi;
+        a.slots = a.bpi;
+        a.mblocks = nimg * a.bpi;
         if (bpi_out) *bpi_out = a.bpi;
     } else {
         a.bpi = 0;
+        a.slots = 0;
         a.mblocks = srf_ceil_div(M, TM);
+    }
+    // tail of the last, partly filled round of 128 x 128 tiles as 64 x 64 tiles (SRF_GEMM_TAIL=0 turns it off; developer A/B knob)
+    const char *tail_env = getenv("SRF_GEMM_TAIL");   // read per call: the tests flip it
+    const int tail_on = tail_env ? atoi(tail_env) : 1;
+    static const double tail_frac = getenv("SRF_GEMM_TAIL_FRAC") ? atof(getenv("SRF_GEMM_TAIL_FRAC")) : 0.45;
+    if (TM == 128 && tail_on) {
+        int cus = 0;
+        SRF_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (cus <= 0) cus = 256;
+        const long long slots_cu = 3ll * cus, nct = srf_ceil_div(Cout, 128);
+        const long long tiles = a.mblocks * nct, full = tiles / slots_cu;
+        const double frac = (double)(tiles - full * slots_cu) / (double)slots_cu;
+        if (full >= 1 && frac > 0.0 && frac <= tail_frac) {
+            // row blocks (per image) the big tiles keep: whole rounds, a multiple of 8 blocks in total where that is possible
+            const long long keep = (full * slots_cu) / (nct * nimg);   // per image
+            GemmArgs t = a;
+            GemmArgs b = a;
+            b.mblocks = keep * nimg;
+            t.row0 = keep * 128;
+            if (colsum) {
+                b.bpi = (int)keep;
+                t.bpi = (int)srf_ceil_div(HW - t.row0, 64);
+                t.slot0 = (int)keep;
+                b.slots = t.slots = b.bpi + t.bpi;
+                t.mblocks = nimg * t.bpi;
+                if (bpi_out) *bpi_out = b.slots;
+            } else {
+                t.mblocks = srf_ceil_div(M - t.row0, 64);
+            }
+            if (keep >= 1 && t.mblocks >= 1) {
+                const long long gb = ((b.mblocks + 7) / 8) * 8 * nct, gt = ((t.mblocks + 7) / 8) * 8 * srf_ceil_div(Cout, 64);
+                if (gb + gt >= (1ll << 31)) return SRF_EUNSUPPORTED;
+                hipLaunchKernelGGL(srf_conv1x1_nhwc_mixed_k, dim3((unsigned)(gb + gt)), dim3(256), LDS_STD, stream, b, t, (unsigned)gb);
+                SRF_LAUNCH_CHECK();
+                return SRF_OK;
+            }
+            if (bpi_out && colsum) *bpi_out = a.bpi;
+        }
     }
     const long long blocks = ((a.mblocks + 7) / 8) * 8 * srf_ceil_div(Cout, 256 / ncs);
     if (blocks >= (1ll << 31)) return SRF_EUNSUPPORTED;
@@ -1208,6 +1288,8 @@ extern "C" int srf_conv_gemm_nhwc(const float *x, int N, int H, int W, int Cin, 
     a.cin_chunks = Cin / 32;
     a.x_bytes = x_bytes;
     a.colsum = nullptr;
+    a.row0 = 0;
+    a.slot0 = a.slots = 0;
     a.HW = 0;
     a.bpi = 0;
     a.top = nullptr;

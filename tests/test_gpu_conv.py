@@ -273,7 +273,7 @@ def test_winograd_half_block_kernel_gives_the_same_bits(monkeypatch, N, H, W, Ci
     shift = torch.randn(Cout, generator=g).to(DEV)
     pk = ops.pack_wino3x3_weights(w)
     outs = []
-    for force in ("0", "1"):
+    for force in ("0", "1", "2"):   # one-launch form / last block as half blocks / every block as two half blocks
         monkeypatch.setenv("SRF_WINO_HALF", force)
         for twl in ("1", "2", "3"):
             monkeypatch.setenv("SRF_WINO_TWL", twl)   # 8 x 8, 16 x 4 and 32 x 2 tile blocks
@@ -283,6 +283,38 @@ def test_winograd_half_block_kernel_gives_the_same_bits(monkeypatch, N, H, W, Ci
     ref = F.conv2d(x.permute(0, 3, 1, 2).cpu().double(), w.cpu().double(), padding=1)
     ref = (ref * scale.cpu().double().view(1, -1, 1, 1) + shift.cpu().double().view(1, -1, 1, 1)).relu().permute(0, 2, 3, 1)
     assert (outs[0].cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("N,HW,K,Cout,mode", [(1, 128 * 404, 64, 256, "flat"), (2, 128 * 200 + 40, 64, 256, "pool"), (3, 128 * 86 + 1, 32, 384, "pool"),
+                                              (1, 128 * 260 + 77, 96, 400, "flat"), (2, 100 * 257, 32, 256, "top")])
+def test_conv1x1_mixed_tiles_give_the_same_bits(monkeypatch, N, HW, K, Cout, mode):
+    """A partly filled last round of 128 x 128 tiles runs as 64 x 64 tiles in the same launch (srf_conv1x1_nhwc_mixed_k): every
+    output is the same k-ordered fma chain, so the map is bit-identical to the one-size launch; the pooled means add the
+    blocks of an image in another grouping and agree to rounding."""
+    g = torch.Generator().manual_seed(HW + Cout)
+    x = torch.randn(N, 1, HW, K, generator=g).to(DEV)
+    w = (torch.randn(Cout, K, generator=g) / K ** 0.5).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    pk = ops.pack_conv1x1_nhwc_weights(w)
+    outs = []
+    for tail in ("0", "1"):
+        monkeypatch.setenv("SRF_GEMM_TAIL", tail)
+        if mode == "pool":
+            outs.append(ops.conv1x1_nhwc(x, pk, Cout, None, shift, True, pool=True))
+        elif mode == "top":
+            xm = x.view(N, 100, 257, K)
+            top = torch.randn(N, 50, 129, Cout, generator=torch.Generator().manual_seed(5)).to(DEV)
+            outs.append((ops.conv1x1_nhwc(xm, pk, Cout, None, shift, False, top=top),))
+        else:
+            outs.append((ops.conv1x1_nhwc(x, pk, Cout, None, shift, True),))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if mode == "pool":
+        m_ref = outs[0][0].double().mean(dim=(1, 2))
+        for o in outs:
+            assert (o[1].double() - m_ref).abs().max().item() <= 1e-5 * m_ref.abs().max().item()
+    if mode != "top":
+        ref = torch.relu(torch.mm(x.view(N * HW, K), w.t()) + shift).view(N, 1, HW, Cout)
+        assert (outs[1][0] - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("N,H,W,Ht,Wt,K,Cout", [(2, 12, 20, 6, 10, 64, 96), (3, 29, 50, 15, 25, 128, 256), (1, 7, 9, 4, 5, 32, 40),
