@@ -1117,14 +1117,17 @@ static int conv1x1_launch(const float *x, long long M, int K, long long x_ld, co
     // tail of the last, partly filled round of 128 x 128 tiles as 64 x 64 tiles (SRF_GEMM_TAIL=0 turns it off; developer A/B knob)
     const char *tail_env = getenv("SRF_GEMM_TAIL");   // read per call: the tests flip it
     const int tail_on = tail_env ? atoi(tail_env) : 1;
-    static const double tail_frac = getenv("SRF_GEMM_TAIL_FRAC") ? atof(getenv("SRF_GEMM_TAIL_FRAC")) : 0.45;
+    static const double tail_frac = getenv("SRF_GEMM_TAIL_FRAC") ? atof(getenv("SRF_GEMM_TAIL_FRAC")) : 1.0;
+    static const int tail_extra = getenv("SRF_GEMM_TAIL_EXTRA") ? atoi(getenv("SRF_GEMM_TAIL_EXTRA")) : 0;
     if (TM == 128 && tail_on) {
         int cus = 0;
         SRF_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (cus <= 0) cus = 256;
         const long long slots_cu = 3ll * cus, nct = srf_ceil_div(Cout, 128);
-        const long long tiles = a.mblocks * nct, full = tiles / slots_cu;
+        const long long tiles = a.mblocks * nct;
+        long long full = tiles / slots_cu;
         const double frac = (double)(tiles - full * slots_cu) / (double)slots_cu;
+        if (full > tail_extra) full -= tail_extra;
         if (full >= 1 && frac > 0.0 && frac <= tail_frac) {
             // row blocks (per image) the big tiles keep: whole rounds, a multiple of 8 blocks in total where that is possible
             const long long keep = (full * slots_cu) / (nct * nimg);   // per image
