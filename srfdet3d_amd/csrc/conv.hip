@@ -992,14 +992,13 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
         split = force_half < 0 ? then < rounds_best : force_half == 1;
         if (split) rounds_best = then;
     }
-    // a small map (VoVNet stage 5: 36 spatial blocks x 3.5 channel blocks on 256 CUs) leaves CUs idle for the length of a full
-    // workgroup: every block as two half-block workgroups (32 channels each, the waves split the frequencies) is one shorter round
+    // Every block as two half-block workgroups (32 channels each, the waves split the frequencies): measured, not faster
+    // anywhere -- a launch of half blocks only runs at ~0.7 of the full form's rate (the input transform is done twice), so a
+    // shorter last round does not pay it back (SECOND 128 -> 128 @ 184 x 184: 96 -> 104 us).  Kept behind SRF_WINO_HALF=2: the
+    // parity test runs it against the full form.
     const int nhb = srf_ceil_div(Cout, 32);
-    {
-        const double halves = 0.62 * (double)srf_ceil_div(nspatial * nhb, cus);
-        all_half = force_half < 0 ? halves < rounds_best - 0.05 : force_half == 2;
-        if (all_half) split = false;
-    }
+    all_half = force_half == 2;
+    if (all_half) split = false;
 #define WN_LAUNCH(HB, GRID)                                                                                                    \
     do {                                                                                                                       \
         if (twl == 3) hipLaunchKernelGGL((srf_wino3x3_k<0, 3, HB>), dim3((unsigned)(GRID)), blk, WN_LDS_BYTES, (hipStream_t)stream, a);      \

@@ -11,6 +11,8 @@ the C-ABI entry points only enqueue on the current stream, and workspaces come f
 import numpy as np
 import torch
 
+from . import nhwc
+
 
 def _l2i_host(img_metas):
     """(bs, n_cam, 4, 4) float32 lidar->image matrices of this call, or None (as heads._lidar2img lays them out)."""
@@ -141,6 +143,8 @@ class GraphedTail:
         static_img = None
         if img_feats is not None:
             static_img = list(img_feats) if img_static else [f.clone() for f in img_feats]
+            if isinstance(img_feats, nhwc.ConsumedLevels):
+                static_img = nhwc.ConsumedLevels(static_img)   # the head's img_convs already ran in the camera graph
         sm = _StaticMetas(img_metas, bev.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -195,14 +199,19 @@ class GraphedImageBranch:
         static_img = img.clone()
         side = self.stream
         side.wait_stream(torch.cuda.current_stream())
+        # the head's per-level `img_convs` join the camera graph (the head skips them on nhwc.ConsumedLevels): inside the
+        # capture the chains of the coarse levels become parallel branches of the graph
+        hook = getattr(getattr(m, "bbox_head", None), "img_level_consumer", None)
+        consumer = hook() if hook is not None and not safe else None
         with torch.cuda.stream(side), torch.no_grad(), _graph_safe_convs(safe):
             for _ in range(self.warmup):
-                ref = m.extract_img_feat(static_img, img_metas)
+                with nhwc.level_consumer(consumer):
+                    ref = m.extract_img_feat(static_img, img_metas)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ref = [r.clone() for r in ref]
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), _graph_safe_convs(safe), torch.cuda.graph(graph, stream=side):
+        with torch.no_grad(), _graph_safe_convs(safe), torch.cuda.graph(graph, stream=side), nhwc.level_consumer(consumer):
             feats = m.extract_img_feat(static_img, img_metas)
         torch.cuda.synchronize()
         _validate(graph, feats, ref, "image-branch graph")

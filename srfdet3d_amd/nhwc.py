@@ -19,6 +19,8 @@ looks at shapes keeps working and the RoI gather finds its channels-last operand
 Taken only for fp32 CUDA inference with BatchNorm in eval mode (`dense.fusable` / `dense._foldable`); anything else goes
 through the modules as written.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -315,19 +317,83 @@ def _cm(cm, x, fn):
     return fn(x, cm.conv, bn, cm.with_activation)
 
 
+class ConsumedLevels(list):
+    """Pyramid levels a per-level consumer (the head's `img_convs`) has already been applied to (see `level_consumer`)."""
+
+
+_LEVEL_CONSUMER = None
+
+
+class level_consumer:
+    """Within this context the next FPN forward on the channels-last path hands every finished level to `fn(i, x_nhwc) ->
+    y_nhwc` as part of that level's chain (lateral -> output convolution -> consumer).  graphs.GraphedImageBranch uses it to
+    run the head's `img_convs` (srfdet_head.py:404-416) inside the camera graph, where the chains of the coarse levels are
+    captured as parallel branches: their few-workgroup kernels (29 x 50 and 58 x 100 maps cover 65 % / 80 % of the CUs) run
+    beside the lateral GEMMs and the finest level's kernels instead of after them."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __enter__(self):
+        global _LEVEL_CONSUMER
+        _LEVEL_CONSUMER = self.fn
+        return self
+
+    def __exit__(self, *exc):
+        global _LEVEL_CONSUMER
+        _LEVEL_CONSUMER = None
+        return False
+
+
+_CHAIN_STREAMS = []
+
+
+def _chain_stream(i):
+    while len(_CHAIN_STREAMS) <= i:
+        _CHAIN_STREAMS.append(torch.cuda.Stream())
+    return _CHAIN_STREAMS[i]
+
+
 def fpn_forward(fpn, inputs):
     # laterals from the top level down: the top-down step (`laterals[i - 1] += upsample(laterals[i])`) is the epilogue of the
     # lateral convolution of level i - 1 (srf_conv1x1_nhwc_topdown): no separate pass over the finer map
+    global _LEVEL_CONSUMER
     n = len(fpn.lateral_convs)
+    convs = list(fpn.fpn_convs)
+    consumer, _LEVEL_CONSUMER = _LEVEL_CONSUMER, None
+    if len(convs) > n:
+        consumer = None   # extra levels hang off the last output: one chain
+    # under a graph capture the chain of every coarse level forks off as soon as its lateral is final
+    fork_from = int(os.environ.get("SRF_FPN_FORK", "2"))   # first level whose chain forks; 0: none
+    fork = consumer is not None and inputs[0].is_cuda and torch.cuda.is_current_stream_capturing() and fork_from > 0
+    main = torch.cuda.current_stream() if fork else None
+
+    def chain(i):
+        o = _cm(convs[i], lats[i], conv3x3)
+        return consumer(i, o) if consumer is not None else o
+
     lats = [None] * n
+    outs = [None] * n
+    used = []
     for i in range(n - 1, -1, -1):
         cm = fpn.lateral_convs[i]
         bn = getattr(cm, cm.norm_name) if cm.with_norm else None
         lats[i] = conv1x1(nhwc_view(inputs[i]), cm.conv, bn, cm.with_activation, top=lats[i + 1] if i + 1 < n else None)
-    outs = [_cm(cm, lats[i], conv3x3) for i, cm in enumerate(list(fpn.fpn_convs)[:n])]
-    for cm in list(fpn.fpn_convs)[n:]:   # add_extra_convs='on_output': stride-2 3x3 on the previous output
+        if fork and i >= fork_from:
+            s = _chain_stream(i)
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                outs[i] = chain(i)
+            used.append(s)
+    for i in range(n):
+        if outs[i] is None:
+            outs[i] = chain(i)
+    for s in used:
+        main.wait_stream(s)   # the join; `lats` and `outs` stay referenced until here, so no block is reused across streams
+    for cm in convs[n:]:   # add_extra_convs='on_output': stride-2 3x3 on the previous output
         src = outs[-1]
         if fpn.relu_before_extra_convs and len(outs) > n:
             src = torch.relu(src)
         outs.append(_cm(cm, src, conv_strided))
-    return tuple(nchw_view(o) for o in outs)
+    res = tuple(nchw_view(o) for o in outs)
+    return ConsumedLevels(res) if consumer is not None else res

@@ -4,6 +4,7 @@ constructor arguments, sub-module attribute names and forward signatures as the 
 import torch
 import torch.nn.functional as F
 
+from .. import nhwc
 from ..compat.boxes import bbox3d2result
 from ..compat.cnn import BaseModule
 from ..compat.registry import (DETECTORS, build_backbone, build_head, build_middle_encoder, build_neck,
@@ -155,7 +156,8 @@ class SRFDet(BaseModule):
                 feats = list(feats.values())
             if self.img_neck is not None:
                 feats = self.img_neck(feats)
-        return [f.float().view(B, f.shape[0] // B, *f.shape[1:]) for f in feats]
+        out = [f.float().view(B, f.shape[0] // B, *f.shape[1:]) for f in feats]
+        return nhwc.ConsumedLevels(out) if isinstance(feats, nhwc.ConsumedLevels) else out
 
     @torch.no_grad()
     def voxelize(self, points):

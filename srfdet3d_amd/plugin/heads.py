@@ -539,11 +539,20 @@ class SRFDetHead(BaseModule):
             out[i] = g.reshape(bs, n_cam, *g.shape[1:])
         return out
 
+    def img_level_consumer(self):
+        """`img_convs` as a per-level consumer for nhwc.level_consumer (channels-last in, channels-last out), or None when the
+        head has no `img_convs` or a level cannot run on the Winograd kernel."""
+        if not (self.use_img and self.hidden_dim != self.feat_channels_img and nhwc.enabled()):
+            return None
+        if not all(nhwc.wino_ok(conv, self.feat_channels_img) for conv in self.img_convs):
+            return None
+        return lambda i, x: nhwc.conv3x3(x, self.img_convs[i])
+
     # ---- forward --------------------------------------------------------------------------------------------
     def forward(self, img_feats, point_feats, img_metas):
         """-> logits (#stage, bs, n_p, #cls), boxes (#stage, bs, n_p, D) with centres in metres, log sizes."""
         point_feats = list(point_feats)
-        if self.use_img and self.hidden_dim != self.feat_channels_img:
+        if self.use_img and self.hidden_dim != self.feat_channels_img and not isinstance(img_feats, nhwc.ConsumedLevels):
             img_feats = self._img_convs_only(img_feats)
         boxes, prop_feats = self._get_init_proposals(img_feats, point_feats)
         boxes = boxes.contiguous()
