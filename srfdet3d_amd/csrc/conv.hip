@@ -1318,46 +1318,48 @@ extern "C" int srf_conv_gemm_nhwc(const float *x, int N, int H, int W, int Cin, 
 // ---------------------------------------------------------------------------------------------------------------------
 // srf_stem_conv_nchw: the first layer of the image backbone, Conv2d(Cin <= 4, 64, 3, stride 2, padding 1) + scale / shift
 // + ReLU, reading the NCHW camera images and writing channels-last (VoVNet stem_1: 3 -> 64 on 6 x 928 x 1600; 7.7 GFLOP,
-// HBM-bound: 107 MB in, 570 MB out).  A workgroup owns 256 consecutive output pixels: every thread gathers the 9 Cin taps
-// of its pixel once (the first version had 16 threads of a pixel each fetch all taps and spent its time in the texture
-// path) into an LDS im2col image A[k][pixel], then the 4 waves multiply their 64 pixels by the 64 channels on
+// HBM-bound: 107 MB in, 570 MB out).  A workgroup owns a tile of 4 x 64 output pixels: its 9 x 129 input patch per channel
+// is read once, row by row (coalesced; the earlier versions gathered the 9 Cin taps of every pixel with stride-2 loads),
+// into LDS with the even and the odd columns apart, so that the A operand of tap (ky, kx) is a unit-stride read:
+// P[ci][row][column parity][65].  Wave w multiplies the 64 pixels of output row w by the 64 channels on
 // v_mfma_f32_32x32x2_f32: k = ci * 9 + ky * 3 + kx ascending, one fma chain per output, zero taps add +0.
 // ---------------------------------------------------------------------------------------------------------------------
-#define ST_PIX 256
+#define ST_R 4
+#define ST_C 64
+#define ST_ROWP 130
 __global__ __launch_bounds__(256) void srf_stem_conv_nchw_k(const float *__restrict__ x, int N, int Cin, int H, int W, int Ho, int Wo,
                                                            const float *__restrict__ wt, const float *__restrict__ scale,
-                                                           const float *__restrict__ shift, int relu, float *__restrict__ y, long long y_ld)
+                                                           const float *__restrict__ shift, int relu, float *__restrict__ y, long long y_ld,
+                                                           int tilesX, int tilesY)
 {
-    __shared__ float s_a[36][ST_PIX];  // [k][pixel]
-    __shared__ float s_w[36][64];      // [k][channel]
+    __shared__ float s_p[4 * 9 * ST_ROWP];  // [ci][patch row 0 .. 8][column parity][65]
+    __shared__ float s_w[36][64];           // [k][channel]
+    __shared__ int s_off[36];               // patch offset of tap k
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int K = Cin * 9, KP = (K + 1) & ~1;
+    const int bx = blockIdx.x % tilesX, rest = blockIdx.x / tilesX;
+    const int by = rest % tilesY, n = rest / tilesY;
+    const int ox0 = bx * ST_C, oy0 = by * ST_R;
     for (int e = tid; e < KP * 64; e += 256) {
         const int k = e >> 6, co = e & 63;
         s_w[k][co] = k < K ? wt[(size_t)co * K + k] : 0.f;
     }
-    const long long total = (long long)N * Ho * Wo;
-    const long long p = (long long)blockIdx.x * ST_PIX + tid;
+    if (tid < KP) {
+        const int k = tid < K ? tid : 0;
+        const int ci = k / 9, r = k - ci * 9, ky = r / 3, kx = r - ky * 3;
+        s_off[tid] = (ci * 9 + ky) * ST_ROWP + (kx & 1) * 65 + (kx >> 1);
+    }
     {
-        const bool live = p < total;
-        const long long pp = live ? p : 0;
-        const int ox = (int)(pp % Wo);
-        const long long r = pp / Wo;
-        const int oy = (int)(r % Ho), n = (int)(r / Ho);
-        for (int ci = 0; ci < Cin; ++ci) {
-            const float *xc = x + ((size_t)n * Cin + ci) * H * W;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int iy = 2 * oy - 1 + ky;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = 2 * ox - 1 + kx;
-                    s_a[ci * 9 + ky * 3 + kx][tid] = (live && iy >= 0 && iy < H && ix >= 0 && ix < W) ? xc[(size_t)iy * W + ix] : 0.f;
-                }
-            }
+        const int cols = 2 * ST_C + 1, total = Cin * 9 * cols;
+        const float *xn = x + (size_t)n * Cin * H * W;
+        for (int e = tid; e < total; e += 256) {
+            const int r = e / cols, c = e - r * cols;
+            const int ci = r / 9, iyl = r - ci * 9;
+            const int iy = 2 * oy0 - 1 + iyl, ix = 2 * ox0 - 1 + c;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            s_p[r * ST_ROWP + (c & 1) * 65 + (c >> 1)] = ok ? xn[((size_t)ci * H + iy) * W + ix] : 0.f;
         }
-        if (KP > K) s_a[K][tid] = 0.f;
     }
     __syncthreads();
     f32x16 acc[2][2];
@@ -1368,9 +1370,12 @@ __global__ __launch_bounds__(256) void srf_stem_conv_nchw_k(const float *__restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int ksteps = KP >> 1;
+    const int a_base = 2 * wave * ST_ROWP + li;   // output row `wave` of the tile: patch rows 2 wave + ky
     for (int s2 = 0; s2 < ksteps; ++s2) {
         const int k = 2 * s2 + lh;
-        const float a0 = s_a[k][wave * 64 + li], a1 = s_a[k][wave * 64 + 32 + li];
+        const int off = s_off[k] + a_base;
+        const bool live = k < K;
+        const float a0 = live ? s_p[off] : 0.f, a1 = live ? s_p[off + 32] : 0.f;
         const float b0 = s_w[k][li], b1 = s_w[k][32 + li];
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
@@ -1383,21 +1388,25 @@ __global__ __launch_bounds__(256) void srf_stem_conv_nchw_k(const float *__restr
         sc[j] = scale ? scale[j * 32 + li] : 1.f;
         sh[j] = shift ? shift[j * 32 + li] : 0.f;
     }
-    const long long prow = (long long)blockIdx.x * ST_PIX + wave * 64 + 4 * lh;
+    // stores through a buffer descriptor of image n: a pixel outside the map gets an offset beyond the range and is dropped
+    __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(y + (long long)n * Ho * Wo * y_ld, 0,
+                                                                     (int)((long long)Ho * Wo * y_ld * 4), 0x00020000);
+    const int oy = oy0 + wave;
+    const unsigned px_b = (unsigned)(y_ld * 4);
+    const unsigned row_off = (unsigned)(((long long)oy * Wo + ox0) * y_ld * 4) + (unsigned)(li * 4);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long long q = prow + i * 32 + (r & 3) + 8 * (r >> 2);
-            if (q < total) {
+            const int px = i * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+            const bool ok = oy < Ho && ox0 + px < Wo;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float o = acc[i][j][r];
-                    if (scale) o = __fmaf_rn(o, sc[j], sh[j]);
-                    else if (shift) o = __fadd_rn(o, sh[j]);
-                    if (relu) o = fmaxf(o, 0.f);
-                    y[q * y_ld + j * 32 + li] = o;
-                }
+            for (int j = 0; j < 2; ++j) {
+                float o = acc[i][j][r];
+                if (scale) o = __fmaf_rn(o, sc[j], sh[j]);
+                else if (shift) o = __fadd_rn(o, sh[j]);
+                if (relu) o = fmaxf(o, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), yrsrc, ok ? (int)(row_off + (unsigned)px * px_b + j * 128) : (int)0x80000000, 0, 0);
             }
         }
 }
@@ -1410,9 +1419,12 @@ extern "C" int srf_stem_conv_nchw(const float *x, int N, int Cin, int H, int W, 
     if (N == 0) return SRF_OK;
     if (!x || !Wt || !y) return SRF_EINVAL;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long long total = (long long)N * Ho * Wo;
-    hipLaunchKernelGGL(srf_stem_conv_nchw_k, dim3(srf_ceil_div(total, ST_PIX)), dim3(256), 0, (hipStream_t)stream, x, N, Cin, H, W, Ho, Wo, Wt, scale,
-                       shift, relu, y, y_ld);
+    if ((long long)Ho * Wo * y_ld * 4 >= (1ll << 31)) return SRF_EUNSUPPORTED;   // buffer-descriptor range of one image's output
+    const int tilesX = srf_ceil_div(Wo, ST_C), tilesY = srf_ceil_div(Ho, ST_R);
+    const long long blocks = (long long)N * tilesX * tilesY;
+    if (blocks >= (1ll << 31)) return SRF_EUNSUPPORTED;
+    hipLaunchKernelGGL(srf_stem_conv_nchw_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, N, Cin, H, W, Ho, Wo, Wt, scale, shift,
+                       relu, y, y_ld, tilesX, tilesY);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

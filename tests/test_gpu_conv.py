@@ -386,10 +386,12 @@ def test_conv_gemm_nhwc_matches_torch(N, H, W, Cin, Cout, k, stride, pad):
     assert (y.cpu().double() - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1.0)
 
 
-def test_stem_conv_nchw_matches_torch():
-    g = torch.Generator().manual_seed(4)
-    x = torch.randn(3, 3, 37, 50, generator=g).to(DEV)
-    w = (torch.randn(64, 3, 3, 3, generator=g) / 5).to(DEV)
+@pytest.mark.parametrize("N,Cin,H,W", [(3, 3, 37, 50), (2, 3, 64, 300), (1, 4, 9, 131), (2, 1, 8, 8), (1, 3, 129, 257)])
+def test_stem_conv_nchw_matches_torch(N, Cin, H, W):
+    """Odd and even sizes, maps wider and narrower than the 4 x 64-pixel workgroup tile, Cin = 1 .. 4 (k padded to even)."""
+    g = torch.Generator().manual_seed(4 + H)
+    x = torch.randn(N, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(64, Cin, 3, 3, generator=g) / 5).to(DEV)
     scale = (torch.rand(64, generator=g) + 0.5).to(DEV)
     shift = torch.randn(64, generator=g).to(DEV)
     y = ops.stem_conv_nchw(x, w, scale, shift, True)
