@@ -51,6 +51,7 @@ struct WinoArgs {
     int rowBlocks, colBlocks, coutBlocks, nchunk, nspatial, relu;
     int cb0, ncb;       // channel blocks of this launch: cb0 .. cb0 + ncb - 1 (half-block form: in units of 32 channels)
     int nfull;          // srf_wino3x3_mixed_k: workgroups of the full form (the half-block ones follow)
+    int ntail;          // srf_wino3x3_mixed_k: full work items nfull .. nfull + ntail - 1 run as two half-block workgroups each
     long long *stamps;  // developer timing hook (srf_dev_set_stamp_buffer): 4 s_memtime values per workgroup, else NULL
 };
 
@@ -143,7 +144,7 @@ __device__ __forceinline__ float4 wn_fma(float s, float4 a, float4 b)   // s a +
 // upper frequency half hand their 8 accumulator tiles (the frequency rows 2 and 3 of M) to the lower half through LDS,
 // which then runs the SAME output transform in the same order of operations as the full kernel: identical bits.
 template <int DBG, int TWL, bool HALFB>
-__device__ __forceinline__ void srf_wino3x3_body(const WinoArgs &a, const unsigned bid)
+__device__ __forceinline__ void srf_wino3x3_body(const WinoArgs &a, const int cbi /* HALFB: index of a 32-channel half */, const int sp)
 {
     constexpr int TW = 1 << TWL, TH = 64 >> TWL;       // tiles per block row / column
     constexpr int PR = 2 * TH + 2, PC = 2 * TW + 2;    // patch rows / columns (pixels)
@@ -154,11 +155,7 @@ __device__ __forceinline__ void srf_wino3x3_body(const WinoArgs &a, const unsign
     static_assert(2 * PR * RP <= WN_RAW && 2 * HP <= RP + 1, "patch buffer");
     extern __shared__ __attribute__((aligned(16))) float4 s_w[];  // V[2][2048] | U[2][2048] | RAW[2][WN_RAW]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // workgroups b and b + 8 share an XCD (round-robin dispatch): the cout blocks of one spatial block sit on one L2
-    const int xcd = bid & 7, jq = bid >> 3;
-    const int cbi = a.cb0 + jq % a.ncb;               // HALFB: index of a 32-channel half of a block
     const int cb = HALFB ? cbi >> 1 : cbi;
-    const int sp = (jq / a.ncb) * 8 + xcd;
     if (sp >= a.nspatial) return;
     const int per_img = a.rowBlocks * a.colBlocks;
     const int n = sp / per_img;
@@ -521,7 +518,7 @@ __device__ __forceinline__ void srf_wino3x3_body(const WinoArgs &a, const unsign
     }
     if ((DBG & 8) && a.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        long long *o = a.stamps + (size_t)bid * 4;
+        long long *o = a.stamps + (size_t)blockIdx.x * 4;
         o[0] = st0;
         o[1] = st1;
         o[2] = st2;
@@ -529,26 +526,45 @@ __device__ __forceinline__ void srf_wino3x3_body(const WinoArgs &a, const unsign
     }
 }
 
+// work item -> (channel block, spatial block): items b and b + 8 share an XCD (round-robin dispatch), so the channel blocks of
+// one spatial block sit on one L2
+__device__ __forceinline__ void srf_wino_decode(unsigned item, int cb0, int ncb, int &cbi, int &sp)
+{
+    const int xcd = item & 7, jq = item >> 3;
+    cbi = cb0 + jq % ncb;
+    sp = (jq / ncb) * 8 + xcd;
+}
+
 template <int DBG, int TWL, bool HALFB = false>
 __global__ __launch_bounds__(256, 1) void srf_wino3x3_k(WinoArgs a)
 {
-    srf_wino3x3_body<DBG, TWL, HALFB>(a, blockIdx.x);
+    int cbi, sp;
+    srf_wino_decode(blockIdx.x, a.cb0, a.ncb, cbi, sp);
+    srf_wino3x3_body<DBG, TWL, HALFB>(a, cbi, sp);
 }
 
-// One launch for a layer whose last channel block runs on the half-block form: the first a.nfull workgroups are full ones
-// (channel blocks 0 .. coutBlocks - 2), the rest half ones -- the short workgroups fill the tail of the long ones instead
-// of waiting for a launch of their own.
+// One launch, full and half-block workgroups: the first a.nfull workgroups are full ones (work items 0 .. nfull - 1 over the
+// channel blocks 0 .. ncb - 1); then the a.ntail work items that would form a partly filled last round run as TWO half-block
+// workgroups each (a round of half blocks is ~0.7 of a full one: 276 items on 256 CUs take 1.7 rounds instead of 2); then, for
+// a layer whose last channel block holds <= 32 channels (cb0 = that block's first half, else -1), one half-block workgroup per
+// spatial block.  The short workgroups fill the tail of the long ones instead of waiting for a launch of their own.
 template <int TWL>
 __global__ __launch_bounds__(256, 1) void srf_wino3x3_mixed_k(WinoArgs a)
 {
+    int cbi, sp;
     if (blockIdx.x < (unsigned)a.nfull) {
-        srf_wino3x3_body<0, TWL, false>(a, blockIdx.x);
-    } else {
-        WinoArgs h = a;
-        h.cb0 = 2 * (a.coutBlocks - 1);
-        h.ncb = 1;
-        srf_wino3x3_body<0, TWL, true>(h, blockIdx.x - (unsigned)a.nfull);
+        srf_wino_decode(blockIdx.x, 0, a.ncb, cbi, sp);
+        srf_wino3x3_body<0, TWL, false>(a, cbi, sp);
+        return;
     }
+    const unsigned h = blockIdx.x - (unsigned)a.nfull;
+    if (h < 2u * (unsigned)a.ntail) {
+        srf_wino_decode((unsigned)a.nfull + (h >> 1), 0, a.ncb, cbi, sp);
+        cbi = 2 * cbi + (int)(h & 1);
+    } else {
+        srf_wino_decode(h - 2u * (unsigned)a.ntail, a.cb0, 1, cbi, sp);
+    }
+    srf_wino3x3_body<0, TWL, true>(a, cbi, sp);
 }
 
 // =====================================================================================================================
@@ -1006,14 +1022,23 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
         else hipLaunchKernelGGL((srf_wino3x3_k<0, 1, HB>), dim3((unsigned)(GRID)), blk, WN_LDS_BYTES, (hipStream_t)stream, a);               \
     } while (0)
     a.nfull = 0;
+    a.ntail = 0;
+#define WN_LAUNCH_MIXED(GRID)                                                                                                  \
+    do {                                                                                                                       \
+        const dim3 gm_((unsigned)(GRID));                                                                                      \
+        if (twl == 3) hipLaunchKernelGGL((srf_wino3x3_mixed_k<3>), gm_, blk, WN_LDS_BYTES, (hipStream_t)stream, a);            \
+        else if (twl == 2) hipLaunchKernelGGL((srf_wino3x3_mixed_k<2>), gm_, blk, WN_LDS_BYTES, (hipStream_t)stream, a);       \
+        else hipLaunchKernelGGL((srf_wino3x3_mixed_k<1>), gm_, blk, WN_LDS_BYTES, (hipStream_t)stream, a);                     \
+    } while (0)
+    // a partly filled last round of full workgroups (SECOND 128 -> 128 @ 184 x 184: 288 work items on 256 CUs) as half-block
+    // workgroups in the same launch, when they all fit beside each other (SRF_WINO_HALF=3 forces it on half of the items)
+    const long long items = sp8 * a.coutBlocks, tail_items = items % cus;
+    const bool tail = !split && !all_half && (force_half < 0 ? (items > cus && tail_items > 0 && 2 * tail_items <= cus) : force_half == 3);
     if (split && !all_half && a.coutBlocks > 1) {
-        a.cb0 = 0;
+        a.cb0 = 2 * (a.coutBlocks - 1);
         a.ncb = a.coutBlocks - 1;
         a.nfull = (int)(sp8 * a.ncb);
-        const dim3 gm((unsigned)(sp8 * a.coutBlocks));
-        if (twl == 3) hipLaunchKernelGGL((srf_wino3x3_mixed_k<3>), gm, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
-        else if (twl == 2) hipLaunchKernelGGL((srf_wino3x3_mixed_k<2>), gm, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((srf_wino3x3_mixed_k<1>), gm, blk, WN_LDS_BYTES, (hipStream_t)stream, a);
+        WN_LAUNCH_MIXED(sp8 * a.coutBlocks);
     } else if (split) {
         a.cb0 = 2 * (a.coutBlocks - 1);
         a.ncb = 1;
@@ -1022,9 +1047,16 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
         a.cb0 = 0;
         a.ncb = nhb;
         WN_LAUNCH(true, sp8 * nhb);
+    } else if (tail) {
+        a.cb0 = -1;
+        a.ncb = a.coutBlocks;
+        a.ntail = (int)(force_half == 3 ? items / 2 : tail_items);
+        a.nfull = (int)(items - a.ntail);
+        WN_LAUNCH_MIXED((long long)a.nfull + 2ll * a.ntail);
     } else {
         WN_LAUNCH(false, blocks);
     }
+#undef WN_LAUNCH_MIXED
 #undef WN_LAUNCH
     SRF_LAUNCH_CHECK();
     return SRF_OK;

@@ -273,7 +273,8 @@ def test_winograd_half_block_kernel_gives_the_same_bits(monkeypatch, N, H, W, Ci
     shift = torch.randn(Cout, generator=g).to(DEV)
     pk = ops.pack_wino3x3_weights(w)
     outs = []
-    for force in ("0", "1", "2"):   # one-launch form / last block as half blocks / every block as two half blocks
+    for force in ("0", "1", "2", "3"):   # one-launch form / last block as half blocks / every block as two half blocks / the
+        # second half of the work items as two half blocks each (the form a partly filled last round takes)
         monkeypatch.setenv("SRF_WINO_HALF", force)
         for twl in ("1", "2", "3"):
             monkeypatch.setenv("SRF_WINO_TWL", twl)   # 8 x 8, 16 x 4 and 32 x 2 tile blocks
