@@ -26,8 +26,8 @@ SQ = ("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY S
 TARGETS = {
     "wino3x3": (["tools/prof_img_branch.py", "3"], ("srf_wino3x3_k<", "srf_wino3x3_mixed_k<"),
                 "every srf_wino3x3_k launch of 3 eager passes of the LC camera branch (89 per frame: VoVNet-99, image FPN, img_convs)"),
-    "conv1x1": (["tools/prof_img_branch.py", "3"], "srf_conv1x1_nhwc_k<2, 2, 3, false>",
-                "every srf_conv1x1_nhwc_k launch of the same passes (OSA concat convolutions + FPN laterals, 20 per frame)"),
+    "conv1x1": (["tools/prof_img_branch.py", "3"], ("srf_conv1x1_nhwc_k<2, 2, 3, false>", "srf_conv1x1_nhwc_mixed_k"),
+                "every 128 x 128-tile srf_conv1x1_nhwc launch of the same passes, one-size or mixed-tile form (OSA concat convolutions + FPN laterals)"),
     "spconv128": (["tools/bench_spconv.py", "--levels", "4", "--reps", "8"], "srf_spconv_gs_k<4, 128>",
                   "SubM 128->128 on the 5x184x184 level of frame 2000 (A=34992), BN + residual + ReLU epilogue"),
     "spconv64": (["tools/bench_spconv.py", "--levels", "3", "--reps", "8"], "srf_spconv_gs_k<2, 64>",
