@@ -2,9 +2,9 @@
 
 Mirrors mmdet3d `box3d_multiclass_nms` as called at mmdet3d_plugin/models/sparse_heads/srfdet_head.py:1276-1293:
 per class keep score > score_thr, rotated NMS on the BEV boxes, concatenate, then top `max_num` by score.
-All classes go through ONE NMS launch: boxes of different classes are moved apart by a per-class offset larger
-than any box, so they never overlap (the standard batched-NMS trick), which gives the same keeps as the
-reference's per-class Python loop.
+All classes go through ONE NMS launch that carries the class id of every box and suppresses inside a class only
+(`srf_nms_rotated_classes`), which gives the same keeps as the reference's per-class Python loop without moving any
+coordinate.
 """
 import torch
 
