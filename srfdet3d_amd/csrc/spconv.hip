@@ -1147,6 +1147,7 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
     // groups of 16 rows per step (srf_gs_offset).  COUT = 64, nuScenes level 3 (59.6k rows, 10.9 pairs per row): 107 us with 1,
     // 123 us with 2; 64-row tiles walked by two workgroups per range (four per CU) 118 us; B fetched a whole offset ahead 113 us.
     // Ablations of the 107 us: without MFMAs 70, without the gathers 99, without barriers 100, prologue + epilogue alone 14.
+    // Three workgroups per CU (88-row tiles, 768 ranges, 46 KB of LDS each): 105 us -- occupancy is not what holds it.
     constexpr int GP = 1;
     constexpr int NA = 16 * GP * 8 * NCH / 256, NKW = (SRF_KMAX + 3) / 4, CHS = 16 * GP * 32 + 8;
     constexpr int TMAX = COUT == 128 ? SRF_GS_TMAX : 120, LS = COUT == 128 ? SRF_GS_LS : 128, OS = COUT + 4;
