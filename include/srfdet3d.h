@@ -359,6 +359,19 @@ int srf_wino3x3_pack_weights(const float *W, int Cout, int Cin, float *packed, s
 int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long long x_ld, const float *U_packed, int Cout,
                 const float *scale, const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream);
 
+/* srf_wino43: the same layer as srf_wino3x3 as Winograd F(4x4, 3x3) (csrc/wino43.hip): 36 products per 16 outputs instead of
+ * 16 per 4, i.e. direct FLOPs / 4 on the MFMA.  Two kernels per call: the input transform V = B^T d B of every 6 x 6 patch into
+ * `workspace` (srf_wino43_workspace_bytes), then the 36 batched products with the output transform, scale / shift / ReLU as the
+ * epilogue.  U_packed comes from srf_wino43_pack_weights(W (Cout, Cin, 3, 3)) (U = G g G^T computed in double, rounded once).
+ * Replaces the same reference call sites as srf_wino3x3 (vovnet.py:116-133, :180-216; srfdet_head.py:404-416;
+ * second_custom.py:41-63).  f32 result within ~2e-5 of the map's maximum of the direct convolution (Cin <= 1024).
+ * Cin % 8 == 0, Cout % 4 == 0, x / y / scale / shift 16-byte aligned, x_ld % 4 == 0, y_ld % 4 == 0, else SRF_EUNSUPPORTED. */
+size_t srf_wino43_packed_weight_bytes(int Cout, int Cin);
+int srf_wino43_pack_weights(const float *W, int Cout, int Cin, float *packed, srf_stream_t stream);
+size_t srf_wino43_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int srf_wino43(const float *x, int N, int H, int W, int Cin, long long x_ld, const float *U_packed, int Cout, const float *scale,
+               const float *shift, int relu, float *y, long long y_ld, void *workspace, size_t workspace_bytes, srf_stream_t stream);
+
 /* srf_conv1x1_nhwc: Conv2d(K, Cout, 1) on channels-last activations = the GEMM y[p][co] = sum_k x[p][k] W[co][k] over
  * M = N * H * W pixels, then y = y * scale[co] + shift[co] (either may be NULL) and an optional ReLU: the `concat` layer of
  * VoVNet's OSA blocks read straight from the block's concat buffer (vovnet.py:222-223) and the FPN lateral convolutions.

@@ -81,6 +81,10 @@ SIGNATURES = {
     "srf_conv1x1_packed_weight_bytes": (c_size_t, [c_int, c_int]),
     "srf_conv1x1_pack_weights": (c_int, [_P, c_int, c_int, _P, _P]),
     "srf_conv1x1": (c_int, [POINTER(c_void_p), _HI, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, _P]),
+    "srf_wino43_packed_weight_bytes": (c_size_t, [c_int, c_int]),
+    "srf_wino43_pack_weights": (c_int, [_P, c_int, c_int, _P, _P]),
+    "srf_wino43_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "srf_wino43": (c_int, [_P, c_int, c_int, c_int, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_longlong, _P, c_size_t, _P]),
     "srf_wino3x3_packed_weight_bytes": (c_size_t, [c_int, c_int]),
     "srf_wino3x3_pack_weights": (c_int, [_P, c_int, c_int, _P, _P]),
     "srf_wino3x3": (c_int, [_P, c_int, c_int, c_int, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_longlong, _P]),

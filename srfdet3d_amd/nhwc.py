@@ -80,9 +80,28 @@ def _affine_of(conv, bn):
     return None, conv.bias
 
 
+def _wino43_weights(conv):
+    w = conv.weight
+    return _cached(conv, "_srf_wino43", (w._version, w.data_ptr()), lambda: ops.pack_wino43_weights(w.detach()))
+
+
+def wino43_enabled():
+    """SRF_WINO43=0 keeps every 3x3 layer on Winograd F(2x2, 3x3) (A/B switch for tests and benchmarks)."""
+    return os.environ.get("SRF_WINO43", "1") != "0"
+
+
+def use_wino43(x, cout, out=None):
+    """F(4x4, 3x3) (`srf_wino43`: direct FLOPs / 4, plus an HBM pass that writes the transformed input) where it is the faster
+    of the two kernels: every layer from 96 input channels up.  Below that (VoVNet stem_2: 64 -> 64 on 464 x 800) the
+    transform pass costs more than the saved MFMA time (tools/micro/wino43_bench.hip: 954 against 928 us)."""
+    return wino43_enabled() and x.shape[3] >= 96 and ops.wino43_supported(x, cout, out)
+
+
 def conv3x3(x, conv, bn=None, relu=False, out=None):
     """x: NHWC slice; conv: nn.Conv2d 3x3 / stride 1 / padding 1."""
     scale, shift = _affine_of(conv, bn)
+    if use_wino43(x, conv.out_channels, out):
+        return ops.wino43(x, _wino43_weights(conv), conv.out_channels, scale, shift, relu, out=out)
     return ops.wino3x3(x, _wino_weights(conv), conv.out_channels, scale, shift, relu, out=out)
 
 

@@ -964,6 +964,73 @@ def wino3x3(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None
     return out
 
 
+def pack_wino43_weights(weight):
+    """(Cout, Cin, 3, 3) -> U = G g G^T of Winograd F(4x4, 3x3) in the operand order srf_wino43 streams (once per layer)."""
+    weight = _dev(weight, "weight", torch.float32)
+    Cout, Cin, kh, kw = weight.shape
+    L = _lib.lib()
+    nbytes = L.srf_wino43_packed_weight_bytes(Cout, Cin)
+    if (kh, kw) != (3, 3) or nbytes == 0:
+        raise ValueError("wino43: needs a (Cout, Cin, 3, 3) weight with Cin % 8 == 0")
+    packed = _empty((nbytes // 4,), torch.float32, weight.device)
+    check(L.srf_wino43_pack_weights(_ptr(weight), Cout, Cin, _ptr(packed), _stream()), "wino43_pack_weights")
+    return packed
+
+
+def wino43_supported(x, Cout, out=None):
+    """Shape / layout limits of srf_wino43 (csrc/wino43.hip: w43_make_args, w43_slab_args)."""
+    if not (x.dim() == 4 and x.is_cuda and x.dtype == torch.float32 and x.shape[3] % 8 == 0 and Cout % 4 == 0
+            and x.data_ptr() % 16 == 0):
+        return False
+    try:
+        ld = nhwc_ld(x)
+        old = nhwc_ld(out) if out is not None else Cout
+    except RuntimeError:
+        return False
+    if ld % 4 or old % 4 or (out is not None and out.data_ptr() % 16):
+        return False
+    N, H, W, _ = x.shape
+    # one slab = the whole layer below 2 GB of V: its images must span less than 4 GB of x and of y
+    return 4 * N * H * W * max(ld, old) < (1 << 32) - 16 and N * ((H + 3) // 4) * ((W + 3) // 4) < (1 << 31) - 64
+
+
+def _aligned16(t):
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
+def wino43(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None):
+    """3x3 / stride 1 / padding 1 convolution of the NHWC slice x (N, H, W, Cin) as Winograd F(4x4, 3x3) + per-channel scale /
+    shift + ReLU into `out` (an (N, H, W, Cout) slice of an NHWC buffer; a new contiguous tensor when None)."""
+    x_ld = nhwc_ld(x)
+    N, H, W, Cin = x.shape
+    if out is None:
+        out = _empty((N, H, W, Cout), torch.float32, x.device)
+    elif tuple(out.shape) != (N, H, W, Cout):
+        raise ValueError("wino43: out has the wrong shape")
+    y_ld = nhwc_ld(out)
+    L = _lib.lib()
+    if packed_weight.numel() * 4 != L.srf_wino43_packed_weight_bytes(Cout, Cin):
+        raise ValueError("wino43: packed weight does not match (Cout, Cin)")
+    if N == 0:
+        return out
+    ws_bytes = L.srf_wino43_workspace_bytes(N, H, W, Cin, Cout)
+    ws = _empty((ws_bytes // 4,), torch.float32, x.device)
+    sc = None if scale is None else _aligned16(_dev(scale, "scale", torch.float32))
+    sh = None if shift is None else _aligned16(_dev(shift, "shift", torch.float32))
+    timing = _dense_timing("wino")
+    check(L.srf_wino43(_ptr(x), N, H, W, Cin, x_ld, _ptr(packed_weight), Cout, None if sc is None else _ptr(sc),
+                       None if sh is None else _ptr(sh), int(bool(relu)), _ptr(out), y_ld, _ptr(ws), ws_bytes, _stream()), "wino43")
+    if timing is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        # direct-convolution FLOPs, FLOPs executed on the MFMA (36 products per 16 outputs = direct / 4), algorithmic bytes:
+        # in + out + weights + V written and read once (2.25x the input each way)
+        direct = 2.0 * 9 * Cin * Cout * N * H * W
+        timing[1].append((timing[0], ev1, f"{Cin}->{Cout} @{N}x{H}x{W} F(4,3)", direct, direct / 4.0,
+                          4.0 * N * H * W * (Cin + Cout) + 4.0 * 36 * Cin * Cout + 2.0 * ws_bytes))
+    return out
+
+
 def pack_conv1x1_nhwc_weights(weight):
     """(Cout, K) or (Cout, K, 1, 1) -> the LDS operand order srf_conv1x1_nhwc copies (once per layer)."""
     weight = _dev(weight.reshape(weight.shape[0], -1), "weight", torch.float32)
