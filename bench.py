@@ -8,11 +8,13 @@ are independent: no data-path collective); the job's time is the m
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
   roofline     -- the dominant hand-written kernel of the workload against the 157.3 TFLOP/s f32 MFMA peak, from HIP events
-                  on the launch stream around every launch: LC = srf_wino3x3_k (the 89 Winograd 3x3 launches of the
-                  camera branch: FLOPs it executes on the MFMA = direct FLOPs / 2.25, direct-equivalent rate beside it);
+                  on the launch stream around every launch: LC = srf_wino43_mm_k (the multiply kernel of the Winograd
+                  F(4x4, 3x3) layers of the camera branch: FLOPs it executes on the MFMA = direct FLOPs / 4, direct-equivalent
+                  rate beside it), with roofline.xform = its HBM-bound input-transform kernel against the 8 TB/s peak,
+                  roofline.wino23 = the layers left on F(2x2, 3x3) and roofline.gemm = srf_conv1x1_nhwc_k;
                   LiDAR-only = the 128->128 SubM sparse conv (2 * pairs * Cin * Cout per launch); plus
                   roofline.stage = the WHOLE sparse-conv stage (all 21 launches: sum of algorithmic FLOPs and bytes over the sum
-                  of their event times, against the MFMA and the HBM peak) and, on LC, roofline.gemm for srf_conv1x1_nhwc_k;
+                  of their event times, against the MFMA and the HBM peak);
   cpu_baseline -- oracle/pipeline.py (the CPU port of the same path: C/OpenMP operators + torch-CPU dense layers)
                   timed on this host, rank 0 at N=1 only.
 """
@@ -30,7 +32,7 @@ import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 HBM_PEAK_GBS = 8000.0         # same guide, "HBM3E peak BW" (spec)
-ROUND = "r02"                 # prefix of the profiles/ files this build's counter numbers live in
+ROUND = "r03"                 # prefix of the profiles/ files this build's counter numbers live in
 
 WORKLOADS = {
     "nusc_L": dict(cfg="srfdet_voxel_nusc_L", desc="srfdet_voxel_nusc_L inference (LiDAR-only), synthetic 30k-pt sweep, "
@@ -150,7 +152,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ops.KERNEL_TIMING = {"spconv": [], "wino": [], "gemm": []}  # HIP-event pairs around every launch of the timed region
+    ops.KERNEL_TIMING = {"spconv": [], "wino": [], "gemm": [], "w43x": [], "w43m": []}  # HIP-event pairs around every launch of the timed region
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -171,7 +173,7 @@ def main():
         torch.cuda.synchronize()
         records = ops.KERNEL_TIMING["spconv"]
     dense_source = roofline_source
-    if model.use_img and not ops.KERNEL_TIMING["wino"] and not args.img_precomputed:
+    if model.use_img and not (ops.KERNEL_TIMING["wino"] or ops.KERNEL_TIMING["w43m"]) and not args.img_precomputed:
         # the camera branch replayed as a hipGraph: time its launches on 3 eager passes right after the timed region
         dense_source = ("HIP events around the launches of 3 eager passes of the camera branch run right after the timed region "
                         "(the timed frames replay it as a hipGraph; per-launch times inside it: profiles/)")
@@ -184,6 +186,7 @@ def main():
         torch.cuda.synchronize()
         model._graphed_img = gi
     wino_rec, gemm_rec = ops.KERNEL_TIMING["wino"], ops.KERNEL_TIMING["gemm"]
+    w43x_rec, w43m_rec = ops.KERNEL_TIMING["w43x"], ops.KERNEL_TIMING["w43m"]
     ops.KERNEL_TIMING = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -191,13 +194,37 @@ def main():
         elapsed = t.item()
 
     if rank == 0:
+        def _source_id():
+            """sha of the kernel sources: a counter file is only quoted for the build it was measured on."""
+            import glob
+            import hashlib
+            h = hashlib.sha256()
+            for f in sorted(glob.glob(os.path.join(ROOT, "srfdet3d_amd", "csrc", "*.h*"))):
+                with open(f, "rb") as fh:
+                    h.update(fh.read())
+            return h.hexdigest()[:16]
+
         def _traffic(name):
-            """HBM bytes per launch from the rocprofv3 --pmc passes of THIS round (tools/measure_traffic.py writes the file)."""
+            """HBM bytes per launch from the rocprofv3 --pmc passes of THIS build (tools/measure_traffic.py writes the file with
+            the sha of the kernel sources it ran; a file measured on other sources is not quoted: null)."""
             path = os.path.join(ROOT, "profiles", f"{ROUND}_pmc_{name}_traffic.json")
             if not os.path.exists(path):
                 return None
             with open(path) as fh:
-                return json.load(fh).get("traffic_bytes_per_launch")
+                d = json.load(fh)
+            if d.get("kernel_source_sha16") not in (None, _source_id()) and not os.environ.get("SRF_BENCH_ANY_TRAFFIC"):
+                return None
+            return d.get("traffic_bytes_per_launch")
+
+        def _in_graph(name):
+            """ms per frame of a kernel family inside the timed hipGraphs, from the tracked rocprofv3 kernel trace of the same
+            command (profiles/<round>_in_graph_summary.json, written by tools/in_graph_summary.py): kernels of the camera graph
+            share the chip with the BEV half there, so this is larger than the serial event time."""
+            path = os.path.join(ROOT, "profiles", f"{ROUND}_in_graph_summary.json")
+            if not os.path.exists(path):
+                return None
+            with open(path) as fh:
+                return json.load(fh).get(args.workload, {}).get(name)
 
         # the dominant sparse-conv shape = the (Cin, Cout, K) group with the most time: the 128 -> 128, 27-offset SubM conv on
         # nuScenes / Waymo (4 launches per frame on the 5x184x184 level), 64 -> 64 on KITTI's narrower encoder
@@ -238,27 +265,58 @@ def main():
                          gbs=round(by / (ms * 1e-3) / 1e9, 1), frac_hbm=round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          measured=roofline_source)
 
-        def _dense(recs, kernel, name):
+        def _dense(recs, kernel, name, passes=1):
             if not recs:
                 return None
             t_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             direct, executed, byts = sum(r[3] for r in recs), sum(r[4] for r in recs), sum(r[5] for r in recs)
             worst = max(recs, key=lambda r: r[0].elapsed_time(r[1]))
             ach = executed / (t_ms * 1e-3) / 1e12
-            return dict(kernel=kernel, bound="mfma", achieved=round(ach, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / F32_MFMA_PEAK_TFLOPS, 4), traffic=_traffic(name), launches=len(recs),
-                        avg_us=round(t_ms * 1e3 / len(recs), 2), measured=dense_source,
-                        algorithmic_flops_per_launch=int(executed / len(recs)),
-                        direct_equivalent_tflops=round(direct / (t_ms * 1e-3) / 1e12, 3),
-                        algorithmic_bytes_per_launch=int(byts / len(recs)),
-                        longest_launch=dict(layer=worst[2], us=round(worst[0].elapsed_time(worst[1]) * 1e3, 1)),
-                        note="aggregate over all launches of the kernel in a frame: sum of FLOPs over sum of event times")
+            d = dict(kernel=kernel, bound="mfma", achieved=round(ach, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                     frac=round(ach / F32_MFMA_PEAK_TFLOPS, 4), traffic=_traffic(name), launches=len(recs),
+                     avg_us=round(t_ms * 1e3 / len(recs), 2), serial_ms_per_frame=round(t_ms / passes, 3), measured=dense_source,
+                     algorithmic_flops_per_launch=int(executed / len(recs)),
+                     direct_equivalent_tflops=round(direct / (t_ms * 1e-3) / 1e12, 3),
+                     algorithmic_bytes_per_launch=int(byts / len(recs)),
+                     longest_launch=dict(layer=worst[2], us=round(worst[0].elapsed_time(worst[1]) * 1e3, 1)),
+                     note="aggregate over all launches of the kernel in a frame: sum of FLOPs over sum of event times; traffic and "
+                          "algorithmic bytes are averages over the same launches")
+            ig = _in_graph(name)
+            if ig is not None:
+                d["in_graph_ms_per_frame"] = ig
+                d["in_graph_frac"] = round(executed / passes / (ig * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)
+            return d
 
-        wino = _dense(wino_rec, "srf_wino3x3_k (Winograd F(2x2,3x3), every 3x3 / stride 1 convolution of VoVNet-99, the image FPN and "
-                                "img_convs; `achieved` counts the FLOPs it executes on the MFMA = direct FLOPs / 2.25)", "wino3x3")
-        gemm = _dense(gemm_rec, "srf_conv1x1_nhwc_k (the OSA concat 1x1 convolutions and the FPN laterals as one GEMM each)", "conv1x1")
-        if wino is not None:   # LC: the camera branch dominates the frame, its Winograd kernel is the dominant kernel
-            roofline = wino
+        def _stream(recs, kernel, name, passes=1):
+            """an HBM-bound kernel: algorithmic bytes over event time against the 8 TB/s peak"""
+            if not recs:
+                return None
+            t_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            byts = sum(r[5] for r in recs)
+            ach = byts / (t_ms * 1e-3) / 1e9
+            d = dict(kernel=kernel, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                     traffic=_traffic(name), launches=len(recs), avg_us=round(t_ms * 1e3 / len(recs), 2),
+                     serial_ms_per_frame=round(t_ms / passes, 3), measured=dense_source, algorithmic_bytes_per_launch=int(byts / len(recs)))
+            ig = _in_graph(name)
+            if ig is not None:
+                d["in_graph_ms_per_frame"] = ig
+            return d
+
+        cam_passes = 3 if dense_source != roofline_source else max(1, args.steps)
+        w43m = _dense(w43m_rec, "srf_wino43_mm_k (Winograd F(4x4,3x3) multiply + output transform: every 3x3 / stride 1 convolution of "
+                                "VoVNet-99 from 96 input channels up, the image FPN and img_convs; `achieved` counts the FLOPs it executes "
+                                "on the MFMA = direct FLOPs / 4)", "wino43mm", cam_passes)
+        xform = _stream(w43x_rec, "srf_wino43_xform_k (input transform V = B^T d B of the same layers: reads the input once, writes 2.25x)",
+                        "wino43xf", cam_passes)
+        wino = _dense(wino_rec, "srf_wino3x3_k (Winograd F(2x2,3x3): the 3x3 layers below 96 input channels -- VoVNet stem_2; `achieved` "
+                                "counts the FLOPs it executes on the MFMA = direct FLOPs / 2.25)", "wino3x3", cam_passes)
+        gemm = _dense(gemm_rec, "srf_conv1x1_nhwc_k (the OSA concat 1x1 convolutions and the FPN laterals as one GEMM each)", "conv1x1",
+                      cam_passes)
+        if w43m is not None or wino is not None:   # LC: the camera branch dominates the frame
+            roofline = w43m if w43m is not None else wino
+            if w43m is not None:
+                roofline["xform"] = xform
+                roofline["wino23"] = wino
             roofline["gemm"] = gemm
             roofline["spconv128"] = spconv128
         else:
@@ -275,15 +333,21 @@ def main():
             import ctypes
             ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
             pts = frames[0].cpu().numpy()
-            tc = time.perf_counter()
-            nfr = 0
-            while nfr < 1 or (time.perf_counter() - tc < 10.0 and nfr < 3):
-                pipeline.forward_to_decode(model_cpu, [pts], metas, img.cpu() if img is not None else None)
-                nfr += 1
-            dt = time.perf_counter() - tc
-            cpu_baseline = dict(value=round(nfr / dt, 4), unit="frames/s", cores=cores, kind="port",
-                                sample=f"{nfr} frame(s) of the same workload through oracle/pipeline.py "
-                                       f"(C/OpenMP operators + torch-CPU dense layers), {dt:.1f} s")
+            img_cpu = img.cpu() if img is not None else None
+            # warm-up, then the median of several frames.  One warm-up frame (page-in, torch-CPU / OpenMP thread pools),
+            # then 3 timed frames (LC: ~15 s each), bounded to about a minute
+            pipeline.forward_to_decode(model_cpu, [pts], metas, img_cpu)
+            times = []
+            t_all = time.perf_counter()
+            while len(times) < 3 and (not times or time.perf_counter() - t_all < 60.0):
+                tc = time.perf_counter()
+                pipeline.forward_to_decode(model_cpu, [pts], metas, img_cpu)
+                times.append(time.perf_counter() - tc)
+            med = sorted(times)[len(times) // 2]
+            cpu_baseline = dict(value=round(1.0 / med, 4), unit="frames/s", cores=cores, kind="port",
+                                sample=f"median of {len(times)} frame(s) after 1 warm-up frame of the same workload through "
+                                       f"oracle/pipeline.py (C/OpenMP operators + torch-CPU dense layers); frames took "
+                                       + ", ".join(f"{t:.2f}" for t in times) + " s")
         total_frames = args.steps * world
         out = dict(metric=f"frames/sec, {wl['cfg']} synthetic {n_points // 1000}k-pt sweeps", value=round(total_frames / elapsed, 3),
                    unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -294,7 +358,7 @@ def main():
                                frames_per_rank=args.steps, hip_graph_tail=not args.eager,
                                whole_frame_graph=bool(getattr(model, "_graphed_frame", None) is not None), img_branch_overlap=bool(args.img_overlap and model.use_img),
                                img_features_precomputed=bool(args.img_precomputed and model.use_img),
-                               img_branch="channels-last on srf_wino3x3 / srf_conv1x1_nhwc" if (model.use_img and nhwc_on) else ("MIOpen" if model.use_img else None),
+                               img_branch=("channels-last on srf_wino43 / srf_wino3x3 / srf_conv1x1_nhwc" if nhwc.wino43_enabled() else "channels-last on srf_wino3x3 / srf_conv1x1_nhwc") if (model.use_img and nhwc_on) else ("MIOpen" if model.use_img else None),
                                graph_validation_failures=len(graphs.VALIDATION_LOG),
                                weights="seeded random init, randomised BN statistics",
                                parallelism=f"replica per GPU x{world}, frames sharded, no data-path collective"),

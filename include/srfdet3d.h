@@ -372,6 +372,14 @@ size_t srf_wino43_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int srf_wino43(const float *x, int N, int H, int W, int Cin, long long x_ld, const float *U_packed, int Cout, const float *scale,
                const float *shift, int relu, float *y, long long y_ld, void *workspace, size_t workspace_bytes, srf_stream_t stream);
 
+/* The two kernels of srf_wino43 as separate calls, for callers that time them apart (bench.py's roofline: the transform is
+ * HBM-bound, the multiply MFMA-bound) or order other work between them.  Same arguments and limits; SRF_EUNSUPPORTED when the
+ * layer's transformed input exceeds one workspace slab (srf_wino43 then runs it in several). */
+int srf_wino43_transform(const float *x, int N, int H, int W, int Cin, long long x_ld, int Cout, void *workspace, size_t workspace_bytes,
+                         srf_stream_t stream);
+int srf_wino43_multiply(const void *workspace, size_t workspace_bytes, int N, int H, int W, int Cin, const float *U_packed, int Cout,
+                        const float *scale, const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream);
+
 /* srf_conv1x1_nhwc: Conv2d(K, Cout, 1) on channels-last activations = the GEMM y[p][co] = sum_k x[p][k] W[co][k] over
  * M = N * H * W pixels, then y = y * scale[co] + shift[co] (either may be NULL) and an optional ReLU: the `concat` layer of
  * VoVNet's OSA blocks read straight from the block's concat buffer (vovnet.py:222-223) and the FPN lateral convolutions.

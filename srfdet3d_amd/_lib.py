@@ -85,6 +85,8 @@ SIGNATURES = {
     "srf_wino43_pack_weights": (c_int, [_P, c_int, c_int, _P, _P]),
     "srf_wino43_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "srf_wino43": (c_int, [_P, c_int, c_int, c_int, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_longlong, _P, c_size_t, _P]),
+    "srf_wino43_transform": (c_int, [_P, c_int, c_int, c_int, c_int, c_longlong, c_int, _P, c_size_t, _P]),
+    "srf_wino43_multiply": (c_int, [_P, c_size_t, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, c_longlong, _P]),
     "srf_wino3x3_packed_weight_bytes": (c_size_t, [c_int, c_int]),
     "srf_wino3x3_pack_weights": (c_int, [_P, c_int, c_int, _P, _P]),
     "srf_wino3x3": (c_int, [_P, c_int, c_int, c_int, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_longlong, _P]),

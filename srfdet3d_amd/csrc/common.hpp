@@ -65,9 +65,11 @@ __device__ __forceinline__ int srf_table_find(const uint32_t *__restrict__ keys,
 }
 
 // ---------------------------------------------------------------------------------------------
-// device fill.  A kernel, not hipMemsetAsync: memset NODES of a captured hipGraph stopped taking effect on replay once
-// other work had run between replays (ROCm 7.2; the whole-frame graph then saw stale hash tables), and a kernel node
-// costs the same.  nbytes must be a multiple of 4 and ptr 4-byte aligned (every use here is).
+// device fill as a kernel: the library enqueues nothing but kernel nodes into a captured hipGraph (a kernel node costs the same
+// as a memset node).  Round 1 introduced it as a workaround for "memset nodes not taking effect on replay"; that diagnosis was
+// withdrawn (tools/micro/graph_memset.hip: 0 of 120 replays wrong) -- the fill kernel stays because it is
+// what every graph of this library has been validated with.  nbytes must be a multiple of 4 and ptr 4-byte aligned (every
+// use here is).
 // ---------------------------------------------------------------------------------------------
 static __global__ __launch_bounds__(256) void srf_fill_words_k(uint32_t *__restrict__ p, uint32_t v, size_t nwords)
 {

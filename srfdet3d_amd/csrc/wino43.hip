@@ -622,3 +622,35 @@ extern "C" int srf_wino43(const float *x, int N, int H, int W, int Cin, long lon
     }
     return SRF_OK;
 }
+
+// The two kernels of a layer as separate calls (measurement: bench.py times them apart; a caller that wants to overlap the
+// HBM-bound transform with other work).  Whole layer in one slab only: SRF_EUNSUPPORTED when srf_wino43 would cut it.
+extern "C" int srf_wino43_transform(const float *x, int N, int H, int W, int Cin, long long x_ld, int Cout, void *workspace,
+                                    size_t workspace_bytes, srf_stream_t stream)
+{
+    W43Args a;
+    // U, y stand-ins pass the pointer checks of the shared argument builder; the transform kernel reads neither
+    const int rc = w43_make_args(a, x, N, H, W, Cin, x_ld, (const float *)workspace, Cout, nullptr, nullptr, 0, (float *)workspace,
+                                 (long long)((Cout + 3) & ~3), workspace, workspace_bytes);
+    if (rc != SRF_OK || N == 0) return rc;
+    if (w43_slab_tb(a.ntb, a.nchunk, a.ncb) < a.ntb) return SRF_EUNSUPPORTED;
+    W43Args s;
+    const int r0 = w43_slab_args(a, 0, a.ntb, s);
+    if (r0 != SRF_OK) return r0;
+    return w43_launch_xform(s, (hipStream_t)stream);
+}
+
+extern "C" int srf_wino43_multiply(const void *workspace, size_t workspace_bytes, int N, int H, int W, int Cin, const float *U_packed,
+                                   int Cout, const float *scale, const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream)
+{
+    W43Args a;
+    const int rc = w43_make_args(a, (const float *)workspace, N, H, W, Cin, (long long)Cin, U_packed, Cout, scale, shift, relu, y, y_ld,
+                                 const_cast<void *>(workspace), workspace_bytes);
+    if (rc != SRF_OK || N == 0) return rc;
+    if (w43_slab_tb(a.ntb, a.nchunk, a.ncb) < a.ntb) return SRF_EUNSUPPORTED;
+    W43Args s;
+    a.x_ld = 4;   // x is not read by the multiply kernel; keep the slab's 32-bit extent check on y alone
+    const int r0 = w43_slab_args(a, 0, a.ntb, s);
+    if (r0 != SRF_OK) return r0;
+    return w43_launch_mm(s, (hipStream_t)stream);
+}

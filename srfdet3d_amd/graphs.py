@@ -29,19 +29,18 @@ def _graph_safe_convs(safe=True):
     under this context (see `_capture_with_fallback`), because deterministic algorithms can be slower for some shapes
     (Waymo's 192 x 192 BEV maps: -15 % frames/s).
 
-    MIOpen's split-K implicit-GEMM kernels (`..._gkgs`) accumulate with atomics into an output that MIOpen first clears
-    with hipMemsetAsync.  Captured, that clear becomes a graph MEMSET NODE, and on this ROCm memset nodes do not reliably
-    take effect on replay (the same defect that made this library replace its own memsets by fill kernels): the
-    convolution then keeps adding to the previous replay's output -- correct on the first replay, wrong by a constant
-    amount from the second on.  Those kernels are non-deterministic, so asking for deterministic algorithms keeps
-    MIOpen away from them inside graphs; eager execution is unaffected."""
+    MIOpen's split-K implicit-GEMM kernels (`..._gkgs`) accumulate with float atomics: their results differ from run to run
+    in the last bits and, captured, broke the replay check in round 1.  Asking for deterministic algorithms keeps MIOpen
+    away from them inside graphs; eager execution is unaffected.  (Round 1 blamed memset nodes not taking effect on replay;
+    tools/micro/graph_memset.hip shows they do -- DESIGN.md section 3 -- the cause inside the library is not established.
+    Since round 2 no MIOpen convolution is left on the fp32 inference path, so this retry only serves the module path.)"""
     if not safe:
         import contextlib
         return contextlib.nullcontext()
     return torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True)
 
 
-VALIDATION_LOG = []  # one entry per capture whose 3-replay validation failed: (what, attempt, message); bench.py reports it
+VALIDATION_LOG = []  # one (attempt, message) entry per capture whose 3-replay validation failed; bench.py reports the count
 
 
 def _capture_with_fallback(capture):
@@ -66,9 +65,9 @@ class GraphValidationError(RuntimeError):
 
 def _validate(graph, outputs, reference, what, rtol=1e-3, atol=1e-4):
     """Replay a freshly captured graph THREE times on unchanged inputs and require every replay to reproduce the eager
-    result.  A captured library call that depends on a memset node (see _graph_safe_convs / dense.linear_graph_safe) is
-    right on the first replay and wrong afterwards; this turns that silent corruption into an error at capture time, and
-    the caller falls back to eager execution."""
+    result.  A captured library call whose result depends on state left by the previous replay (an accumulate-into-output
+    kernel behind a clear that did not run, an atomics-based reduction) is right on the first replay and wrong afterwards;
+    this turns that silent corruption into an error at capture time, and the caller falls back to eager execution."""
     for rep in range(3):
         graph.replay()
         torch.cuda.synchronize()

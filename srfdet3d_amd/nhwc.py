@@ -114,6 +114,11 @@ def wino_ok(conv, cin):
     return _is_conv(conv, 3) and cin % 8 == 0
 
 
+def _img_fits(H, W, ld):
+    """One image of an (N, H, W, ld) f32 buffer inside the 2^30-byte per-image range of srf_wino3x3 (ops.wino3x3_supported)."""
+    return 4 * H * W * ld < (1 << 30)
+
+
 def gemm_ok(conv, cin):
     return _is_conv(conv, 1) and cin % 32 == 0
 
@@ -144,6 +149,21 @@ def vovnet_supported(net, x):
             and c0.out_channels == 64 and c6.kernel_size == (3, 3) and c6.stride == (2, 2) and c6.padding == (1, 1)
             and strided_ok(c6, c6.in_channels)):
         return False
+    # every buffer the executor makes must fit the kernels' per-image 32-bit offsets (ops.wino3x3_supported: 4 H W ld < 2^30)
+    H, W = (x.shape[2] - 1) // 2 + 1, (x.shape[3] - 1) // 2 + 1          # after stem_1
+    if not _img_fits(H, W, 64):
+        return False
+    H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1                              # after stem_3
+    for name in net.stage_names:
+        for m in getattr(net, name).children():
+            if isinstance(m, nn.MaxPool2d):
+                H, W = ops.pool3s2_out(H), ops.pool3s2_out(W)
+            elif isinstance(m, OSAModule):
+                convs = [_cbr(layer) for layer in m.layers]
+                if any(c is None for c in convs):
+                    return False
+                if not _img_fits(H, W, convs[0][0].in_channels + sum(c[0].out_channels for c in convs)):
+                    return False
     for name in net.stage_names:
         for m in getattr(net, name).children():
             if isinstance(m, nn.MaxPool2d):
@@ -270,6 +290,9 @@ def to_nhwc(x):
 def second_supported(net, x):
     if not (fusable(x) and x.dim() == 4 and x.shape[1] % 8 == 0):
         return False
+    widest = max([x.shape[1]] + [m.out_channels for st in net.blocks for m in st.children() if isinstance(m, nn.Conv2d)])
+    if not _img_fits(x.shape[2], x.shape[3], widest):
+        return False
     for stage in net.blocks:
         mods = list(stage.children())
         if len(mods) % 3:
@@ -318,6 +341,12 @@ def fpn_supported(fpn, inputs):
         return False
     for x, lat, fc in zip(inputs, fpn.lateral_convs, list(fpn.fpn_convs)[:n]):
         if not (fusable(x) and is_channels_last(x)):
+            return False
+        try:   # a channels-last view that is not a channel slice of a pixel-major buffer (or too large) goes to the module path
+            ld = ops.nhwc_ld(nhwc_view(x))
+        except RuntimeError:
+            return False
+        if ld % 4 or x.data_ptr() % 16 or not _img_fits(x.shape[2], x.shape[3], max(ld, lat.conv.out_channels)):
             return False
         for cm in (lat, fc):
             if cm.with_activation and not isinstance(cm.activate, nn.ReLU):

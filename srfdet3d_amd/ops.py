@@ -1017,17 +1017,30 @@ def wino43(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None)
     ws = _empty((ws_bytes // 4,), torch.float32, x.device)
     sc = None if scale is None else _aligned16(_dev(scale, "scale", torch.float32))
     sh = None if shift is None else _aligned16(_dev(shift, "shift", torch.float32))
-    timing = _dense_timing("wino")
-    check(L.srf_wino43(_ptr(x), N, H, W, Cin, x_ld, _ptr(packed_weight), Cout, None if sc is None else _ptr(sc),
-                       None if sh is None else _ptr(sh), int(bool(relu)), _ptr(out), y_ld, _ptr(ws), ws_bytes, _stream()), "wino43")
-    if timing is not None:
-        ev1 = torch.cuda.Event(enable_timing=True)
-        ev1.record()
-        # direct-convolution FLOPs, FLOPs executed on the MFMA (36 products per 16 outputs = direct / 4), algorithmic bytes:
-        # in + out + weights + V written and read once (2.25x the input each way)
-        direct = 2.0 * 9 * Cin * Cout * N * H * W
-        timing[1].append((timing[0], ev1, f"{Cin}->{Cout} @{N}x{H}x{W} F(4,3)", direct, direct / 4.0,
-                          4.0 * N * H * W * (Cin + Cout) + 4.0 * 36 * Cin * Cout + 2.0 * ws_bytes))
+    scp, shp = None if sc is None else _ptr(sc), None if sh is None else _ptr(sh)
+    timing = _dense_timing("w43m")
+    if timing is None:
+        check(L.srf_wino43(_ptr(x), N, H, W, Cin, x_ld, _ptr(packed_weight), Cout, scp, shp, int(bool(relu)), _ptr(out), y_ld, _ptr(ws),
+                           ws_bytes, _stream()), "wino43")
+        return out
+    # bench.py asked for per-launch times: the transform (HBM-bound) and the multiply (MFMA-bound) as separate calls
+    rc = L.srf_wino43_transform(_ptr(x), N, H, W, Cin, x_ld, Cout, _ptr(ws), ws_bytes, _stream())
+    if rc != 0:   # a layer cut into slabs cannot be timed apart
+        check(L.srf_wino43(_ptr(x), N, H, W, Cin, x_ld, _ptr(packed_weight), Cout, scp, shp, int(bool(relu)), _ptr(out), y_ld, _ptr(ws),
+                           ws_bytes, _stream()), "wino43")
+        return out
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev1.record()
+    check(L.srf_wino43_multiply(_ptr(ws), ws_bytes, N, H, W, Cin, _ptr(packed_weight), Cout, scp, shp, int(bool(relu)), _ptr(out), y_ld,
+                                _stream()), "wino43_multiply")
+    ev2 = torch.cuda.Event(enable_timing=True)
+    ev2.record()
+    direct = 2.0 * 9 * Cin * Cout * N * H * W
+    label = f"{Cin}->{Cout} @{N}x{H}x{W}"
+    # transform: reads the input once, writes V (2.25x the input, padded to whole tile blocks)
+    KERNEL_TIMING["w43x"].append((timing[0], ev1, label, 0.0, 0.0, 4.0 * N * H * W * Cin + ws_bytes))
+    # multiply: executes direct / 4 FLOPs on the MFMA; reads V and U once, writes the output
+    timing[1].append((ev1, ev2, label, direct, direct / 4.0, float(ws_bytes) + 4.0 * 36 * Cin * Cout + 4.0 * N * H * W * Cout))
     return out
 
 
@@ -1177,9 +1190,26 @@ def conv_gemm_nhwc(x, packed_weight, Cout, ksize, stride, pad, scale=None, shift
     L = _lib.lib()
     if packed_weight.numel() * 4 != L.srf_conv1x1_nhwc_packed_weight_bytes(Cout, kh * kw * Cin):
         raise ValueError("conv_gemm_nhwc: packed weight does not match the layer")
-    check(L.srf_conv_gemm_nhwc(_ptr(x), N, H, W, Cin, x_ld, _ptr(packed_weight), Cout, kh, kw, stride, pad, _opt(scale, "scale"),
-                               _opt(shift, "shift"), int(bool(relu)), _ptr(out), nhwc_ld(out), _stream()), "conv_gemm_nhwc")
+    # the kernel addresses its whole input through ONE 32-bit buffer descriptor (N H W x_ld 4 < 2^31 bytes): larger batches
+    # run in groups of images (VoVNet stem_3 reads 464 x 800 x 64 per camera: 23 images reach the limit -- LC inference at
+    # batch 4, the frozen prefix of config 4 at bs >= 4)
+    per_img = 4 * H * W * x_ld
+    group = N if N * per_img < (1 << 31) else max(1, ((1 << 31) - 1) // per_img)
+    sc, sh = _opt(scale, "scale"), _opt(shift, "shift")
+    for n0 in range(0, max(N, 1), max(group, 1)):
+        xs, os_ = x[n0:n0 + group], out[n0:n0 + group]
+        check(L.srf_conv_gemm_nhwc(_ptr(xs), xs.shape[0], H, W, Cin, x_ld, _ptr(packed_weight), Cout, kh, kw, stride, pad, sc, sh,
+                                   int(bool(relu)), _ptr(os_), nhwc_ld(out), _stream()), "conv_gemm_nhwc")
     return out
+
+
+def conv_gemm_nhwc_supported(x):
+    """Layout / size limits of srf_conv_gemm_nhwc as `conv_gemm_nhwc` drives it (batches are split, one image must fit)."""
+    try:
+        ld = nhwc_ld(x)
+    except RuntimeError:
+        return False
+    return x.shape[3] % 32 == 0 and ld % 4 == 0 and x.data_ptr() % 16 == 0 and 4 * x.shape[1] * x.shape[2] * ld < (1 << 31)
 
 
 def stem_conv_nchw(x, weight, scale=None, shift=None, relu=False, out=None):

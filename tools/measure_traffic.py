@@ -4,9 +4,9 @@
 `--pmc` passes (each with --kernel-trace only), read bytes = 2 x FETCH_SIZE x 1024 on gfx950 (128-B requests are tallied
 as 64 B), WRITE_SIZE x 1024 exact.  Run on the GPU box from the repo root:
 
-    python tools/measure_traffic.py            # writes gpurun_out/traffic/r02_pmc_<name>_traffic.json
+    python tools/measure_traffic.py            # writes gpurun_out/traffic/r03_pmc_<name>_traffic.json
 
-and copy the files into profiles/ (bench.py reads profiles/r02_pmc_<name>_traffic.json -> roofline.traffic).
+and copy the files into profiles/ (bench.py reads profiles/r03_pmc_<name>_traffic.json -> roofline.traffic).
 This process never touches the GPU itself: every pass is `rocprofv3 ... -- python3 <tool>` started as a child.
 """
 import csv
@@ -23,11 +23,18 @@ SQ = ("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY S
       "SQ_LDS_BANK_CONFLICT").split()
 
 # name -> (program after `--`, kernel-name substring, description, algorithmic bytes note)
+ROUND = "r03"
 TARGETS = {
+    "wino43mm": (["tools/prof_img_branch.py", "3"], ("srf_wino43_mm_k<",),
+                 "every srf_wino43_mm_k launch of 3 eager passes of the LC camera branch (88 per frame: VoVNet-99 from stage 2 on, image FPN, img_convs)"),
+    "wino43xf": (["tools/prof_img_branch.py", "3"], ("srf_wino43_xform_k",),
+                 "every srf_wino43_xform_k launch of the same passes (one per F(4x4,3x3) layer)"),
     "wino3x3": (["tools/prof_img_branch.py", "3"], ("srf_wino3x3_k<", "srf_wino3x3_mixed_k<"),
-                "every srf_wino3x3_k launch of 3 eager passes of the LC camera branch (89 per frame: VoVNet-99, image FPN, img_convs)"),
-    "conv1x1": (["tools/prof_img_branch.py", "3"], ("srf_conv1x1_nhwc_k<2, 2, 3, false>", "srf_conv1x1_nhwc_mixed_k"),
-                "every 128 x 128-tile srf_conv1x1_nhwc launch of the same passes, one-size or mixed-tile form (OSA concat convolutions + FPN laterals)"),
+                "every srf_wino3x3_k launch of the same passes (the layers left on F(2x2,3x3): VoVNet stem_2)"),
+    "conv1x1": (["tools/prof_img_branch.py", "3"], ("srf_conv1x1_nhwc_k<1, 1, 4, false>", "srf_conv1x1_nhwc_k<2, 2, 3, false>",
+                                                     "srf_conv1x1_nhwc_k<4, 4, 1, false>", "srf_conv1x1_nhwc_mixed_k"),
+                "EVERY srf_conv1x1_nhwc launch of the same passes, whatever its tile form (20 per frame: OSA concat convolutions + FPN "
+                "laterals) -- the launch set bench.py's roofline.gemm aggregates"),
     "spconv128": (["tools/bench_spconv.py", "--levels", "4", "--reps", "8"], "srf_spconv_gs_k<4, 128>",
                   "SubM 128->128 on the 5x184x184 level of frame 2000 (A=34992), BN + residual + ReLU epilogue"),
     "spconv64": (["tools/bench_spconv.py", "--levels", "3", "--reps", "8"], "srf_spconv_gs_k<2, 64>",
@@ -66,6 +73,16 @@ def durations_of(d, sub):
     return ts
 
 
+def source_id():
+    """sha of the kernel sources (bench.py quotes a counter file only for the build it was measured on)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "srfdet3d_amd", "csrc", "*.h*"))):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     want = sys.argv[1:] or list(TARGETS)
     os.makedirs(OUT, exist_ok=True)
@@ -92,6 +109,7 @@ def main():
         dur = durations_of(ds, sub)
         out = {
             "kernel": " | ".join(sub) if isinstance(sub, tuple) else sub, "workload": desc, "launches_averaged": n,
+            "kernel_source_sha16": source_id(),
             "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb,
             "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B -> read bytes = 2 * FETCH_SIZE * 1024 "
                           "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
@@ -105,7 +123,7 @@ def main():
         if s.get("SQ_VALU_MFMA_BUSY_CYCLES") and s.get("SQ_BUSY_CYCLES"):
             # SQ_BUSY_CYCLES is summed over the 32 shader engines, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
             out["derived"] = {"mfma_busy_fraction_per_simd": round(s["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (s["SQ_BUSY_CYCLES"] / 32), 4)}
-        path = os.path.join(OUT, f"r02_pmc_{name}_traffic.json")
+        path = os.path.join(OUT, f"{ROUND}_pmc_{name}_traffic.json")
         with open(path, "w") as fh:
             json.dump(out, fh, indent=1)
         print(name, json.dumps({k: out[k] for k in ("launches_averaged", "traffic_bytes_per_launch", "avg_duration_us_under_pmc")}), flush=True)
