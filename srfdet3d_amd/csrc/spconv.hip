@@ -334,6 +334,29 @@ __global__ __launch_bounds__(256) void srf_pack_weights_k(const float *__restric
     P[t] = c < Cin ? W[((size_t)k * Cin + c) * Cout + col] : 0.0f;
 }
 
+// wave-private layout of the 32-output-channel layers (srf_spconv_w32_k below): [k][group of 4 steps][channel parity][col 32][4]
+static bool srf_w32_layout(int K, int Cin, int Cout)
+{
+    static const bool off = [] {
+        const char *e = getenv("SRF_SPCONV_W32");  // developer switch: 0 = the LDS-staged tile kernel, for A/B timing
+        return e && e[0] == '0';
+    }();
+    return !off && K == SRF_KMAX && Cout == 32 && (Cin == 16 || Cin == 32);
+}
+
+__global__ __launch_bounds__(256) void srf_pack_weights_w32_k(const float *__restrict__ W, int K, int Cin, float *__restrict__ P)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int total = K * Cin * 32;
+    if (t >= total) return;
+    const int nb = Cin / 8;
+    const int i = t & 3, col = (t >> 2) & 31, kh = (t >> 7) & 1;
+    const int rest = t >> 8;
+    const int sg = rest % nb, k = rest / nb;
+    const int c = 2 * (4 * sg + i) + kh;   // MFMA step 4 sg + i multiplies the channels 2 s (lanes 0-31) and 2 s + 1 (lanes 32-63)
+    P[t] = W[((size_t)k * Cin + c) * 32 + col];
+}
+
 extern "C" size_t srf_spconv_packed_weight_bytes(int K, int Cin, int Cout)
 {
     if (K <= 0 || Cin <= 0 || Cout <= 0) return 0;
@@ -345,7 +368,10 @@ extern "C" int srf_spconv_pack_weights(const float *W, int K, int Cin, int Cout,
     if (!W || !packed || K <= 0 || K > SRF_KMAX || Cin <= 0 || Cout <= 0) return SRF_EINVAL;
     const int nchunk = (Cin + 31) / 32;
     const long long total = (long long)K * nchunk * Cout * 32;
-    if (srf_gs_layout(Cin, Cout))
+    if (srf_w32_layout(K, Cin, Cout))
+        hipLaunchKernelGGL(srf_pack_weights_w32_k, dim3(srf_ceil_div((long long)K * Cin * 32, 256)), dim3(256), 0, (hipStream_t)stream, W, K,
+                           Cin, packed);
+    else if (srf_gs_layout(Cin, Cout))
         hipLaunchKernelGGL(srf_pack_weights_gs_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, W, K, Cin,
                            Cout, nchunk, packed);
     else if (srf_direct_layout(Cin, Cout))
@@ -1298,6 +1324,113 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
     }
 }
 
+// =====================================================================================================================
+// srf_spconv_w32_k: the 32-output-channel layers (SubM 32 -> 32 x 4 and the strided 16 -> 32 of the nuScenes encoder,
+// sparse_encoder_custom.py:109-140 through spconv's SubMConv3d / SparseConv3d) -- 2 GFLOP per frame that took 0.33 ms: the
+// tile kernel above walks its 27 offsets as gather -> LDS -> barrier -> 16 MFMAs with one step of lookahead, i.e. at the
+// latency of a gather per step (2.4 us) whatever the arithmetic.  Here nothing is shared but the weights:
+//   * a workgroup = 8 waves x 32 output rows; all 27 x Cin x 32 weights sit in LDS (110 KB at Cin = 32), copied once;
+//   * every wave gathers ITS 32 rows straight into the MFMA's A layout -- lane (row, half) loads half of the neighbour's
+//     channels with Cin / 8 buffer_load_dwordx4 (a missing neighbour is an out-of-range offset and reads as zero), then
+//     v_permlane32_swap hands the odd channels to lanes 32-63 and the even ones to lanes 0-31 (the f32 32x32x2 MFMA takes
+//     channel 2 s from lanes 0-31 and 2 s + 1 from lanes 32-63) -- three offsets in flight, no barrier, no LDS round trip;
+//   * offsets none of the wave's rows has are skipped (one ballot per offset).
+// Every output is the same chain as before (offset ascending, channel ascending, zero terms added as +0): bit-identical to
+// the tile kernel and the oracle.
+// =====================================================================================================================
+template <int CIN>
+__global__ __launch_bounds__(512) void srf_spconv_w32_k(const float *__restrict__ in, int A_in, const float *__restrict__ Wp,
+                                                       const int *__restrict__ nbr, int nbr_stride, int A_out,
+                                                       const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                       const float *__restrict__ residual, int relu, float *__restrict__ out,
+                                                       const int *__restrict__ rows_dev)
+{
+    constexpr int K = SRF_KMAX, H = CIN / 2, NV = H / 4, NB = CIN / 8, TM = 256;
+    extern __shared__ __attribute__((aligned(16))) f32x4 s_w32[];   // [K][NB][2][32]
+    if (rows_dev) {
+        const int live = *rows_dev;
+        A_out = A_out < live ? A_out : live;
+    }
+    const int n_tiles = (A_out + TM - 1) / TM;
+    if ((int)blockIdx.x >= n_tiles) return;
+    const int row0 = srf_xcd_tile(blockIdx.x, n_tiles) * TM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kh = lane >> 5;
+    const int row = row0 + wave * 32 + r;
+    const f32x4 *Wp4 = reinterpret_cast<const f32x4 *>(Wp);
+    for (int i = tid; i < K * NB * 64; i += 512) s_w32[i] = Wp4[i];
+    int idx[K];
+    unsigned anym = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        idx[k] = row < A_out ? nbr[(size_t)k * nbr_stride + row] : -1;
+        anym |= (__ballot(idx[k] >= 0) != 0ull ? 1u : 0u) << k;
+    }
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)((long long)A_in * CIN * 4), 0x00020000);
+    f32x4 a[3][NV];
+#define W32_LOAD(SET, KK)                                                                                    \
+    if (anym & (1u << (KK))) {                                                                               \
+        const unsigned vo_ = idx[KK] >= 0 ? (unsigned)(idx[KK] * (CIN * 4) + kh * (H * 4)) : 0x80000000u;    \
+        _Pragma("unroll") for (int j_ = 0; j_ < NV; ++j_) {                                                  \
+            auto v_ = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(vo_ + j_ * 16), 0, 0);                      \
+            a[SET][j_] = *reinterpret_cast<f32x4 *>(&v_);                                                    \
+        }                                                                                                    \
+    }
+    W32_LOAD(0, 0)
+    W32_LOAD(1, 1)
+    __syncthreads();   // the weights are in LDS
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (k + 2 < K) { W32_LOAD((k + 2) % 3, k + 2) }
+        if (anym & (1u << k)) {
+            f32x4 b[NB];
+#pragma unroll
+            for (int sg = 0; sg < NB; ++sg) b[sg] = s_w32[((k * NB + sg) * 2 + kh) * 32 + r];
+            // lanes 0-31 hold the first half of the row's channels, lanes 32-63 the second: swap so that lanes 0-31 end up with
+            // the even channels (first half in x / z, second half in y / w), lanes 32-63 with the odd ones
+            float e0[NV], e1[NV], o0[NV], o1[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const f32x4 v = a[k % 3][j];
+                auto p0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
+                auto p1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2]), __float_as_uint(v[3]), false, false);
+                e0[j] = __uint_as_float(p0[0]);   // channel 4 j + kh
+                o0[j] = __uint_as_float(p0[1]);   // channel H + 4 j + kh
+                e1[j] = __uint_as_float(p1[0]);   // channel 4 j + 2 + kh
+                o1[j] = __uint_as_float(p1[1]);   // channel H + 4 j + 2 + kh
+            }
+            // steps in channel order: s = 2 j (channels 4 j, 4 j + 1), 2 j + 1; then the second half from step H / 2 on
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e0[j], b[(2 * j) >> 2][(2 * j) & 3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e1[j], b[(2 * j + 1) >> 2][(2 * j + 1) & 3], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(o0[j], b[(H / 2 + 2 * j) >> 2][(H / 2 + 2 * j) & 3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(o1[j], b[(H / 2 + 2 * j + 1) >> 2][(H / 2 + 2 * j + 1) & 3], acc, 0, 0, 0);
+            }
+        }
+    }
+#undef W32_LOAD
+    const float al = alpha ? alpha[r] : 1.0f;
+    const float be = alpha ? beta[r] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int orow = row0 + wave * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+        if (orow < A_out) {
+            float v = acc[j];
+            if (alpha) v = __fmaf_rn(v, al, be);
+            if (residual) v = __fadd_rn(v, residual[(size_t)orow * 32 + r]);
+            if (relu) v = v > 0.0f ? v : 0.0f;
+            out[(size_t)orow * 32 + r] = v;
+        }
+    }
+}
+
 extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const float *W_packed, int K, const int *nbr,
                                      int nbr_stride, int A_out, int Cout, const float *alpha, const float *beta,
                                      const float *residual, int relu, float *out, const int *rows_dev, const int *tiles,
@@ -1312,6 +1445,24 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
 #define SRF_ARGS in, Cin, W_packed, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev
     switch (Cout) {
     case 32:
+        if (srf_w32_layout(K, Cin, Cout) && (long long)A_in * Cin * 4 < (1ll << 31)) {
+            int dev = 0;
+            SRF_HIP_TRY(hipGetDevice(&dev));
+            static bool attr_set[64] = {false};
+            if (dev < 0 || dev >= 64) return SRF_EUNSUPPORTED;
+            if (!attr_set[dev]) {
+                SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_spconv_w32_k<32>, hipFuncAttributeMaxDynamicSharedMemorySize, SRF_KMAX * 32 * 32 * 4));
+                SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_spconv_w32_k<16>, hipFuncAttributeMaxDynamicSharedMemorySize, SRF_KMAX * 16 * 32 * 4));
+                attr_set[dev] = true;
+            }
+            if (Cin == 32)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_w32_k<32>), dim3(srf_ceil_div(A_out, 256)), dim3(512), SRF_KMAX * 32 * 32 * 4, st, in,
+                                   A_in, W_packed, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_w32_k<16>), dim3(srf_ceil_div(A_out, 256)), dim3(512), SRF_KMAX * 16 * 32 * 4, st, in,
+                                   A_in, W_packed, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev);
+            break;
+        }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_packed_k<32, 128, 4, 1>), dim3(srf_ceil_div(A_out, 128)), dim3(256),
                            0, st, SRF_ARGS);
         break;
