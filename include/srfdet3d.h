@@ -389,6 +389,23 @@ size_t srf_conv1x1_nhwc_packed_weight_bytes(int Cout, int K);
 int srf_conv1x1_nhwc_pack_weights(const float *W, int Cout, int K, float *packed, srf_stream_t stream);
 int srf_conv1x1_nhwc(const float *x, long long M, int K, long long x_ld, const float *W_packed, int Cout, const float *scale,
                      const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream);
+/* srf_conv1x1_nhwc_direct*: the same three operations (plain, _topdown, _pooled) on a GEMM kernel whose operands go L2 ->
+ * registers without LDS staging or barriers (csrc/gemm_direct.hip; 128 x 128 tiles only: meant for launches of >= ~1000 tiles,
+ * where it runs at 122-135 TFLOP/s against 110-117 for srf_conv1x1_nhwc).  W_packed comes from
+ * srf_conv1x1_nhwc_direct_pack_weights (a different operand order than srf_conv1x1_nhwc_pack_weights).  Same arguments, limits
+ * and -- output for output -- the same fma chain, i.e. identical bits in y; the pooled mean adds its block sums in a different
+ * (fixed) order.  Workspace of the pooled form: srf_conv1x1_nhwc_pooled_workspace_bytes. */
+size_t srf_conv1x1_nhwc_direct_packed_weight_bytes(int Cout, int K);
+int srf_conv1x1_nhwc_direct_pack_weights(const float *W, int Cout, int K, float *packed, srf_stream_t stream);
+int srf_conv1x1_nhwc_direct(const float *x, long long M, int K, long long x_ld, const float *W_packed, int Cout, const float *scale,
+                            const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream);
+int srf_conv1x1_nhwc_direct_topdown(const float *x, int N, int H, int W, int K, long long x_ld, const float *W_packed, int Cout,
+                                    const float *scale, const float *shift, int relu, const float *top, int Ht, int Wt, long long top_ld,
+                                    float *y, long long y_ld, srf_stream_t stream);
+int srf_conv1x1_nhwc_direct_pooled(const float *x, int N, long long HW, int K, long long x_ld, const float *W_packed, int Cout,
+                                   const float *scale, const float *shift, int relu, float *y, long long y_ld, float *mean, void *workspace,
+                                   size_t workspace_bytes, srf_stream_t stream);
+
 /* srf_conv1x1_nhwc_topdown: an FPN lateral convolution with the top-down step in its epilogue (mmdet FPN.forward:
  * `laterals[i - 1] += F.interpolate(laterals[i], size=..., mode="nearest")`, necks of configs/nus/srfdet_voxel_nusc_LC.py:55-64
  * and :67-76): y[n][py][px][co] = act(conv) + top[n][floor(py Ht / H)][floor(px Wt / W)][co].  x rows are the pixels of an

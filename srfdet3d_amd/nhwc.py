@@ -105,9 +105,16 @@ def conv3x3(x, conv, bn=None, relu=False, out=None):
     return ops.wino3x3(x, _wino_weights(conv), conv.out_channels, scale, shift, relu, out=out)
 
 
+def _gemm_direct_weights(conv):
+    w = conv.weight
+    return _cached(conv, "_srf_gemm_direct", (w._version, w.data_ptr()), lambda: ops.pack_conv1x1_nhwc_direct_weights(w.detach()))
+
+
 def conv1x1(x, conv, bn=None, relu=False, out=None, pool=False, top=None):
     scale, shift = _affine_of(conv, bn)
-    return ops.conv1x1_nhwc(x, _gemm_weights(conv), conv.out_channels, scale, shift, relu, out=out, pool=pool, top=top)
+    # both operand orders are packed lazily: a layer only ever packs the one its launch size selects
+    return ops.conv1x1_nhwc(x, lambda: _gemm_weights(conv), conv.out_channels, scale, shift, relu, out=out, pool=pool, top=top,
+                            packed_direct=lambda: _gemm_direct_weights(conv))
 
 
 def wino_ok(conv, cin):

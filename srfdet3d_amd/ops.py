@@ -1057,11 +1057,40 @@ def pack_conv1x1_nhwc_weights(weight):
     return packed
 
 
-def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None, pool=False, top=None):
+def pack_conv1x1_nhwc_direct_weights(weight):
+    """(Cout, K) or (Cout, K, 1, 1) -> the operand order srf_conv1x1_nhwc_direct streams from L2 (once per layer)."""
+    weight = _dev(weight.reshape(weight.shape[0], -1), "weight", torch.float32)
+    Cout, K = weight.shape
+    L = _lib.lib()
+    nbytes = L.srf_conv1x1_nhwc_direct_packed_weight_bytes(Cout, K)
+    if nbytes == 0:
+        raise ValueError("conv1x1_nhwc: K must be a multiple of 32")
+    packed = _empty((nbytes // 4,), torch.float32, weight.device)
+    check(L.srf_conv1x1_nhwc_direct_pack_weights(_ptr(weight), Cout, K, _ptr(packed), _stream()), "conv1x1_nhwc_direct_pack_weights")
+    return packed
+
+
+GEMM_DIRECT_MIN_TILES = 1024   # 128 x 128 tiles of a launch from which the LDS-free kernel wins (tools/micro/gemm_direct_bench.hip)
+
+
+def conv1x1_direct_wanted(M, Cout):
+    """The LDS-free GEMM (`srf_conv1x1_nhwc_direct`) pays on launches of more than a round of 128 x 128 tiles at three workgroups
+    per CU (VoVNet stages 2-4: 122-135 against 110-117 TFLOP/s); below that the 64 x 64 tiles of `srf_conv1x1_nhwc` fill the chip
+    better (stage 5: 104 against 93).  SRF_GEMM_DIRECT=0 / 1 forces the choice (A/B switch for tests and benchmarks)."""
+    import os
+    force = os.environ.get("SRF_GEMM_DIRECT")
+    if force is not None:
+        return force != "0"
+    return ((M + 127) // 128) * ((Cout + 127) // 128) >= GEMM_DIRECT_MIN_TILES
+
+
+def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None, pool=False, top=None, packed_direct=None):
     """1x1 convolution of the NHWC slice x (N, H, W, K) + per-channel scale / shift + ReLU into `out` ((N, H, W, Cout) slice
     of an NHWC buffer; new contiguous tensor when None).  pool=True: returns (out, mean (N, Cout) over the pixels of each
     image) from the same pass (`srf_conv1x1_nhwc_pooled`).  top: an (N, Ht, Wt, Cout) NHWC slice whose nearest-neighbour
-    upsampling to (H, W) is added to the result in the epilogue (`srf_conv1x1_nhwc_topdown`: the FPN top-down step)."""
+    upsampling to (H, W) is added to the result in the epilogue (`srf_conv1x1_nhwc_topdown`: the FPN top-down step).
+    packed_direct: the same weight packed by `pack_conv1x1_nhwc_direct_weights`, or a callable returning it; large launches then
+    run on the LDS-free kernel (`srf_conv1x1_nhwc_direct*`: the same bits in `out`)."""
     x_ld = nhwc_ld(x)
     N, H, W, K = x.shape
     if out is None:
@@ -1070,8 +1099,19 @@ def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out
         raise ValueError("conv1x1_nhwc: out has the wrong shape")
     y_ld = nhwc_ld(out)
     L = _lib.lib()
-    if packed_weight.numel() * 4 != L.srf_conv1x1_nhwc_packed_weight_bytes(Cout, K):
-        raise ValueError("conv1x1_nhwc: packed weight does not match (Cout, K)")
+    direct = packed_direct is not None and conv1x1_direct_wanted(N * H * W, Cout) and max(x_ld, y_ld) * 512 < (1 << 31)
+    if direct:
+        if callable(packed_direct):
+            packed_direct = packed_direct()
+        if packed_direct.numel() * 4 != L.srf_conv1x1_nhwc_direct_packed_weight_bytes(Cout, K):
+            raise ValueError("conv1x1_nhwc: direct-packed weight does not match (Cout, K)")
+        wp = _ptr(packed_direct)
+    else:
+        if callable(packed_weight):
+            packed_weight = packed_weight()
+        if packed_weight.numel() * 4 != L.srf_conv1x1_nhwc_packed_weight_bytes(Cout, K):
+            raise ValueError("conv1x1_nhwc: packed weight does not match (Cout, K)")
+        wp = _ptr(packed_weight)
     timing = _dense_timing("gemm")
     sc = None if scale is None else _ptr(_dev(scale, "scale", torch.float32))
     sh = None if shift is None else _ptr(_dev(shift, "shift", torch.float32))
@@ -1079,22 +1119,25 @@ def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out
     if top is not None:
         if pool or top.dim() != 4 or top.shape[0] != N or top.shape[3] != Cout:
             raise ValueError("conv1x1_nhwc: top must be (N, Ht, Wt, Cout) and excludes pool")
-        check(L.srf_conv1x1_nhwc_topdown(_ptr(x), N, H, W, K, x_ld, _ptr(packed_weight), Cout, sc, sh, int(bool(relu)), _ptr(top),
-                                         top.shape[1], top.shape[2], nhwc_ld(top), _ptr(out), y_ld, _stream()), "conv1x1_nhwc_topdown")
+        fn = L.srf_conv1x1_nhwc_direct_topdown if direct else L.srf_conv1x1_nhwc_topdown
+        check(fn(_ptr(x), N, H, W, K, x_ld, wp, Cout, sc, sh, int(bool(relu)), _ptr(top), top.shape[1], top.shape[2], nhwc_ld(top), _ptr(out),
+                 y_ld, _stream()), "conv1x1_nhwc_topdown")
     elif pool:
         mean = _empty((N, Cout), torch.float32, x.device)
         nbytes = L.srf_conv1x1_nhwc_pooled_workspace_bytes(N, H * W, Cout)
         ws = _empty((max(nbytes, 4) // 4,), torch.float32, x.device)
-        check(L.srf_conv1x1_nhwc_pooled(_ptr(x), N, H * W, K, x_ld, _ptr(packed_weight), Cout, sc, sh, int(bool(relu)), _ptr(out), y_ld,
-                                        _ptr(mean), _ptr(ws), nbytes, _stream()), "conv1x1_nhwc_pooled")
+        fn = L.srf_conv1x1_nhwc_direct_pooled if direct else L.srf_conv1x1_nhwc_pooled
+        check(fn(_ptr(x), N, H * W, K, x_ld, wp, Cout, sc, sh, int(bool(relu)), _ptr(out), y_ld, _ptr(mean), _ptr(ws), nbytes, _stream()),
+              "conv1x1_nhwc_pooled")
     else:
-        check(L.srf_conv1x1_nhwc(_ptr(x), N * H * W, K, x_ld, _ptr(packed_weight), Cout, sc, sh, int(bool(relu)), _ptr(out), y_ld,
-                                 _stream()), "conv1x1_nhwc")
+        fn = L.srf_conv1x1_nhwc_direct if direct else L.srf_conv1x1_nhwc
+        check(fn(_ptr(x), N * H * W, K, x_ld, wp, Cout, sc, sh, int(bool(relu)), _ptr(out), y_ld, _stream()), "conv1x1_nhwc")
     if timing is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
         fl = 2.0 * K * Cout * N * H * W
-        timing[1].append((timing[0], ev1, f"{K}->{Cout} @{N}x{H}x{W}", fl, fl, 4.0 * N * H * W * (K + Cout) + 4.0 * K * Cout))
+        timing[1].append((timing[0], ev1, f"{K}->{Cout} @{N}x{H}x{W}" + (" direct" if direct else ""), fl, fl,
+                          4.0 * N * H * W * (K + Cout) + 4.0 * K * Cout))
     return (out, mean) if pool else out
 
 

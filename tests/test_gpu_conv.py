@@ -400,3 +400,55 @@ def test_stem_conv_nchw_matches_torch(N, Cin, H, W):
            + shift.cpu().double().view(1, -1, 1, 1)).relu().permute(0, 2, 3, 1)
     assert y.shape == ref.shape
     assert (y.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+# ---- the LDS-free GEMM (csrc/gemm_direct.hip) ------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,W,K,Cout,ld_in,ld_out", [
+    (1, 3, 5, 32, 8, 32, 8),             # a partial row tile, Cout < 32
+    (2, 9, 14, 64, 300, 96, 320),        # three column tiles (the last one partial), slices of wider buffers
+    (3, 29, 50, 160, 256, 160, 256),     # rows of several images, partial last block per image in the pooled form
+    (2, 58, 100, 96, 128, 128, 128),
+])
+def test_conv1x1_direct_gives_the_bits_of_the_lds_kernel(monkeypatch, N, H, W, K, Cout, ld_in, ld_out):
+    """`srf_conv1x1_nhwc_direct*` against `srf_conv1x1_nhwc*`: every output is the same fma chain, so plain, top-down and pooled
+    outputs must be bitwise equal; the pooled mean (block sums added in another fixed order) within 1e-6 relative."""
+    g = torch.Generator().manual_seed(K + Cout + H)
+    xb = torch.randn(N, H, W, ld_in, generator=g).to(DEV)
+    x = xb[..., ld_in - K:]
+    w = (torch.randn(Cout, K, generator=g) / K ** 0.5).to(DEV)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    top = torch.randn(N, (H + 1) // 2, (W + 1) // 2, Cout, generator=g).to(DEV)
+    pk, pd = ops.pack_conv1x1_nhwc_weights(w), ops.pack_conv1x1_nhwc_direct_weights(w)
+    res = {}
+    for force in ("0", "1"):
+        monkeypatch.setenv("SRF_GEMM_DIRECT", force)
+        ob = torch.full((N, H, W, ld_out), 7.0, device=DEV)
+        y = ops.conv1x1_nhwc(x, pk, Cout, scale, shift, True, out=ob[..., :Cout], packed_direct=pd)
+        assert torch.all(ob[..., Cout:] == 7.0)                   # nothing written outside the slice
+        yt = ops.conv1x1_nhwc(x, pk, Cout, None, shift, False, top=top, packed_direct=pd)
+        yp, mean = ops.conv1x1_nhwc(x, pk, Cout, scale, shift, True, pool=True, packed_direct=pd)
+        res[force] = (y.clone(), yt, yp, mean)
+    for a, b in zip(res["0"][:3], res["1"][:3]):
+        assert torch.equal(a, b)
+    torch.testing.assert_close(res["0"][3], res["1"][3], rtol=1e-6, atol=1e-6)
+    ref = _ref(x, w.view(Cout, K, 1, 1), scale, shift, True)
+    assert (res["1"][0].cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    torch.testing.assert_close(res["1"][3], res["1"][2].mean((1, 2)), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,HW,K,Cout", [(6, 232 * 400, 768, 256), (6, 58 * 100, 1728, 768)])
+def test_conv1x1_direct_at_full_layer_sizes(monkeypatch, N, HW, K, Cout):
+    """BASELINE.json's full sizes (the stage-2 and stage-4 concat convolutions of VoVNet-99 on six 928 x 1600 views): the
+    launch-size rule picks the LDS-free kernel by itself; bits equal to the LDS kernel's on every pixel."""
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(N, 1, HW, K, generator=g).relu().to(DEV)
+    w = (torch.randn(Cout, K, generator=g) / K ** 0.5).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    pk, pd = ops.pack_conv1x1_nhwc_weights(w), ops.pack_conv1x1_nhwc_direct_weights(w)
+    assert ops.conv1x1_direct_wanted(N * HW, Cout)
+    yd, md = ops.conv1x1_nhwc(x, pk, Cout, None, shift, True, pool=True, packed_direct=pd)
+    monkeypatch.setenv("SRF_GEMM_DIRECT", "0")
+    yl, ml = ops.conv1x1_nhwc(x, pk, Cout, None, shift, True, pool=True, packed_direct=pd)
+    assert torch.equal(yd, yl)
+    torch.testing.assert_close(md, ml, rtol=1e-6, atol=1e-6)
