@@ -25,8 +25,10 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not stale():
+def build(force=False, verbose=False, dev=False):
+    """dev=True (`--dev`): -DSRF_DEV, the developer build with the timing-ablation kernels (wrong outputs by design), the stamp
+    hooks and their knobs (SRF_WINO_DBG); never the library that ships or that the tests and bench.py load."""
+    if not force and not dev and not stale():
         return LIB
     objs = []
     procs = []
@@ -34,7 +36,7 @@ def build(force=False, verbose=False):
     for src in sources():
         obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + (["-DSRF_DEV=1"] if dev else []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -49,4 +51,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv or "--dev" in sys.argv, verbose=True, dev="--dev" in sys.argv))

@@ -884,9 +884,32 @@ __global__ __launch_bounds__(256, 3) void srf_conv1x1_nhwc_mixed_k(GemmArgs big,
     else srf_gemm_body<1, 1, false>(tail, blockIdx.x - nbig);
 }
 
+#ifdef SRF_DEV
+// developer build only (python -m srfdet3d_amd.build --dev): device buffer of 4 * gridDim.x int64 for SRF_WINO_DBG=8; the
+// production library has neither this symbol nor the ablation kernels
 static long long *g_wino_stamps = nullptr;
-// developer hook, not part of the C ABI (include/srfdet3d.h): device buffer of 4 * gridDim.x int64 for SRF_WINO_DBG=8
 extern "C" void srf_dev_set_stamp_buffer(long long *p) { g_wino_stamps = p; }
+#endif
+
+// Developer A/B knobs choose between forms that produce IDENTICAL bits (tile-block shape, half-block / tail mixes); they are
+// read once per process -- the parity tests run each setting in its own interpreter.
+static int srf_knob(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+static int srf_cu_count(int dev)
+{
+    static int cus[64] = {0};
+    if (dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
 
 extern "C" size_t srf_wino3x3_packed_weight_bytes(int Cout, int Cin)
 {
@@ -938,8 +961,7 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
             twl = l;
         }
     }
-    const char *twl_env = getenv("SRF_WINO_TWL");             // developer A/B knob, read per call (the tests flip it)
-    const int force_twl = twl_env ? atoi(twl_env) : 0;
+    static const int force_twl = srf_knob("SRF_WINO_TWL", 0);
     if (force_twl >= 1 && force_twl <= 3) twl = force_twl;
     a.rowBlocks = srf_ceil_div(tilesY, 64 >> twl);
     a.colBlocks = srf_ceil_div(tilesX, 1 << twl);
@@ -950,13 +972,19 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
     if (srf_wino3x3_packed_weight_bytes(Cout, Cin) >= ((size_t)1 << 31)) return SRF_EUNSUPPORTED;  // buffer-descriptor range of U
     a.nspatial = (int)nspatial;
     a.relu = relu;
+#ifdef SRF_DEV
     a.stamps = g_wino_stamps;
+#else
+    a.stamps = nullptr;
+#endif
     const long long blocks = ((nspatial + 7) / 8) * 8 * a.coutBlocks;
     int dev = 0;
     SRF_HIP_TRY(hipGetDevice(&dev));
     static bool attr_set[64] = {false};
     if (dev < 0 || dev >= 64) return SRF_EUNSUPPORTED;
-    static const int dbg = getenv("SRF_WINO_DBG") ? atoi(getenv("SRF_WINO_DBG")) : 0;  // timing ablations (developer knob)
+#ifdef SRF_DEV
+    static const int dbg = srf_knob("SRF_WINO_DBG", 0);  // timing ablations: skip loads / MFMAs, stamps (WRONG outputs by design)
+#endif
     if (!attr_set[dev]) {
 #define WN_ATTR(D, L, HB) SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_k<D, L, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES))
         WN_ATTR(0, 1, false);
@@ -968,15 +996,18 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
         SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_mixed_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
         SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_mixed_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
         SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_wino3x3_mixed_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES));
+#ifdef SRF_DEV
         WN_ATTR(1, 3, false);
         WN_ATTR(4, 3, false);
         WN_ATTR(8, 3, false);
+#endif
 #undef WN_ATTR
         attr_set[dev] = true;
     }
     const dim3 blk(256);
     a.cb0 = 0;
     a.ncb = a.coutBlocks;
+#ifdef SRF_DEV
     if (dbg == 1 || dbg == 4 || dbg == 8) {   // ablation builds exist for the 8 x 8 shape only
         a.rowBlocks = srf_ceil_div(tilesY, 8);
         a.colBlocks = srf_ceil_div(tilesX, 8);
@@ -988,17 +1019,15 @@ extern "C" int srf_wino3x3(const float *x, int N, int H, int W, int Cin, long lo
         SRF_LAUNCH_CHECK();
         return SRF_OK;
     }
+#endif
     // A last channel block with at most 32 real channels (Cout = 160, 224, ...) can run on the half-block kernel, whose
     // workgroups take ~0.62 of a full one, as a launch of its own.  Worth it when it saves rounds of 256 workgroups
     // (SRF_WINO_HALF=0 / 1 forces the choice: developer A/B knob).
     const long long sp8 = ((nspatial + 7) / 8) * 8;
     const int rem = Cout - (a.coutBlocks - 1) * 64;
-    const char *fh_env = getenv("SRF_WINO_HALF");   // read per call: the tests flip it
-    const int force_half = fh_env ? atoi(fh_env) : -1;
+    static const int force_half = srf_knob("SRF_WINO_HALF", -1);
     bool split = false, all_half = false;
-    int cus = 0;
-    SRF_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (cus <= 0) cus = 256;
+    const int cus = srf_cu_count(dev);
     double rounds_best = (double)srf_ceil_div(sp8 * a.coutBlocks, cus);   // rounds of full workgroups
     if (rem <= 32) {
         // one mixed launch: the half workgroups (0.62 of a full one each) fill the tail of the full ones
@@ -1126,11 +1155,11 @@ static int conv1x1_launch(const float *x, long long M, int K, long long x_ld, co
         SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_conv1x1_nhwc_k<4, 4, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BIG));
         attr_set[dev] = true;
     }
-    static const int big = getenv("SRF_GEMM_BIG") ? atoi(getenv("SRF_GEMM_BIG")) : 0;
+    static const int big = srf_knob("SRF_GEMM_BIG", 0);
     int TM = (big && !colsum) ? 256 : 128, ncs = (big && !colsum) ? 1 : 2;
     // below ~0.8 rounds of 128 x 128 tiles at three per CU the 64 x 64 tiles win (stage 5 of VoVNet: 544 tiles, 417 -> 386 us);
     // SRF_GEMM_SMALL overrides the threshold (developer A/B knob)
-    static const int small_thr = getenv("SRF_GEMM_SMALL") ? atoi(getenv("SRF_GEMM_SMALL")) : 640;
+    static const int small_thr = srf_knob("SRF_GEMM_SMALL", 640);
     if (srf_ceil_div(M, 128) * srf_ceil_div(Cout, 128) < small_thr) TM = 64, ncs = 4;  // small problem: 64 x 64 tiles
     a.row0 = 0;
     a.slot0 = 0;
@@ -1146,14 +1175,11 @@ static int conv1x1_launch(const float *x, long long M, int K, long long x_ld, co
         a.mblocks = srf_ceil_div(M, TM);
     }
     // tail of the last, partly filled round of 128 x 128 tiles as 64 x 64 tiles (SRF_GEMM_TAIL=0 turns it off; developer A/B knob)
-    const char *tail_env = getenv("SRF_GEMM_TAIL");   // read per call: the tests flip it
-    const int tail_on = tail_env ? atoi(tail_env) : 1;
+    static const int tail_on = srf_knob("SRF_GEMM_TAIL", 1);
     static const double tail_frac = getenv("SRF_GEMM_TAIL_FRAC") ? atof(getenv("SRF_GEMM_TAIL_FRAC")) : 1.0;
-    static const int tail_extra = getenv("SRF_GEMM_TAIL_EXTRA") ? atoi(getenv("SRF_GEMM_TAIL_EXTRA")) : 0;
+    static const int tail_extra = srf_knob("SRF_GEMM_TAIL_EXTRA", 0);
     if (TM == 128 && tail_on) {
-        int cus = 0;
-        SRF_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        if (cus <= 0) cus = 256;
+        const int cus = srf_cu_count(dev);
         const long long slots_cu = 3ll * cus, nct = srf_ceil_div(Cout, 128);
         const long long tiles = a.mblocks * nct;
         long long full = tiles / slots_cu;

@@ -204,13 +204,13 @@ class GraphedImageBranch:
         consumer = hook() if hook is not None and not safe else None
         with torch.cuda.stream(side), torch.no_grad(), _graph_safe_convs(safe):
             for _ in range(self.warmup):
-                with nhwc.level_consumer(consumer):
+                with nhwc.level_consumer(m.img_neck, consumer):
                     ref = m.extract_img_feat(static_img, img_metas)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ref = [r.clone() for r in ref]
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), _graph_safe_convs(safe), torch.cuda.graph(graph, stream=side), nhwc.level_consumer(consumer):
+        with torch.no_grad(), _graph_safe_convs(safe), torch.cuda.graph(graph, stream=side), nhwc.level_consumer(m.img_neck, consumer):
             feats = m.extract_img_feat(static_img, img_metas)
         torch.cuda.synchronize()
         _validate(graph, feats, ref, "image-branch graph")

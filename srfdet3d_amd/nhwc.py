@@ -55,6 +55,20 @@ def _cached(mod, key, vers, make):
     return cache[1]
 
 
+_CACHE_KEYS = ("_srf_wino", "_srf_wino43", "_srf_gemm", "_srf_gemm_direct", "_srf_cgemm", "_srf_packed")
+
+
+def invalidate_caches(model):
+    """Drops the packed-weight images cached on the convolution modules of `model`.  The caches are keyed on (weight._version,
+    data_ptr): optimiser steps, `copy_` and `load_state_dict` bump the version, but an in-place update THROUGH `.data`
+    (`p.data.mul_()`, old-style EMA) does not -- call this after such an update.  The detector calls it from `train()` and
+    after `load_state_dict`."""
+    for m in model.modules():
+        for k in _CACHE_KEYS:
+            if hasattr(m, k):
+                delattr(m, k)
+
+
 def _wino_weights(conv):
     w = conv.weight
     return _cached(conv, "_srf_wino", (w._version, w.data_ptr()), lambda: ops.pack_wino3x3_weights(w.detach()))
@@ -376,27 +390,25 @@ class ConsumedLevels(list):
     """Pyramid levels a per-level consumer (the head's `img_convs`) has already been applied to (see `level_consumer`)."""
 
 
-_LEVEL_CONSUMER = None
-
-
 class level_consumer:
-    """Within this context the next FPN forward on the channels-last path hands every finished level to `fn(i, x_nhwc) ->
+    """Within this context the channels-last forward of THIS FPN instance hands every finished level to `fn(i, x_nhwc) ->
     y_nhwc` as part of that level's chain (lateral -> output convolution -> consumer).  graphs.GraphedImageBranch uses it to
     run the head's `img_convs` (srfdet_head.py:404-416) inside the camera graph, where the chains of the coarse levels are
     captured as parallel branches: their few-workgroup kernels (29 x 50 and 58 x 100 maps cover 65 % / 80 % of the CUs) run
-    beside the lateral GEMMs and the finest level's kernels instead of after them."""
+    beside the lateral GEMMs and the finest level's kernels instead of after them.  The consumer is an attribute of the neck it
+    is meant for (no module-global state: another FPN's forward is not affected); fn = None is a no-op context."""
 
-    def __init__(self, fn):
-        self.fn = fn
+    def __init__(self, fpn, fn):
+        self.fpn, self.fn = fpn, fn
 
     def __enter__(self):
-        global _LEVEL_CONSUMER
-        _LEVEL_CONSUMER = self.fn
+        if self.fn is not None:
+            self.fpn._srf_level_consumer = self.fn
         return self
 
     def __exit__(self, *exc):
-        global _LEVEL_CONSUMER
-        _LEVEL_CONSUMER = None
+        if self.fn is not None:
+            self.fpn._srf_level_consumer = None
         return False
 
 
@@ -412,10 +424,9 @@ def _chain_stream(i):
 def fpn_forward(fpn, inputs):
     # laterals from the top level down: the top-down step (`laterals[i - 1] += upsample(laterals[i])`) is the epilogue of the
     # lateral convolution of level i - 1 (srf_conv1x1_nhwc_topdown): no separate pass over the finer map
-    global _LEVEL_CONSUMER
     n = len(fpn.lateral_convs)
     convs = list(fpn.fpn_convs)
-    consumer, _LEVEL_CONSUMER = _LEVEL_CONSUMER, None
+    consumer = getattr(fpn, "_srf_level_consumer", None)
     if len(convs) > n:
         consumer = None   # extra levels hang off the last output: one chain
     # under a graph capture the chain of every coarse level forks off as soon as its lateral is final

@@ -388,7 +388,9 @@ def spconv_fwd(feats, weight, nbr, alpha=None, beta=None, residual=None, relu=Fa
         # epilogue as torch ops so that autograd differentiates it
         out = _SpconvFn.apply(feats, weight, nbr, bool(subm))
         if alpha is not None:
-            out = out * alpha + beta
+            out = out * alpha
+        if beta is not None:
+            out = out + beta
         if residual is not None:
             out = out + residual
         return torch.relu(out) if relu else out

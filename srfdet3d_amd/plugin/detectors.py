@@ -68,6 +68,20 @@ class SRFDet(BaseModule):
         self._graphed_frame = GraphedFrame(self) if (enabled and whole_frame and GraphedFrame.eligible(self)) else None
         return self
 
+    def train(self, mode=True):
+        """Also drops the packed-weight images the channels-last executor cached on the convolutions (nhwc.invalidate_caches):
+        whatever was done to the weights before a mode switch -- incl. in-place updates through `.data`, which the caches'
+        (version, pointer) key cannot see -- the next inference pass packs them afresh."""
+        from .. import nhwc
+        nhwc.invalidate_caches(self)
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        from .. import nhwc
+        out = super().load_state_dict(*args, **kwargs)
+        nhwc.invalidate_caches(self)
+        return out
+
     def init_weights(self):
         super().init_weights()
         if self.freeze_img and self.use_img and self.img_backbone is not None:

@@ -48,9 +48,14 @@ def _per_class_nms(boxes, scores, score_thr, max_num, nms_thr):
         idx = (scores[:, c] > score_thr).nonzero(as_tuple=False).squeeze(1)
         if idx.numel() == 0:
             continue
-        if idx.numel() > NMS_MAX_BOXES:  # keep the best ones: anything below them cannot reach the top max_num anyway
-            idx = idx[scores[idx, c].topk(NMS_MAX_BOXES).indices]
-        keep = idx[ops.nms_rotated(boxes[idx][:, [0, 1, 3, 4, 6]].contiguous(), scores[idx, c], nms_thr)]  # descending score
+        if idx.numel() > NMS_MAX_BOXES:
+            # more candidates of ONE class than a launch takes (64 mask words per row): truncating to the best 4096 would differ
+            # from the reference's loop once suppression removes many of them, so the greedy NMS runs exactly, in blocks of
+            # descending score -- a block is first thinned by the survivors so far, then by itself
+            keep = _nms_rotated_blocks(boxes[idx][:, [0, 1, 3, 4, 6]].contiguous(), scores[idx, c], nms_thr)
+            keep = idx[keep]
+        else:
+            keep = idx[ops.nms_rotated(boxes[idx][:, [0, 1, 3, 4, 6]].contiguous(), scores[idx, c], nms_thr)]  # descending score
         out_b.append(boxes[keep])
         out_s.append(scores[keep, c])
         out_l.append(torch.full((keep.numel(),), c, dtype=torch.long, device=boxes.device))
@@ -61,6 +66,26 @@ def _per_class_nms(boxes, scores, score_thr, max_num, nms_thr):
         top = out_s.sort(descending=True)[1][:max_num]
         out_b, out_s, out_l = out_b[top], out_s[top], out_l[top]
     return out_b, out_s, out_l
+
+
+def _nms_rotated_blocks(bev, scores, thr, block=NMS_MAX_BOXES):
+    """Exact greedy rotated NMS of any number of boxes of one class on launches of at most NMS_MAX_BOXES boxes; returns the kept
+    indices in descending score.  Blocks of descending score: a block is first thinned by the survivors of the earlier blocks
+    (`ops.box_iou_rotated` of survivors x block: only KEPT boxes may suppress), then by itself (`ops.nms_rotated`)."""
+    order = scores.argsort(descending=True, stable=True)
+    kept = order.new_zeros((0,))
+    for b0 in range(0, order.numel(), block):
+        cand = order[b0:b0 + block]
+        if kept.numel():
+            dead = torch.zeros(cand.numel(), dtype=torch.bool, device=bev.device)
+            for k0 in range(0, kept.numel(), 8192):
+                iou = ops.box_iou_rotated(bev[kept[k0:k0 + 8192]].contiguous(), bev[cand].contiguous())
+                dead |= (iou > thr).any(dim=0)
+            cand = cand[~dead]
+        if cand.numel():
+            cand = cand[ops.nms_rotated(bev[cand].contiguous(), scores[cand], thr)]
+        kept = torch.cat([kept, cand])
+    return kept
 
 
 STATIC_CANDIDATES = 2048  # capacity of the fixed-shape NMS (the kernel takes up to 4096)

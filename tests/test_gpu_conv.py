@@ -260,62 +260,84 @@ def test_conv1x1_at_full_layer_sizes_against_rocblas(N, HW, K, Cout):
     assert torch.equal(y, y2) and torch.equal(mean, mean2)
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 37, 53, 64, 160), (1, 64, 64, 32, 32), (3, 20, 132, 40, 96), (1, 58, 100, 224, 224),
-                                            (2, 9, 11, 16, 20)])
-def test_winograd_half_block_kernel_gives_the_same_bits(monkeypatch, N, H, W, Cin, Cout):
+_WINO_FORMS = r"""
+import sys, torch
+from srfdet3d_amd import ops
+outs = []
+for (N, H, W, Cin, Cout) in [(2, 37, 53, 64, 160), (1, 64, 64, 32, 32), (3, 20, 132, 40, 96), (1, 58, 100, 224, 224), (2, 9, 11, 16, 20)]:
+    g = torch.Generator().manual_seed(Cout + W)
+    x = torch.randn(N, H, W, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).cuda()
+    scale = (torch.rand(Cout, generator=g) + 0.5).cuda()
+    shift = torch.randn(Cout, generator=g).cuda()
+    outs.append(ops.wino3x3(x, ops.pack_wino3x3_weights(w), Cout, scale, shift, True).cpu())
+torch.save(outs, sys.argv[1])
+"""
+
+
+def test_winograd_half_block_kernel_gives_the_same_bits(tmp_path):
     """A last channel block with <= 32 real channels can run on the half-block kernel (waves split the frequencies instead
     of the channels, the upper half hands its accumulators over through LDS): the output transform then performs the same
-    operations in the same order, so the results are bit-identical to the one-launch form, whichever the launcher picks."""
+    operations in the same order, so the results are bit-identical to the one-launch form, whichever the launcher picks.
+    Forms: SRF_WINO_HALF = 0 one-launch / 1 last block as half blocks / 2 every block as two half blocks / 3 the second half of the
+    work items as two half blocks each (the form a partly filled last round takes), each on the 8 x 8, 16 x 4 and 32 x 2 tile
+    blocks (SRF_WINO_TWL).  The knobs are read once per process: one interpreter per setting (tests/forms.py)."""
+    from forms import run_forms
+    settings = [{"SRF_WINO_HALF": h, "SRF_WINO_TWL": t} for h in ("0", "1", "2", "3") for t in ("1", "2", "3")]
+    res = run_forms(_WINO_FORMS, settings, tmp_path)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
+    # and the default choice against float64
+    N, H, W, Cin, Cout = 2, 37, 53, 64, 160
     g = torch.Generator().manual_seed(Cout + W)
-    x = torch.randn(N, H, W, Cin, generator=g).to(DEV)
-    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(DEV)
-    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
-    shift = torch.randn(Cout, generator=g).to(DEV)
-    pk = ops.pack_wino3x3_weights(w)
-    outs = []
-    for force in ("0", "1", "2", "3"):   # one-launch form / last block as half blocks / every block as two half blocks / the
-        # second half of the work items as two half blocks each (the form a partly filled last round takes)
-        monkeypatch.setenv("SRF_WINO_HALF", force)
-        for twl in ("1", "2", "3"):
-            monkeypatch.setenv("SRF_WINO_TWL", twl)   # 8 x 8, 16 x 4 and 32 x 2 tile blocks
-            outs.append(ops.wino3x3(x, pk, Cout, scale, shift, True))
-    for o in outs[1:]:
-        assert torch.equal(o, outs[0])
-    ref = F.conv2d(x.permute(0, 3, 1, 2).cpu().double(), w.cpu().double(), padding=1)
-    ref = (ref * scale.cpu().double().view(1, -1, 1, 1) + shift.cpu().double().view(1, -1, 1, 1)).relu().permute(0, 2, 3, 1)
-    assert (outs[0].cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1)
+    ref = (ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)).relu().permute(0, 2, 3, 1)
+    assert (res[0][0].double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("N,HW,K,Cout,mode", [(1, 128 * 404, 64, 256, "flat"), (2, 128 * 200 + 40, 64, 256, "pool"), (3, 128 * 86 + 1, 32, 384, "pool"),
-                                              (1, 128 * 260 + 77, 96, 400, "flat"), (2, 100 * 257, 32, 256, "top")])
-def test_conv1x1_mixed_tiles_give_the_same_bits(monkeypatch, N, HW, K, Cout, mode):
-    """A partly filled last round of 128 x 128 tiles runs as 64 x 64 tiles in the same launch (srf_conv1x1_nhwc_mixed_k): every
-    output is the same k-ordered fma chain, so the map is bit-identical to the one-size launch; the pooled means add the
-    blocks of an image in another grouping and agree to rounding."""
+_GEMM_FORMS = r"""
+import sys, torch
+from srfdet3d_amd import ops
+outs = []
+for (N, HW, K, Cout, mode) in [(1, 128 * 404, 64, 256, "flat"), (2, 128 * 200 + 40, 64, 256, "pool"), (3, 128 * 86 + 1, 32, 384, "pool"),
+                               (1, 128 * 260 + 77, 96, 400, "flat"), (2, 100 * 257, 32, 256, "top")]:
     g = torch.Generator().manual_seed(HW + Cout)
-    x = torch.randn(N, 1, HW, K, generator=g).to(DEV)
-    w = (torch.randn(Cout, K, generator=g) / K ** 0.5).to(DEV)
-    shift = torch.randn(Cout, generator=g).to(DEV)
+    x = torch.randn(N, 1, HW, K, generator=g).cuda()
+    w = (torch.randn(Cout, K, generator=g) / K ** 0.5).cuda()
+    shift = torch.randn(Cout, generator=g).cuda()
     pk = ops.pack_conv1x1_nhwc_weights(w)
-    outs = []
-    for tail in ("0", "1"):
-        monkeypatch.setenv("SRF_GEMM_TAIL", tail)
-        if mode == "pool":
-            outs.append(ops.conv1x1_nhwc(x, pk, Cout, None, shift, True, pool=True))
-        elif mode == "top":
-            xm = x.view(N, 100, 257, K)
-            top = torch.randn(N, 50, 129, Cout, generator=torch.Generator().manual_seed(5)).to(DEV)
-            outs.append((ops.conv1x1_nhwc(xm, pk, Cout, None, shift, False, top=top),))
-        else:
-            outs.append((ops.conv1x1_nhwc(x, pk, Cout, None, shift, True),))
-    assert torch.equal(outs[0][0], outs[1][0])
     if mode == "pool":
-        m_ref = outs[0][0].double().mean(dim=(1, 2))
-        for o in outs:
-            assert (o[1].double() - m_ref).abs().max().item() <= 1e-5 * m_ref.abs().max().item()
+        y, m = ops.conv1x1_nhwc(x, pk, Cout, None, shift, True, pool=True)
+        outs.append((y.cpu(), m.cpu()))
+    elif mode == "top":
+        top = torch.randn(N, 50, 129, Cout, generator=torch.Generator().manual_seed(5)).cuda()
+        outs.append((ops.conv1x1_nhwc(x.view(N, 100, 257, K), pk, Cout, None, shift, False, top=top).cpu(),))
+    else:
+        outs.append((ops.conv1x1_nhwc(x, pk, Cout, None, shift, True).cpu(),))
     if mode != "top":
         ref = torch.relu(torch.mm(x.view(N * HW, K), w.t()) + shift).view(N, 1, HW, Cout)
-        assert (outs[1][0] - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+        assert (outs[-1][0].cuda() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+torch.save(outs, sys.argv[1])
+"""
+
+
+def test_conv1x1_mixed_tiles_give_the_same_bits(tmp_path):
+    """A partly filled last round of 128 x 128 tiles runs as 64 x 64 tiles in the same launch (srf_conv1x1_nhwc_mixed_k,
+    SRF_GEMM_TAIL=1, the default) or as one more round of big tiles (SRF_GEMM_TAIL=0): every output is the same k-ordered fma
+    chain, so the map is bit-identical; the pooled means add the blocks of an image in another grouping and agree to rounding."""
+    from forms import run_forms
+    res = run_forms(_GEMM_FORMS, [{"SRF_GEMM_TAIL": "0"}, {"SRF_GEMM_TAIL": "1"}], tmp_path)
+    for a, b in zip(*res):
+        assert torch.equal(a[0], b[0])
+        if len(a) > 1:
+            m_ref = a[0].double().mean(dim=(1, 2))
+            for o in (a, b):
+                assert (o[1].double() - m_ref).abs().max().item() <= 1e-5 * m_ref.abs().max().item()
 
 
 @pytest.mark.parametrize("N,H,W,Ht,Wt,K,Cout", [(2, 12, 20, 6, 10, 64, 96), (3, 29, 50, 15, 25, 128, 256), (1, 7, 9, 4, 5, 32, 40),

@@ -170,3 +170,110 @@ def test_conv_gemm_nhwc_batch_beyond_one_descriptor(dev):
         y1 = ops.conv_gemm_nhwc(x[n:n + 1], pk, 32, (3, 3), 2, 1, None, None, True)
         assert torch.equal(y[n:n + 1], y1)
     assert (y > 0).float().mean().item() > 0.2
+
+
+def test_blockwise_nms_equals_one_launch(dev):
+    """More candidates of one class than a srf_nms_rotated launch takes (4096) run as an exact blockwise greedy NMS
+    (postprocess._nms_rotated_blocks: survivors thin the next block through srf_box_iou_rotated, the block then thins itself).
+    With a small block size on 3000 boxes it must keep exactly what one launch keeps, in the same order."""
+    from srfdet3d_amd import postprocess
+    g = torch.Generator().manual_seed(4)
+    n = 3000
+    bev = torch.cat([torch.rand(n, 2, generator=g) * 60 - 30, torch.rand(n, 2, generator=g) * 4 + 1, torch.rand(n, 1, generator=g) * 6.28 - 3.14], 1).to(dev)
+    scores = torch.rand(n, generator=g).to(dev)
+    want = ops.nms_rotated(bev, scores, 0.2)
+    assert 200 < want.numel() < n - 200
+    for block in (257, 1024):
+        got = postprocess._nms_rotated_blocks(bev, scores, 0.2, block=block)
+        assert torch.equal(got, want)
+    # and through the public entry point: 5000 boxes of ONE class above the threshold
+    n = 5000
+    boxes = torch.cat([torch.rand(n, 2, generator=g) * 100 - 50, torch.zeros(n, 1), torch.rand(n, 2, generator=g) * 4 + 1, torch.ones(n, 1),
+                       torch.rand(n, 1, generator=g) * 6.28 - 3.14], 1).to(dev)
+    sc = torch.zeros(n, 3)
+    sc[:, 1] = torch.rand(n, generator=g) * 0.5 + 0.5
+    b, s_, l = postprocess._per_class_nms(boxes, sc.to(dev), 0.1, 10 ** 6, 0.2)
+    ref = postprocess._nms_rotated_blocks(boxes[:, [0, 1, 3, 4, 6]].contiguous(), sc[:, 1].to(dev), 0.2, block=4096)
+    assert torch.equal(b, boxes[ref]) and bool((l == 1).all())
+    # a float64 spot check of the greedy property: no kept pair overlaps above the threshold, every dropped box has a kept
+    # box of higher score above it
+    iou = ops.box_iou_rotated(boxes[ref][:, [0, 1, 3, 4, 6]].contiguous(), boxes[:, [0, 1, 3, 4, 6]].contiguous())
+    kk = iou[:, ref]
+    kk.fill_diagonal_(0)
+    assert float(kk.max()) <= 0.2 + 1e-5
+    dropped = torch.ones(n, dtype=torch.bool, device=dev)
+    dropped[ref] = False
+    assert bool((iou[:, dropped].max(dim=0).values > 0.2 - 1e-5).all())
+
+
+@pytest.mark.parametrize("fork_from", ["0", "2"])
+def test_fpn_forward_with_level_consumer_capture_equals_eager(dev, monkeypatch, fork_from):
+    """nhwc.fpn_forward with a per-level consumer (the head's img_convs as the tail of each level's chain): captured into a
+    hipGraph -- where the chains of the levels >= SRF_FPN_FORK fork onto side streams (2), or none does (0) -- the replay must
+    equal the eager result bit for bit, and both the plain two-step form (FPN, then the consumer on every level)."""
+    from srfdet3d_amd.compat.necks import FPN
+    monkeypatch.setenv("SRF_FPN_FORK", fork_from)
+    torch.manual_seed(3)
+    fpn = FPN(in_channels=[64, 96, 128, 160], out_channels=64, num_outs=4).to(dev).eval()
+    convs = torch.nn.ModuleList([torch.nn.Conv2d(64, 32, 3, padding=1) for _ in range(4)]).to(dev).eval()
+    sizes = [(40, 64), (20, 32), (10, 16), (5, 8)]
+    feats = [torch.randn(2, c, h, w, device=dev).contiguous(memory_format=torch.channels_last) for c, (h, w) in zip([64, 96, 128, 160], sizes)]
+    consumer = lambda i, x: nhwc.conv3x3(x, convs[i])  # noqa: E731
+    with torch.no_grad():
+        assert nhwc.fpn_supported(fpn, feats)
+        plain = [nhwc.nchw_view(nhwc.conv3x3(nhwc.nhwc_view(o), convs[i])) for i, o in enumerate(nhwc.fpn_forward(fpn, feats))]
+        with nhwc.level_consumer(fpn, consumer):
+            eager = nhwc.fpn_forward(fpn, feats)
+        assert isinstance(eager, nhwc.ConsumedLevels) and getattr(fpn, "_srf_level_consumer", None) is None
+        for a, b in zip(eager, plain):
+            assert torch.equal(a, b)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side), nhwc.level_consumer(fpn, consumer):
+            got = nhwc.fpn_forward(fpn, feats)
+        for rep in range(2):
+            for o in got:
+                o.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            for a, b in zip(got, eager):
+                assert torch.equal(a, b)
+
+
+def test_stair_nhwc_equals_the_module_stair(dev):
+    """SRFDetHead._stair_nhwc (the depthwise stair of the proposal generator on channels-last levels: srf_nhwc_dwconv3x3s2 writing
+    slices of the next level's concat buffer) against the module stair (Conv2d + BN + ReLU, torch.cat) of srfdet_head.py:520-537."""
+    from srfdet3d_amd.compat.cnn import ConvModule
+    from srfdet3d_amd.plugin.heads import SRFDetHead
+    torch.manual_seed(1)
+    chans = [16, 32, 48]
+    convs = torch.nn.ModuleList([ConvModule(c, c, kernel_size=3, stride=2, padding=1, groups=c, norm_cfg=dict(type="BN2d", eps=1e-3, momentum=0.01))
+                                 for c in chans]).to(dev).eval()
+    _randomize_bn(convs, 3)
+    feats = [torch.randn(2, 16, 32, 48, device=dev), torch.randn(2, 16, 16, 24, device=dev), torch.randn(2, 16, 8, 12, device=dev)]
+    with torch.no_grad():
+        x = convs[0](feats[0])
+        for lvl in range(1, len(feats)):
+            x = torch.cat([feats[lvl], x], dim=1)
+            if lvl < len(convs):
+                x = convs[lvl](x)
+        cl = [f.contiguous(memory_format=torch.channels_last) for f in feats]
+        got = SRFDetHead._stair_nhwc(list(convs), cl)
+    assert got.shape == x.shape
+    torch.testing.assert_close(got, x, rtol=1e-5, atol=1e-5)
+
+
+def test_packed_weight_caches_are_dropped_on_mode_switch(dev):
+    """nhwc caches key on (weight._version, data_ptr); an update through `.data` changes neither.  `train()` / `eval()` and
+    `load_state_dict` of the detector call nhwc.invalidate_caches, after which the next pass packs the new weights."""
+    conv = torch.nn.Conv2d(96, 32, 3, padding=1, bias=False).to(dev)
+    x = torch.randn(1, 8, 12, 96, device=dev)
+    with torch.no_grad():
+        y0 = nhwc.conv3x3(x, conv).clone()
+        conv.weight.data.mul_(2.0)                       # invisible to the cache key
+        assert torch.equal(nhwc.conv3x3(x, conv), y0)    # stale on purpose: this is what the invalidation is for
+        holder = torch.nn.Sequential(conv)
+        nhwc.invalidate_caches(holder)
+        y1 = nhwc.conv3x3(x, conv)
+    torch.testing.assert_close(y1, 2 * y0, rtol=1e-5, atol=1e-6)

@@ -3,10 +3,6 @@
 Bars (stated by VERDICT r2 item 1 and met with margin): per layer <= 3e-5 of the output map's maximum (tests/
 test_wino43_emulation.py tabulates 5e-6 ... 2e-5 for the same arithmetic on the CPU); bitwise repeatable; the same bits from
 both workgroup forms (64-channel blocks / 32-channel halves) and from a layer cut into slabs."""
-import os
-import subprocess
-import sys
-
 import pytest
 import torch
 import torch.nn.functional as F
@@ -132,17 +128,12 @@ torch.save(outs, sys.argv[1])
 
 
 def test_wino43_workgroup_forms_and_slabs_give_the_same_bits(tmp_path):
-    """The developer knobs are read once per process, so each form runs in its own interpreter: 64-channel blocks
-    (SRF_W43_NB=2), 32-channel halves (SRF_W43_NB=1) and a layer cut into slabs of 8 tile blocks (SRF_W43_SLAB_TB=8) must
-    produce identical bits -- every output is the same fma chain and the same transform sequence whichever workgroup owns it."""
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = []
-    for i, extra in enumerate(({"SRF_W43_NB": "2"}, {"SRF_W43_NB": "1"}, {"SRF_W43_NB": "1", "SRF_W43_SLAB_TB": "8"},
-                               {"SRF_W43_NB": "2", "SRF_W43_SLAB_TB": "16"})):
-        env = dict(os.environ, PYTHONPATH=root, **extra)
-        f = tmp_path / f"o{i}.pt"
-        subprocess.run([sys.executable, "-c", _FORMS, str(f)], check=True, env=env, cwd=root, timeout=600)
-        res.append(torch.load(f, weights_only=True))
+    """The developer knobs are read once per process, so each form runs in its own interpreter (tests/forms.py): 64-channel
+    blocks (SRF_W43_NB=2), 32-channel halves (SRF_W43_NB=1) and a layer cut into slabs of 8 / 16 tile blocks (SRF_W43_SLAB_TB)
+    must produce identical bits -- every output is the same fma chain and the same transform sequence whichever workgroup owns it."""
+    from forms import run_forms
+    res = run_forms(_FORMS, [{"SRF_W43_NB": "2"}, {"SRF_W43_NB": "1"}, {"SRF_W43_NB": "1", "SRF_W43_SLAB_TB": "8"},
+                             {"SRF_W43_NB": "2", "SRF_W43_SLAB_TB": "16"}], tmp_path)
     for other in res[1:]:
         for a, b in zip(res[0], other):
             assert torch.equal(a, b)

@@ -38,12 +38,14 @@ for name, HW, K, Cout, pool, count in SHAPES:
     x = torch.randn(N, 1, HW, K, device=dev)
     w = (torch.randn(Cout, K, generator=g) / K ** 0.5).to(dev)
     p = ops.pack_conv1x1_nhwc_weights(w)
+    pd = ops.pack_conv1x1_nhwc_direct_weights(w)
     sh = torch.zeros(Cout, device=dev)
     ts = {"0": [], "1": []}
-    for rep in range(5):          # the two forms interleaved: box and clock drift hit both alike
-        for tail in ("0", "1"):
-            os.environ["SRF_GEMM_TAIL"] = tail
-            ts[tail].append(timeit(lambda: ops.conv1x1_nhwc(x, p, Cout, None, sh, True, pool=pool)))
+    for rep in range(5):          # the two kernels interleaved: box and clock drift hit both alike
+        for tail in ("0", "1"):   # "0": srf_conv1x1_nhwc (LDS-staged), "1": srf_conv1x1_nhwc_direct (round 2 compared SRF_GEMM_TAIL
+            # here; that knob is read once per process now)
+            os.environ["SRF_GEMM_DIRECT"] = tail
+            ts[tail].append(timeit(lambda: ops.conv1x1_nhwc(x, p, Cout, None, sh, True, pool=pool, packed_direct=pd)))
     t0, t1 = min(ts["0"]), min(ts["1"])
     total[0] += t0 * count
     total[1] += t1 * count

@@ -1,4 +1,5 @@
-"""In-kernel phase times of srf_wino3x3_k (SRF_WINO_DBG=8 SRF_WINO_W8=0): prologue / loop / epilogue cycles per workgroup."""
+"""In-kernel phase times of srf_wino3x3_k (SRF_WINO_DBG=8): prologue / loop / epilogue cycles per workgroup.
+Needs the developer build of the library (`python -m srfdet3d_amd.build --dev`: ablation kernels + stamp hook)."""
 import ctypes
 import os
 import sys

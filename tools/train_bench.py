@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--bs", type=int, default=2)
     ap.add_argument("--np", type=int, default=900)
     ap.add_argument("--img-hw", default="928x1600")
+    ap.add_argument("--kernel-table", default=None, metavar="FILE",
+                    help="after the timed iterations, trace 2 more with torch.profiler and write the per-kernel table of the steady "
+                         "state to FILE (markdown); rank 0 only")
     a = ap.parse_args()
     rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     torch.cuda.set_device(local)
@@ -89,6 +92,26 @@ def main():
         print(json.dumps(dict(metric="training iterations/s, srfdet_voxel_nusc_LC", value=round(a.iters / dt, 3), n_gpus=world,
                               frames_per_s=round(a.iters * a.bs * world / dt, 3), bs_per_gpu=a.bs, num_proposals=a.np,
                               image=f"{h}x{w}", trainable_params=ntrain, grad_bytes_per_step=4 * ntrain, last_loss=round(loss, 4))))
+    if rank == 0 and a.kernel_table:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+        rows = {}
+        for ev in prof.events():
+            if ev.device_type.name != "CUDA":
+                continue
+            r = rows.setdefault(ev.name, [0, 0.0])
+            r[0] += 1
+            r[1] += ev.device_time_total if hasattr(ev, "device_time_total") else ev.cuda_time_total
+        tot = sum(r[1] for r in rows.values())
+        with open(a.kernel_table, "w") as fh:
+            fh.write(f"Steady-state kernels of one training iteration (`tools/train_bench.py --bs {a.bs} --np {a.np} --img-hw {a.img_hw}`, "
+                     f"torch.profiler over 2 iterations after the timed region; {a.iters / dt:.2f} iterations/s untraced).\n\n")
+            fh.write(f"GPU kernel time per iteration: {tot / 2e3:.1f} ms\n\n| kernel | calls / iteration | ms / iteration | % |\n|---|---|---|---|\n")
+            for name, (n, us) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:60]:
+                fh.write(f"| `{name[:150]}` | {n / 2:.1f} | {us / 2e3:.3f} | {100 * us / tot:.1f} |\n")
     if world > 1:
         dist.destroy_process_group()
 
