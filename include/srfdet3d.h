@@ -291,6 +291,8 @@ int srf_linear(const float *X, int M, int K, int ldx, const float *W, int N, int
                const float *ln2_g, const float *ln2_b, float eps2, int relu2, float *Y, int ldy, void *workspace,
                size_t workspace_bytes, srf_stream_t stream);
 int srf_self_attention(const float *qkv, int P, int E, int H, float *out, srf_stream_t stream);
+/* the same for B samples of P proposals each (rows sample-major): one launch instead of the per-sample loop of a batched head */
+int srf_self_attention_batched(const float *qkv, int B, int P, int E, int H, float *out, srf_stream_t stream);
 int srf_dynconv_mid(const float *feats, const float *params, int R, int S, int C, int D, const float *g1,
                     const float *b1, float eps1, const float *g2, const float *b2, float eps2, float *out,
                     srf_stream_t stream);

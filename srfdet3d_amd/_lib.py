@@ -64,6 +64,7 @@ SIGNATURES = {
     "srf_linear": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, c_float, c_int, _P, c_int, _P, _P, c_float,
                            c_int, _P, c_int, _P, c_size_t, _P]),
     "srf_self_attention": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "srf_self_attention_batched": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "srf_dynconv_mid": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, c_float, _P, _P]),
     "srf_bitmap_words": (c_size_t, [_HI, c_int]),
     "srf_bitmap_pair_count_ints": (c_size_t, []),

@@ -94,7 +94,11 @@ class ConvModule(nn.Module):
             relu = self.with_activation and isinstance(self.activate, nn.ReLU)
             if _foldable(norm) and fusable(x) and (relu or not self.with_activation):
                 return conv_bn_act(self.conv, norm, relu, x)
-        x = self.conv(x)
+        if isinstance(self.conv, nn.Conv2d):
+            from .. import train_conv
+            x = train_conv.conv2d(self.conv, x)   # training: the 3x3 layers on srf_wino43 (forward and data gradient)
+        else:
+            x = self.conv(x)
         if self.with_norm:
             x = getattr(self, self.norm_name)(x)
         if self.with_activation:

@@ -930,6 +930,9 @@ __global__ __launch_bounds__(256) void srf_self_attention_k(const float *__restr
     __shared__ __attribute__((aligned(16))) float s_v[ATT_KTILE * LD];
     const int h = blockIdx.x, q0 = blockIdx.y * ATT_QPB;
     const int tid = threadIdx.x;
+    // blockIdx.z = sample: attention is among the P proposals of one sample (nn.MultiheadAttention over a (P, bs, E) batch)
+    qkv += (size_t)blockIdx.z * P * 3 * E;
+    out += (size_t)blockIdx.z * P * E;
     const int qi = q0 + tid / ATT_PARTS, part = tid % ATT_PARTS;
     const float scale = 1.0f / sqrtf((float)DH);
     f32x4 q[DH / 4], o[DH / 4];
@@ -994,12 +997,25 @@ __global__ __launch_bounds__(256) void srf_self_attention_k(const float *__restr
     }
 }
 
+static int srf_self_attention_launch(const float *qkv, int B, int P, int E, int H, float *out, srf_stream_t stream);
+
 extern "C" int srf_self_attention(const float *qkv, int P, int E, int H, float *out, srf_stream_t stream)
 {
-    if (P < 0 || E <= 0 || H <= 0 || E % H || (E / H) > ATT_DMAX || (E & 3)) return SRF_EINVAL;
-    if (P == 0) return SRF_OK;
+    return srf_self_attention_launch(qkv, 1, P, E, H, out, stream);
+}
+
+// B samples of P proposals each in one launch: qkv (B * P, 3E), out (B * P, E), sample-major rows
+extern "C" int srf_self_attention_batched(const float *qkv, int B, int P, int E, int H, float *out, srf_stream_t stream)
+{
+    return srf_self_attention_launch(qkv, B, P, E, H, out, stream);
+}
+
+static int srf_self_attention_launch(const float *qkv, int B, int P, int E, int H, float *out, srf_stream_t stream)
+{
+    if (B < 0 || B > 65535 || P < 0 || E <= 0 || H <= 0 || E % H || (E / H) > ATT_DMAX || (E & 3)) return SRF_EINVAL;
+    if (P == 0 || B == 0) return SRF_OK;
     if (!qkv || !out) return SRF_EINVAL;
-    const dim3 grid(H, srf_ceil_div(P, ATT_QPB));
+    const dim3 grid(H, srf_ceil_div(P, ATT_QPB), B);
     switch (E / H) {
     case 16:
         hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_self_attention_k<16>), grid, dim3(256), 0, (hipStream_t)stream, qkv, P, E, H, out);

@@ -50,10 +50,11 @@ def conv_bn_act(conv, bn, relu, x):
         # the depthwise stair of the proposal generator: convolution, BatchNorm and ReLU in one streaming kernel
         scale, shift = _fold_bn2d(bn)
         return ops.dwconv3x3s2(x, conv.weight, scale, shift, relu)
-    y = conv(x)
+    from . import train_conv
+    y = train_conv.conv2d(conv, x)   # training: the 3x3 layers on srf_wino43 (forward and data gradient), else conv(x)
     if _foldable(bn) and fusable(y) and y.is_contiguous() and y.shape[0] * y.shape[1] <= 65535:  # grid.y of the kernel
         return bn_act_(y, bn, relu)
-    y = bn(y)
+    y = train_conv.bn_eval(bn, y)    # eval-mode BatchNorm under autograd as the affine map it is; else bn(y)
     return torch.relu_(y) if relu else y
 
 
@@ -85,7 +86,8 @@ def conv1x1_cat_bn_act(conv, bn, relu, xs):
         return ops.conv1x1(xs, _packed_1x1(conv), conv.out_channels, scale, shift, relu)
     x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=1)
     if bn is None:
-        y = conv(x)
+        from . import train_conv
+        y = train_conv.conv2d(conv, x)
         return torch.relu_(y) if relu else y
     return conv_bn_act(conv, bn, relu, x)
 
@@ -100,6 +102,14 @@ def run_sequential(seq, x):
             relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
             x = conv_bn_act(m, mods[i + 1], relu, x)
             i += 3 if relu else 2
+        elif isinstance(m, nn.Conv2d):
+            from . import train_conv
+            x = train_conv.conv2d(m, x)
+            i += 1
+        elif isinstance(m, nn.BatchNorm2d):
+            from . import train_conv
+            x = train_conv.bn_eval(m, x)
+            i += 1
         else:
             x = m(x)
             i += 1

@@ -723,17 +723,19 @@ def linear(x, weight, bias=None, ln1=None, relu1=False, residual=None, ln2=None,
     return y
 
 
-def self_attention(qkv, num_heads, out=None):
-    """qkv (P, 3E) rows [q|k|v] -> (P, E): softmax(q k^T / sqrt(d)) v per head.  out: a contiguous (P, E) tensor (e.g. the
-    rows of one sample in a batch buffer) written in place."""
+def self_attention(qkv, num_heads, out=None, batch=1):
+    """qkv (batch * P, 3E) rows [q|k|v], sample-major -> (batch * P, E): softmax(q k^T / sqrt(d)) v per head among the P rows of
+    each sample, one launch for the whole batch.  out: a contiguous (batch * P, E) tensor written in place."""
     qkv = _dev(qkv, "qkv", torch.float32)
-    P, E3 = qkv.shape
+    R, E3 = qkv.shape
     E = E3 // 3
+    if batch < 1 or R % batch:
+        raise ValueError("self_attention: rows must be batch * P")
     if out is None:
-        out = _empty((P, E), torch.float32, qkv.device)
-    elif tuple(out.shape) != (P, E) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != qkv.device:
-        raise ValueError("self_attention: out must be a contiguous float32 (P, E) tensor on the input's device")
-    check(_lib.lib().srf_self_attention(_ptr(qkv), P, E, num_heads, _ptr(out), _stream()), "self_attention")
+        out = _empty((R, E), torch.float32, qkv.device)
+    elif tuple(out.shape) != (R, E) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != qkv.device:
+        raise ValueError("self_attention: out must be a contiguous float32 (rows, E) tensor on the input's device")
+    check(_lib.lib().srf_self_attention_batched(_ptr(qkv), batch, R // batch, E, num_heads, _ptr(out), _stream()), "self_attention")
     return out
 
 

@@ -233,9 +233,7 @@ class _StageBase(BaseModule):
         q0 = (roi_feats.mean(dim=1) if prop_feats is None else prop_feats).reshape(R, C).contiguous()
         mha = self.self_attn_lidar
         qkv = ops.linear(q0, mha.in_proj_weight, mha.in_proj_bias)
-        att = qkv.new_empty((R, C))
-        for b in range(bs):  # attention is among the proposals of one sample
-            ops.self_attention(qkv[b * n_p:(b + 1) * n_p], mha.num_heads, out=att[b * n_p:(b + 1) * n_p])
+        att = ops.self_attention(qkv, mha.num_heads, batch=bs)  # among the proposals of each sample, one launch for the batch
         q1 = ops.linear(att, mha.out_proj.weight, mha.out_proj.bias, residual=q0, ln2=self.norm1_lidar)
         dc = self.inst_interact_lidar
         params = ops.linear(q1, dc.dynamic_layer.weight, dc.dynamic_layer.bias)
@@ -535,7 +533,8 @@ class SRFDetHead(BaseModule):
             if nhwc.enabled() and fusable(f4) and nhwc.is_channels_last(f4) and nhwc.wino_ok(conv, C):
                 g = nhwc.nchw_view(nhwc.conv3x3(nhwc.nhwc_view(f4), conv))  # Winograd on the f32 MFMA, bias in the epilogue
             else:
-                g = conv(f4)
+                from .. import train_conv
+                g = train_conv.conv2d(conv, f4)     # training: srf_wino43 forward + data gradient; else conv(f4)
             out[i] = g.reshape(bs, n_cam, *g.shape[1:])
         return out
 

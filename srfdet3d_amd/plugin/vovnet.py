@@ -163,9 +163,13 @@ class VoVNet(BaseModule):
             if not nhwc.vovnet_supported(self, x):
                 return None
             part, cur = nhwc.vovnet_forward(self, x, upto=last)
+            from .. import train_conv
+            keep_cl = train_conv.enabled()       # the trainable remainder runs channels-last (train_conv.py): no copy at all
             for k, v in part.items():
-                out[k] = v.contiguous()          # NCHW for the module path (MIOpen picks other kernels for channels_last)
-            return out[last] if last in out else nhwc.nchw_view(cur).contiguous()
+                out[k] = v if keep_cl else v.contiguous()   # else NCHW for the module path on MIOpen
+            if last in out:
+                return out[last]
+            return nhwc.nchw_view(cur) if keep_cl else nhwc.nchw_view(cur).contiguous()
 
     def _freeze_stages(self):
         if self.frozen_stages >= 0:

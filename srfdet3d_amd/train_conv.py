@@ -1,0 +1,156 @@
+"""Training-time 3x3 convolutions of the camera branch on the library's Winograd kernel (config 4 of BASELINE.json trains
+VoVNet stages 4-5, the image FPN, `img_convs` and the head: tools/train.py:220-234, vovnet.py:354-374).
+
+torch's autograd runs these layers on MIOpen: its fp32 3x3 algorithm is the VALU Winograd F(2x3) kernel for the forward AND the
+data gradient (142 launches, 68 of the 340 ms of kernel time of a bs = 2 step: profiles/r03_train_step_kernels_before.md), wrapped
+in NCHW <-> NHWC transposes for the weight gradient.  Here
+
+* forward        y = conv(x, W) + b              -> `srf_wino43` (F(4x4, 3x3) on the f32 MFMA) on the channels-last tensor;
+* data gradient  dx = conv(dy, rot180(W)^T)      -> the SAME kernel: a stride-1 3x3 convolution of dy with the weights rotated
+                                                    by 180 degrees and their in / out channel axes swapped (packed once per step);
+* weight grad    dW = sum_p dy[p] x[p + tap]     -> aten.convolution_backward with only the weight mask set (MIOpen's NHWC
+                                                    implicit-GEMM kernels; both operands are already channels-last, so the
+                                                    transposes around them disappear);
+* bias grad      db = sum_p dy[p].
+
+Tensors stay logical NCHW with channels_last strides, which every torch op of the module path preserves (BatchNorm in eval
+mode -- `norm_eval=True` -- ReLU, cat, max_pool2d, nearest interpolate), so nothing is copied between the layers.
+SRF_TRAIN_CONV=0 switches back to torch's convolution (A/B switch for tests and benchmarks).
+"""
+import os
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+_DEBUG = [] if os.environ.get("SRF_TRAIN_CONV_DEBUG") else None   # developer: (input shape, Cout, events) of every weight-gradient call
+
+
+def debug_report():
+    torch.cuda.synchronize()
+    rows = {}
+    for shp, co, e0, e1 in _DEBUG or []:
+        r = rows.setdefault((shp, co), [0, 0.0])
+        r[0] += 1
+        r[1] += e0.elapsed_time(e1)
+    return sorted(((k, n, ms / n) for k, (n, ms) in rows.items()), key=lambda t: -t[2] * t[1])
+
+
+def enabled():
+    return os.environ.get("SRF_TRAIN_CONV", "1") != "0"
+
+
+def eligible(conv, x):
+    """A trainable (or gradient-carrying) 3x3 / stride 1 / padding 1 convolution on an fp32 GPU tensor under autograd."""
+    return (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and not torch.is_autocast_enabled() and type(conv) is nn.Conv2d and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
+            and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0 and conv.in_channels >= 32
+            and (x.requires_grad or conv.weight.requires_grad) and x.shape[0] * x.shape[2] * x.shape[3] * max(conv.in_channels, conv.out_channels) * 4 < (1 << 32) - 16)
+
+
+def _nhwc(t):
+    """logical NCHW tensor -> its (N, H, W, C) view over channels-last storage (a copy only if it was not channels-last)."""
+    return t.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+
+
+class _Wino43Conv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        xn = _nhwc(x)
+        Cout = weight.shape[0]
+        y = ops.wino43(xn, ops.pack_wino43_weights(weight.detach()), Cout, None, None if bias is None else bias.detach(), False)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y.permute(0, 3, 1, 2)          # logical NCHW, channels-last strides
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gyn = _nhwc(gy)
+        gy_cl = gyn.permute(0, 3, 1, 2)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            w_t = weight.detach().flip(2, 3).transpose(0, 1).contiguous()          # (Cin, Cout, 3, 3), rotated by 180 degrees
+            gx = ops.wino43(gyn, ops.pack_wino43_weights(w_t), weight.shape[1]).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dbg = _DEBUG is not None
+            if dbg:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            gw = torch.ops.aten.convolution_backward(gy_cl, x.contiguous(memory_format=torch.channels_last), weight, None, (1, 1), (1, 1),
+                                                     (1, 1), False, (0, 0), 1, (False, True, False))[1]
+            if dbg:
+                e1.record()
+                _DEBUG.append((tuple(x.shape), weight.shape[0], e0, e1))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy_cl.sum(dim=(0, 2, 3))
+        return gx, gw, gb
+
+
+class _DepthwiseNative(torch.autograd.Function):
+    """Depthwise convolutions (the stride-2 stair of the proposal generator, srfdet_head.py:520-537) on torch's own depthwise
+    kernels in BOTH directions.  The forward already kept MIOpen away (its choice is a naive reference kernel: 34 ms on the
+    finest image level); under autograd the backward ran outside that context and MIOpen's weight gradient for the grouped
+    convolution was one 59 ms CK batched-GEMM launch per step (profiles/r03_train_step_kernels_before.md)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, groups):
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, padding, groups, bias is not None)
+        with torch.backends.cudnn.flags(enabled=False):
+            return torch.nn.functional.conv2d(x, weight, bias, stride, padding, 1, groups)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, padding, groups, has_bias = ctx.cfg
+        with torch.backends.cudnn.flags(enabled=False):
+            gx, gw, gb = torch.ops.aten.convolution_backward(gy.contiguous(), x, weight, [weight.shape[0]] if has_bias else None, stride, padding,
+                                                             (1, 1), False, (0, 0), groups,
+                                                             (ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]))
+        return gx, gw, gb, None, None, None
+
+
+def eligible_depthwise(conv, x):
+    return (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and type(conv) is nn.Conv2d
+            and conv.groups > 1 and conv.groups == conv.in_channels == conv.out_channels and conv.dilation == (1, 1)
+            and conv.padding_mode == "zeros" and (x.requires_grad or conv.weight.requires_grad))
+
+
+def eligible_1x1(conv, x):
+    return (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and not torch.is_autocast_enabled() and type(conv) is nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and x.shape[2] * x.shape[3] > 1
+            and (x.requires_grad or conv.weight.requires_grad))
+
+
+def conv2d(conv, x):
+    """conv(x) with the training-time 3x3 layers routed through `_Wino43Conv` and the 1x1 layers through a plain GEMM on the
+    (pixels, channels) view of the channels-last tensor (forward, data and weight gradient are then three rocBLAS GEMMs under
+    torch's own autograd; MIOpen's channels-last choices for 1x1 layers cost 24 ms forward and one 59 ms weight-gradient launch
+    per step: profiles/r03_train_step_kernels_before.md).  Every other case is the module itself."""
+    if eligible(conv, x):
+        return _Wino43Conv.apply(x, conv.weight, conv.bias)
+    if eligible_depthwise(conv, x):
+        return _DepthwiseNative.apply(x.contiguous(), conv.weight, conv.bias, conv.stride, conv.padding, conv.groups)
+    if eligible_1x1(conv, x):
+        xn = _nhwc(x)
+        N, H, W, C = xn.shape
+        y = torch.nn.functional.linear(xn.reshape(N * H * W, C), conv.weight.view(conv.out_channels, C), conv.bias)
+        return y.view(N, H, W, conv.out_channels).permute(0, 3, 1, 2)
+    return conv(x)
+
+
+def bn_eval(bn, y):
+    """BatchNorm2d in eval mode under autograd (`norm_eval=True`: vovnet.py:371) as the affine map it is, y * s + t with
+    s = gamma / sqrt(var + eps), t = beta - mean * s: the gradients of gamma and beta come out of two column sums instead of
+    torch's channels-last batch-norm backward (0.36 ms per layer, 26 ms per step).  Anything else: the module."""
+    if (enabled() and torch.is_grad_enabled() and y.is_cuda and y.dtype == torch.float32 and isinstance(bn, nn.BatchNorm2d)
+            and not bn.training and bn.track_running_stats and bn.affine and not torch.is_autocast_enabled()):
+        s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        t = bn.bias - bn.running_mean * s
+        return y * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)
+    return bn(y)

@@ -55,6 +55,24 @@ def test_self_attention_matches_torch_mha(dev, P, E, H):
     torch.testing.assert_close(got, want, rtol=1e-4, atol=2e-5)
 
 
+def test_self_attention_batched_equals_the_per_sample_launches(dev):
+    """bs > 1 (config 4 trains with two frames per GPU, test-time batches): one launch for the batch, sample by sample the bits
+    of the single-sample launch, and the batched nn.MultiheadAttention of the reference (srfdet_head.py:1489-1492)."""
+    torch.manual_seed(7)
+    bs, P, E, H = 3, 117, 128, 8
+    mha = torch.nn.MultiheadAttention(E, H).to(dev).eval()
+    x = torch.randn(P, bs, E, device=dev)
+    with torch.no_grad():
+        want = mha(x, x, value=x)[0]                                     # (P, bs, E)
+        rows = x.permute(1, 0, 2).reshape(bs * P, E).contiguous()        # sample-major, as the head lays its proposals out
+        qkv = ops.linear(rows, mha.in_proj_weight, mha.in_proj_bias)
+        att = ops.self_attention(qkv, H, batch=bs)
+        for b in range(bs):
+            assert torch.equal(att[b * P:(b + 1) * P], ops.self_attention(qkv[b * P:(b + 1) * P].contiguous(), H))
+        got = ops.linear(att, mha.out_proj.weight, mha.out_proj.bias).view(bs, P, E).permute(1, 0, 2)
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("C,D", [(128, 32), (256, 64)])
 def test_dynconv_mid_matches_torch(dev, C, D):
     g = torch.Generator().manual_seed(C)

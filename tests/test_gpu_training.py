@@ -186,3 +186,61 @@ def test_ddp_two_ranks_average_gradients(dev):
         assert p.exitcode == 0
     assert np.isfinite(res[0][1]) and np.isfinite(res[1][1]) and res[0][1] != res[1][1]  # different frames
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=1.3e-6, atol=1e-5)  # gradients all-reduced: identical on both ranks
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,bias", [(2, 64, 96, 13, 21, True), (3, 192, 192, 29, 50, False), (1, 256, 128, 58, 100, True)])
+def test_training_conv3x3_on_the_winograd_kernel_matches_autograd(dev, N, Cin, Cout, H, W, bias):
+    """train_conv._Wino43Conv (forward and data gradient on srf_wino43, weight gradient through aten.convolution_backward on the
+    channels-last operands) against torch's own autograd through F.conv2d in float64: 1e-4 relative to each tensor's maximum, as
+    tests/test_gpu_spconv_bwd.py holds the sparse convolution's gradients."""
+    import torch.nn.functional as F
+    from srfdet3d_amd import train_conv
+    g = torch.Generator().manual_seed(Cin + H)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1, bias=bias).to(dev)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gy = torch.randn(N, Cout, H, W, generator=g).to(dev)
+    assert train_conv.eligible(conv, x)
+    y = train_conv.conv2d(conv, x)
+    assert y.stride(1) == 1 and y.grad_fn is not None            # channels-last, on the autograd tape
+    y.backward(gy)
+    xd = x.detach().double().cpu().requires_grad_(True)
+    wd = conv.weight.detach().double().cpu().requires_grad_(True)
+    bd = conv.bias.detach().double().cpu().requires_grad_(True) if bias else None
+    yd = F.conv2d(xd, wd, bd, padding=1)
+    yd.backward(gy.double().cpu())
+    for got, want in ((y, yd), (x.grad, xd.grad), (conv.weight.grad, wd.grad)) + (((conv.bias.grad, bd.grad),) if bias else ()):
+        err = (got.detach().double().cpu() - want.detach()).abs().max().item()
+        assert err <= 1e-4 * want.detach().abs().max().item(), (err, want.detach().abs().max().item())
+    # not taken without autograd or when the switch is off
+    with torch.no_grad():
+        assert not train_conv.eligible(conv, x)
+
+
+def test_training_depthwise_and_1x1_routes_match_autograd(dev):
+    """train_conv.conv2d: the depthwise stride-2 stair convolutions on torch's native kernels in both directions, the 1x1 layers as
+    a GEMM on the (pixels, channels) view, eval-mode BatchNorm as an affine map -- gradients against float64 autograd."""
+    import torch.nn.functional as F
+    from srfdet3d_amd import train_conv
+    g = torch.Generator().manual_seed(9)
+    for conv in (torch.nn.Conv2d(64, 64, 3, stride=2, padding=1, groups=64, bias=False), torch.nn.Conv2d(96, 160, 1, bias=True)):
+        conv = conv.to(dev)
+        x = torch.randn(2, conv.in_channels, 21, 34, generator=g).to(dev).requires_grad_(True)
+        bn = torch.nn.BatchNorm2d(conv.out_channels).to(dev).eval()
+        with torch.no_grad():
+            bn.running_mean.normal_(0, 0.1)
+            bn.running_var.uniform_(0.5, 1.5)
+            bn.weight.uniform_(0.5, 1.5)
+        y = train_conv.bn_eval(bn, train_conv.conv2d(conv, x))
+        gy = torch.randn(y.shape, generator=g).to(dev)
+        y.backward(gy)
+        xd = x.detach().double().cpu().requires_grad_(True)
+        c64, b64 = torch.nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, groups=conv.groups,
+                                   bias=conv.bias is not None).double(), torch.nn.BatchNorm2d(conv.out_channels).double().eval()
+        c64.load_state_dict({k: v.double().cpu() for k, v in conv.state_dict().items()})
+        b64.load_state_dict({k: (v.double().cpu() if v.is_floating_point() else v.cpu()) for k, v in bn.state_dict().items()})
+        yd = b64(c64(xd))
+        yd.backward(gy.double().cpu())
+        pairs = [(y, yd), (x.grad, xd.grad), (conv.weight.grad, c64.weight.grad), (bn.weight.grad, b64.weight.grad), (bn.bias.grad, b64.bias.grad)]
+        for got, want in pairs:
+            err = (got.detach().double().cpu() - want.detach()).abs().max().item()
+            assert err <= 1e-4 * max(want.detach().abs().max().item(), 1e-3), (err,)

@@ -78,6 +78,9 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
+    if os.environ.get("SRF_TRAIN_CONV_DEBUG"):
+        from srfdet3d_amd import train_conv
+        train_conv._DEBUG.clear()   # the warm-up iterations contain MIOpen's solver search
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -112,6 +115,10 @@ def main():
             fh.write(f"GPU kernel time per iteration: {tot / 2e3:.1f} ms\n\n| kernel | calls / iteration | ms / iteration | % |\n|---|---|---|---|\n")
             for name, (n, us) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:60]:
                 fh.write(f"| `{name[:150]}` | {n / 2:.1f} | {us / 2e3:.3f} | {100 * us / tot:.1f} |\n")
+    if rank == 0 and os.environ.get("SRF_TRAIN_CONV_DEBUG"):
+        from srfdet3d_amd import train_conv
+        for k, n, ms in train_conv.debug_report()[:12]:
+            print("wgrad", k, "calls", n, f"{ms:.2f} ms each")
     if world > 1:
         dist.destroy_process_group()
 
