@@ -120,10 +120,10 @@ def linear_graph_safe(lin, x):
     """nn.Linear for inference on the GPU through this library's f32-MFMA GEMM (ops.linear) instead of rocBLAS / hipBLASLt.
 
     Why: for skinny problems (the DPG layers have M = batch size) the BLAS libraries pick split-K kernels that accumulate
-    with atomics into an output they first clear with hipMemsetAsync; captured into a hipGraph that clear becomes a memset
-    node, which on this ROCm does not reliably take effect on replay -- the layer then returns correct values on the first
-    replay and different ones from the second on (found on `dpg_fc1_img`, 900 -> 1500 at M = 1).  ops.linear has no
-    memsets.  K is zero-padded to a multiple of 4 (cached) when needed."""
+    with atomics into an output they clear first; captured into a hipGraph such a layer returned correct values on the first
+    replay and different ones from the second on (found on `dpg_fc1_img`, 900 -> 1500 at M = 1; round 1 blamed the memset node,
+    tools/micro/graph_memset.hip shows memset nodes do take effect -- the cause inside the library is not established).
+    ops.linear is one ordered fma chain per output and clears nothing.  K is zero-padded to a multiple of 4 (cached) when needed."""
     if not (fusable(x) and x.dim() == 2 and lin.weight.is_cuda):
         return lin(x)
     K = lin.in_features

@@ -17,7 +17,7 @@ FAMILIES = {   # bench.py name -> kernel-name substrings
     "wino43xf": ("srf_wino43_xform_k",),
     "wino3x3": ("srf_wino3x3_k<", "srf_wino3x3_mixed_k<"),
     "conv1x1": ("srf_conv1x1_nhwc_k<1, 1, 4, false>", "srf_conv1x1_nhwc_k<2, 2, 3, false>", "srf_conv1x1_nhwc_k<4, 4, 1, false>",
-                "srf_conv1x1_nhwc_mixed_k"),
+                "srf_conv1x1_nhwc_mixed_k", "srf_gemm_direct_k<"),
 }
 
 

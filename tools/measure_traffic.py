@@ -32,7 +32,7 @@ TARGETS = {
     "wino3x3": (["tools/prof_img_branch.py", "3"], ("srf_wino3x3_k<", "srf_wino3x3_mixed_k<"),
                 "every srf_wino3x3_k launch of the same passes (the layers left on F(2x2,3x3): VoVNet stem_2)"),
     "conv1x1": (["tools/prof_img_branch.py", "3"], ("srf_conv1x1_nhwc_k<1, 1, 4, false>", "srf_conv1x1_nhwc_k<2, 2, 3, false>",
-                                                     "srf_conv1x1_nhwc_k<4, 4, 1, false>", "srf_conv1x1_nhwc_mixed_k"),
+                                                     "srf_conv1x1_nhwc_k<4, 4, 1, false>", "srf_conv1x1_nhwc_mixed_k", "srf_gemm_direct_k<"),
                 "EVERY srf_conv1x1_nhwc launch of the same passes, whatever its tile form (20 per frame: OSA concat convolutions + FPN "
                 "laterals) -- the launch set bench.py's roofline.gemm aggregates"),
     "spconv128": (["tools/bench_spconv.py", "--levels", "4", "--reps", "8"], "srf_spconv_gs_k<4, 128>",

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects the measurements of a round on the GPU box into gpurun_out/<round>/ (copy what is to be judged into profiles/).
-# usage (from the repo root, through gpurun):  bash tools/round_profiles.sh r02
+# usage (from the repo root, through gpurun):  bash tools/round_profiles.sh r03
 set -o pipefail
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/$R
 mkdir -p $O
 export TMPDIR=/tmp
@@ -25,6 +25,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lc -o lc -- pyth
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_l -o l -- python3 bench.py --workload nusc_L --no-cpu-baseline > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_under_rocprof_nuscL.json
 cp $O/prof_lc/lc_kernel_stats.csv $O/${R}_bench_nuscLC_np200_kernel_stats.csv
 cp $O/prof_l/l_kernel_stats.csv $O/${R}_bench_nuscL_np200_kernel_stats.csv
+# ms per frame of the roofline kernel families inside the timed graphs (bench.py quotes it as in_graph_ms_per_frame)
+python tools/in_graph_summary.py $O/${R}_bench_nuscLC_np200_kernel_stats.csv nusc_LC 88 $O/${R}_in_graph_summary.json >> $O/log.txt 2>&1
 rm -rf $O/prof_lc $O/prof_l $O/tmp.json
 echo "kernel traces done" >> $O/log.txt
 
@@ -35,6 +37,10 @@ python tools/stage_roofline.py --workload waymo_L --frames 5 --md $O/${R}_stage_
 python tools/feed_bench.py --workload nusc_LC > $O/${R}_feed_from_host_nuscLC.json 2>> $O/log.txt
 python tools/feed_bench.py --workload nusc_L --steps 100 > $O/${R}_feed_from_host_nuscL.json 2>> $O/log.txt
 [ -x tools/micro/graph_memset.bin ] && tools/micro/graph_memset.bin > $O/${R}_graph_memset_node_test.txt 2>&1
+# config 4 on one GPU: iterations/s + the steady-state kernel table of a step
+python tools/train_bench.py --iters 8 --warmup 3 --kernel-table $O/${R}_train_step_kernels.md 2>> $O/log.txt | grep metric > $O/${R}_train_bench_LC_bs2_np900.json
+# N = 2 rehearsal of bench.py's distributed branch on the one GPU (gloo; both ranks on device 0)
+SRF_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --workload nusc_L --no-cpu-baseline 2>> $O/log.txt | tail -1 > $O/${R}_rehearsal_2ranks_sharing_one_gpu_nuscL.json
 echo "tables done" >> $O/log.txt
 
 # HBM traffic of the roofline kernels (three --pmc passes per target)
