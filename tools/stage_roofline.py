@@ -161,6 +161,14 @@ def install():
         return 4.0 * N * H * W * (Cin + Cout) + 4.0 * 16 * Cin * Cout, direct / 2.25, f"{Cin}->{Cout} @{H}x{W} (executed FLOPs = direct / 2.25)"
     _wrap("wino3x3", "mfma", w_wino)
 
+    def w_wino43(a, k, o):  # (x, packed, Cout, ...): transform + multiply of one F(4x4, 3x3) layer (executed FLOPs = direct / 4)
+        x, Cout = a[0], a[2]
+        N, H, W, Cin = x.shape
+        v = 2.25 * 4.0 * N * H * W * Cin
+        return (4.0 * N * H * W * (Cin + Cout) + 2 * v + 4.0 * 36 * Cin * Cout, 2.0 * 9 * Cin * Cout * N * H * W / 4.0,
+                f"{Cin}->{Cout} @{H}x{W} F(4,3): transform + multiply (executed FLOPs = direct / 4)")
+    _wrap("wino43", "mfma", w_wino43)
+
     def w_g1(a, k, out):
         N, H, W, K = a[0].shape
         Cout = a[2]
