@@ -1174,6 +1174,8 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
     // 123 us with 2; 64-row tiles walked by two workgroups per range (four per CU) 118 us; B fetched a whole offset ahead 113 us.
     // Ablations of the 107 us: without MFMAs 70, without the gathers 99, without barriers 100, prologue + epilogue alone 14.
     // Three workgroups per CU (88-row tiles, 768 ranges, 46 KB of LDS each): 105 us -- occupancy is not what holds it.
+    // Round 3: starting the workgroup in the odd wave slots of a CU (HW_ID) 1-4 k cycles late, so that the two co-resident
+    // workgroups begin out of phase: no change (108 / 262 us with and without, both shapes) -- they do not run in lock-step.
     constexpr int GP = 1;
     constexpr int NA = 16 * GP * 8 * NCH / 256, NKW = (SRF_KMAX + 3) / 4, CHS = 16 * GP * 32 + 8;
     constexpr int TMAX = COUT == 128 ? SRF_GS_TMAX : 120, LS = COUT == 128 ? SRF_GS_LS : 128, OS = COUT + 4;

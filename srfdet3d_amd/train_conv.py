@@ -64,7 +64,14 @@ class _Wino43Conv(torch.autograd.Function):
         y = ops.wino43(xn, ops.pack_wino43_weights(weight.detach()), Cout, None, None if bias is None else bias.detach(), False)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return y.permute(0, 3, 1, 2)          # logical NCHW, channels-last strides
+        ctx.keep_cl = x.stride(1) == 1
+        y = y.permute(0, 3, 1, 2)             # logical NCHW, channels-last strides
+        # The caller's memory format is kept: a channels-last input (the camera branch behind the frozen prefix, whose BatchNorms
+        # are in eval mode and run as affine maps) gets a channels-last output without a copy; an NCHW-contiguous input (the BEV
+        # backbone of the LiDAR-only configs, BatchNorm in TRAIN mode) gets NCHW back -- MIOpen's training batch-norm on a
+        # channels-last tensor crashed the process behind a stride-2 convolution of the BEV FPN
+        # (profiles/r03_fault_pytest_segfault_20261005.log).
+        return y if ctx.keep_cl else y.contiguous()
 
     @staticmethod
     def backward(ctx, gy):
@@ -75,6 +82,8 @@ class _Wino43Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             w_t = weight.detach().flip(2, 3).transpose(0, 1).contiguous()          # (Cin, Cout, 3, 3), rotated by 180 degrees
             gx = ops.wino43(gyn, ops.pack_wino43_weights(w_t), weight.shape[1]).permute(0, 3, 1, 2)
+            if not ctx.keep_cl:
+                gx = gx.contiguous()
         if ctx.needs_input_grad[1]:
             dbg = _DEBUG is not None
             if dbg:
@@ -121,7 +130,8 @@ def eligible_depthwise(conv, x):
 
 
 def eligible_1x1(conv, x):
-    return (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+    # only for tensors that ARE channels-last already: an NCHW pipeline keeps torch's convolution (and its memory format)
+    return (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.stride(1) == 1
             and not torch.is_autocast_enabled() and type(conv) is nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
             and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and x.shape[2] * x.shape[3] > 1
             and (x.requires_grad or conv.weight.requires_grad))
@@ -140,7 +150,7 @@ def conv2d(conv, x):
         xn = _nhwc(x)
         N, H, W, C = xn.shape
         y = torch.nn.functional.linear(xn.reshape(N * H * W, C), conv.weight.view(conv.out_channels, C), conv.bias)
-        return y.view(N, H, W, conv.out_channels).permute(0, 3, 1, 2)
+        return y.view(N, H, W, conv.out_channels).permute(0, 3, 1, 2)   # channels-last in, channels-last out
     return conv(x)
 
 

@@ -283,7 +283,8 @@ def test_winograd_half_block_kernel_gives_the_same_bits(tmp_path):
     work items as two half blocks each (the form a partly filled last round takes), each on the 8 x 8, 16 x 4 and 32 x 2 tile
     blocks (SRF_WINO_TWL).  The knobs are read once per process: one interpreter per setting (tests/forms.py)."""
     from forms import run_forms
-    settings = [{"SRF_WINO_HALF": h, "SRF_WINO_TWL": t} for h in ("0", "1", "2", "3") for t in ("1", "2", "3")]
+    # every half-block form on the default tile-block shape, every tile-block shape on the one-launch and the all-half forms
+    settings = ([{"SRF_WINO_HALF": h} for h in ("0", "1", "2", "3")] + [{"SRF_WINO_HALF": h, "SRF_WINO_TWL": t} for h in ("0", "2") for t in ("1", "2", "3")])
     res = run_forms(_WINO_FORMS, settings, tmp_path)
     for other in res[1:]:
         for a, b in zip(res[0], other):
@@ -364,7 +365,8 @@ def test_conv1x1_topdown_equals_conv_then_upsample_add(N, H, W, Ht, Wt, K, Cout)
 def test_vovnet_training_runs_the_frozen_prefix_on_the_inference_kernels(monkeypatch):
     """Config 4 trains with `frozen_stages=2, norm_eval=True` (configs/nus/srfdet_voxel_nusc_LC.py:44-54): stem, stage2 and
     stage3 carry no gradient.  With autograd recording they run on the channels-last inference kernels under no_grad; the
-    stage outputs equal the all-module path within 2e-4 of the level's max and the trainable stages still get gradients."""
+    stage outputs equal the all-module path within 2e-4 of the level's max and the trainable stages still get gradients (their
+    3x3 layers through train_conv._Wino43Conv, compared here with the torch / MIOpen module path of SRF_IMG_NHWC=0)."""
     from srfdet3d_amd.plugin.vovnet import VoVNet
     g = torch.Generator().manual_seed(4)
     torch.manual_seed(4)
@@ -379,7 +381,8 @@ def test_vovnet_training_runs_the_frozen_prefix_on_the_inference_kernels(monkeyp
     monkeypatch.setenv("SRF_IMG_NHWC", "1")
     out = net(x)
     for k in ref:
-        assert out[k].shape == ref[k].shape and out[k].is_contiguous()
+        # round 3: the trainable remainder runs channels-last (train_conv.py), the frozen prefix hands its maps over without a copy
+        assert out[k].shape == ref[k].shape and (out[k].is_contiguous() or out[k].stride(1) == 1)
         assert (out[k] - ref[k]).abs().max().item() <= 2e-4 * ref[k].abs().max().item(), k
     assert not out["stage3"].requires_grad and out["stage4"].requires_grad
     out["stage5"].square().mean().backward()
