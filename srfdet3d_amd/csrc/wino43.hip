@@ -137,8 +137,8 @@ __device__ __forceinline__ float4 w43_sub4(float4 a, float4 b) { return make_flo
 // through one buffer descriptor over the slab's images -- a pixel outside its image is an out-of-range offset and reads as
 // zero (the convolution's padding).  Every thread transforms its 36 pixels x 4 channels in registers and writes 36 float4;
 // the 8 tiles x 2 quads of a chunk form two 128-byte runs of that chunk's 1 KB piece.
-// Measured (128 channels @ 6 x 232 x 400: 285 MB in, 641 MB out): 194 us = 4.8 TB/s; stores alone 94 us (6.8 TB/s), loads alone
-// 77 us.  Not changed by: a float2-per-lane form at four waves per SIMD instead of two (187 us), nontemporal stores, writing V
+// Measured (128 channels @ 6 x 232 x 400: 285 MB in, 641 MB out), every thread loading its whole patch: 194 us = 4.8 TB/s; stores
+// alone 94 us (6.8 TB/s), loads alone 77 us.  Not changed by: a float2-per-lane form at four waves per SIMD instead of two (187 us), nontemporal stores, writing V
 // into a 75 MB slab that stays in the Infinity Cache -- the read/write mix on HBM is what bounds it.
 __global__ __launch_bounds__(256) void srf_wino43_xform_k(W43Args a)
 {
@@ -161,6 +161,11 @@ __global__ __launch_bounds__(256) void srf_wino43_xform_k(W43Args a)
     const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
     const unsigned px_b = (unsigned)(a.x_ld * 4);
     const unsigned chan_b = (unsigned)((c * 8 + q * 4) * 4) + (unsigned)(n - a.n0) * (unsigned)img_b;
+    // Horizontally adjacent tiles share two of their six patch columns: when the next tile of the wave (lane + 8: same channel
+    // quad) is this tile's right neighbour in the same image row, columns 4 and 5 are ITS columns 0 and 1 -- taken from its
+    // registers (48 ds_bpermute per thread) instead of from memory: 24 + ~1.5 loads per thread instead of 36 (the vertical halo
+    // between tile rows lives in other workgroups and is still read twice).
+    const bool share = (lane < 56) && live && (g + 1 < (int)a.ntiles) && (tx + 1 < a.tilesX);
     float4 d[6][6];
 #pragma unroll
     for (int py = 0; py < 6; ++py) {
@@ -170,12 +175,20 @@ __global__ __launch_bounds__(256) void srf_wino43_xform_k(W43Args a)
 #pragma unroll
         for (int px = 0; px < 6; ++px) {
             const int x = x0 + px;
-            const bool ok = yok && x >= 0 && x < a.W;
+            const bool ok = yok && x >= 0 && x < a.W && !(px >= 4 && share);
             const unsigned off = ok ? row_b + (unsigned)x * px_b : 0xFFFFFFF8u;
             auto v_ = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0);
             d[py][px] = *reinterpret_cast<float4 *>(&v_);
         }
     }
+#pragma unroll
+    for (int py = 0; py < 6; ++py)
+#pragma unroll
+        for (int px = 4; px < 6; ++px) {
+            const float4 nb = d[py][px - 4];
+            const float sx = __shfl_down(nb.x, 8), sy = __shfl_down(nb.y, 8), sz = __shfl_down(nb.z, 8), sw = __shfl_down(nb.w, 8);
+            if (share) d[py][px] = make_float4(sx, sy, sz, sw);
+        }
     if (!c_ok) return;
     // vertical stage (over py) per column, in place
 #pragma unroll
