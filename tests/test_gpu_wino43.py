@@ -147,3 +147,23 @@ def test_wino43_rejects_what_it_cannot_run():
     assert ops.wino43_supported(x, 8)
     with pytest.raises(ValueError):
         ops.wino43(x, torch.zeros(16, device=DEV), 8)   # packed weight of the wrong size
+
+
+def test_wino43_split_calls_equal_the_single_call():
+    """`srf_wino43_transform` + `srf_wino43_multiply` (the two kernels as separate C-ABI calls: what bench.py times apart) write
+    the bits of `srf_wino43`."""
+    from srfdet3d_amd import _lib
+    from srfdet3d_amd.ops import _ptr, _stream
+    x, w, scale, shift = _case(2, 37, 50, 96, 160, 77)
+    pk = ops.pack_wino43_weights(w)
+    want = ops.wino43(x, pk, 160, scale, shift, True)
+    L = _lib.lib()
+    N, H, W, Cin = x.shape
+    nbytes = L.srf_wino43_workspace_bytes(N, H, W, Cin, 160)
+    ws = torch.empty(nbytes // 4, device=DEV)
+    got = torch.full_like(want, float("nan"))
+    assert L.srf_wino43_transform(_ptr(x), N, H, W, Cin, Cin, 160, _ptr(ws), nbytes, _stream()) == 0
+    assert L.srf_wino43_multiply(_ptr(ws), nbytes, N, H, W, Cin, _ptr(pk), 160, _ptr(scale), _ptr(shift), 1, _ptr(got), 160, _stream()) == 0
+    assert torch.equal(got, want)
+    # too small a workspace is refused, not overrun
+    assert L.srf_wino43_transform(_ptr(x), N, H, W, Cin, Cin, 160, _ptr(ws), nbytes - 1024, _stream()) == -2

@@ -1,6 +1,5 @@
 """Weight-gradient kernels MIOpen picks for the trainable 3x3 layers of config 4, channels-last vs contiguous operands
 (developer probe: which layout to hand to aten.convolution_backward in train_conv.py)."""
-import sys
 import time
 
 import torch
