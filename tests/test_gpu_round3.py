@@ -277,3 +277,64 @@ def test_packed_weight_caches_are_dropped_on_mode_switch(dev):
         nhwc.invalidate_caches(holder)
         y1 = nhwc.conv3x3(x, conv)
     torch.testing.assert_close(y1, 2 * y0, rtol=1e-5, atol=1e-6)
+
+
+def test_camera_branch_at_full_size_matches_torch_cpu(dev):
+    """BASELINE.json's full camera input (six 928 x 1600 views) through VoVNet-99 -> image FPN -> the head's img_convs on the HIP
+    channels-last executor (srf_stem_conv_nchw, srf_wino43 on every 3x3 layer from stage 2 on, srf_wino3x3, srf_conv_gemm_nhwc,
+    srf_conv1x1_nhwc_direct / _pooled / _topdown, the streaming kernels) against the SAME modules run by torch on the CPU
+    (its own direct convolutions): every level of the pyramid within 2e-4 of its maximum.  The kernels that are 90 % of the
+    headline frame at the size the headline is quoted on, against an implementation that shares no code with them (VERDICT r2,
+    weak 2 / 3: until now the full sizes were checked per layer against this repo's own direct kernel and rocBLAS)."""
+    torch.manual_seed(0)
+    cpu = workloads.build("srfdet_voxel_nusc_LC", 16).eval()
+    _randomize_bn(cpu, 0)
+    img = torch.from_numpy(S.camera_images(3000))                      # (1, 6, 3, 928, 1600)
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes, lidar2img=[m for m in S.camera_rig()])]
+    gpu = copy.deepcopy(cpu).to(dev)
+    with torch.no_grad():
+        got = gpu.extract_img_feat(img.to(dev), copy.deepcopy(metas))
+        got = gpu.bbox_head._img_convs_only(got)
+        got = [g.float().cpu() for g in got]
+        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+        want = cpu.bbox_head._img_convs_only(cpu.extract_img_feat(img, copy.deepcopy(metas)))
+    assert len(got) == len(want) == 4
+    for lvl, (a, b) in enumerate(zip(got, want)):
+        assert a.shape == b.shape == (1, 6, 128, 232 >> lvl, 400 >> lvl)
+        err = (a - b).abs().max().item()
+        assert err <= 2e-4 * b.abs().max().item(), (lvl, err, b.abs().max().item())
+        assert b.abs().max().item() > 1e-3
+
+
+def test_lc_frame_at_full_size_graphs_equal_eager(dev):
+    """The headline configuration at the headline size (30k points, six 928 x 1600 views, np = 200): the three-graph frame
+    (camera graph beside the BEV half, decoder half after the join) against the eager frame -- pre-NMS scores within 1e-5, box
+    parameters within 1e-4 (the contract of north_star), on two different sweeps and on replays."""
+    torch.manual_seed(0)
+    cpu = workloads.build("srfdet_voxel_nusc_LC", 200).eval()
+    _randomize_bn(cpu, 0)
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes, lidar2img=[m for m in S.camera_rig()])]
+    img = torch.from_numpy(S.camera_images(3000)).to(dev)
+    frames = [torch.from_numpy(S.nuscenes_sweep(2000 + i)).to(dev) for i in range(2)]
+    eager = copy.deepcopy(cpu).to(dev)
+    with torch.no_grad():
+        want = []
+        for p in frames:
+            mt = copy.deepcopy(metas)
+            img_feats, pt_feats = eager.extract_feat(img, [p], mt)
+            want.append([t.clone() for t in eager.bbox_head.decode(*eager.bbox_head(img_feats, pt_feats, mt))])
+    del eager
+    g = copy.deepcopy(cpu).to(dev).enable_hip_graphs(img_overlap=True, whole_frame=True)
+    with torch.no_grad():
+        g.simple_test(img, [frames[0]], copy.deepcopy(metas))          # eager pass + captures
+        for rep in range(2):
+            for p, w in zip(frames, want):
+                g.simple_test(img, [p], copy.deepcopy(metas))
+                e = g._graphed_frame.entry
+                torch.testing.assert_close(e["scores"], w[0], rtol=0, atol=1e-5)
+                torch.testing.assert_close(e["boxes"], w[1], rtol=2e-5, atol=1e-4)
+    assert g._graphed_frame.stats["replays"] >= 4
+    g._graphed_frame = g._graphed_img = g._graphed_tail = None
+    del g
+    gc.collect()
+    torch.cuda.empty_cache()
