@@ -524,14 +524,20 @@ extern "C" size_t srf_wino43_workspace_bytes(int N, int H, int W, int Cin, int C
 }
 
 // argument block shared by srf_wino43 and the developer bench (tools/micro/wino43_bench.hip)
+#define W43_NEED_X 1   /* the transform kernel's operands are checked */
+#define W43_NEED_Y 2   /* the multiply kernel's operands are checked */
 static int w43_make_args(W43Args &a, const float *x, int N, int H, int W, int Cin, long long x_ld, const float *U_packed, int Cout,
-                         const float *scale, const float *shift, int relu, float *y, long long y_ld, void *workspace, size_t workspace_bytes)
+                         const float *scale, const float *shift, int relu, float *y, long long y_ld, void *workspace, size_t workspace_bytes,
+                         int need = W43_NEED_X | W43_NEED_Y)
 {
-    if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || x_ld < Cin || y_ld < Cout) return SRF_EINVAL;
+    if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SRF_EINVAL;
+    if (((need & W43_NEED_X) && x_ld < Cin) || ((need & W43_NEED_Y) && y_ld < Cout)) return SRF_EINVAL;
     if (N == 0) return SRF_OK;
-    if (!x || !U_packed || !y || !workspace) return SRF_EINVAL;
-    if ((Cin & 7) || (Cout & 3) || (x_ld & 3) || (y_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)U_packed & 15) ||
-        ((uintptr_t)workspace & 15) || (scale && ((uintptr_t)scale & 15)) || (shift && ((uintptr_t)shift & 15)))
+    if (!workspace || ((need & W43_NEED_X) && !x) || ((need & W43_NEED_Y) && (!U_packed || !y))) return SRF_EINVAL;
+    if ((Cin & 7) || (Cout & 3) || ((uintptr_t)workspace & 15)) return SRF_EUNSUPPORTED;
+    if ((need & W43_NEED_X) && ((x_ld & 3) || ((uintptr_t)x & 15))) return SRF_EUNSUPPORTED;
+    if ((need & W43_NEED_Y) && ((y_ld & 3) || ((uintptr_t)y & 15) || ((uintptr_t)U_packed & 15) || (scale && ((uintptr_t)scale & 15)) ||
+                                (shift && ((uintptr_t)shift & 15))))
         return SRF_EUNSUPPORTED;
     if (workspace_bytes < srf_wino43_workspace_bytes(N, H, W, Cin, Cout)) return SRF_EWORKSPACE;
     a.x = x;
@@ -645,9 +651,7 @@ extern "C" int srf_wino43_transform(const float *x, int N, int H, int W, int Cin
                                     size_t workspace_bytes, srf_stream_t stream)
 {
     W43Args a;
-    // U, y stand-ins pass the pointer checks of the shared argument builder; the transform kernel reads neither
-    const int rc = w43_make_args(a, x, N, H, W, Cin, x_ld, (const float *)workspace, Cout, nullptr, nullptr, 0, (float *)workspace,
-                                 (long long)((Cout + 3) & ~3), workspace, workspace_bytes);
+    const int rc = w43_make_args(a, x, N, H, W, Cin, x_ld, nullptr, Cout, nullptr, nullptr, 0, nullptr, 4, workspace, workspace_bytes, W43_NEED_X);
     if (rc != SRF_OK || N == 0) return rc;
     if (w43_slab_tb(a.ntb, a.nchunk, a.ncb) < a.ntb) return SRF_EUNSUPPORTED;
     W43Args s;
@@ -660,12 +664,11 @@ extern "C" int srf_wino43_multiply(const void *workspace, size_t workspace_bytes
                                    int Cout, const float *scale, const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream)
 {
     W43Args a;
-    const int rc = w43_make_args(a, (const float *)workspace, N, H, W, Cin, (long long)Cin, U_packed, Cout, scale, shift, relu, y, y_ld,
-                                 const_cast<void *>(workspace), workspace_bytes);
+    const int rc = w43_make_args(a, nullptr, N, H, W, Cin, 4, U_packed, Cout, scale, shift, relu, y, y_ld, const_cast<void *>(workspace),
+                                 workspace_bytes, W43_NEED_Y);
     if (rc != SRF_OK || N == 0) return rc;
     if (w43_slab_tb(a.ntb, a.nchunk, a.ncb) < a.ntb) return SRF_EUNSUPPORTED;
-    W43Args s;
-    a.x_ld = 4;   // x is not read by the multiply kernel; keep the slab's 32-bit extent check on y alone
+    W43Args s;   // (x_ld = y_ld stand-ins of 4 keep the unused tensor out of the slab's 32-bit extent check)
     const int r0 = w43_slab_args(a, 0, a.ntb, s);
     if (r0 != SRF_OK) return r0;
     return w43_launch_mm(s, (hipStream_t)stream);
