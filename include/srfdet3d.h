@@ -35,6 +35,9 @@ typedef void *srf_stream_t;
 #define SRF_EHIP_BASE (-1000) /* -(1000 + hipError_t) */
 
 int srf_abi_version(void);
+/* 0 = the production library; 1 = the developer build (-DSRF_DEV: kernels for timing ablations whose outputs are wrong by
+ * design).  A loader must refuse flavour 1 as the product library. */
+int srf_build_flavour(void);
 const char *srf_error_string(int code);
 /* Number of HIP devices visible, or a negative error.  Used by the Python loader to fail loudly. */
 int srf_device_count(void);

@@ -8,6 +8,9 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_longlong, c_siz
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsrfdet3d_hip.so")
+# the developer build (`python -m srfdet3d_amd.build --dev`: ablation kernels with wrong outputs by design) has its own file
+# name and is loaded only when SRF_DEV_LIB=1 asks for it (tools/stamp_wino.py); it can never sit at LIB_PATH
+DEV_LIB_PATH = os.path.join(_HERE, "libsrfdet3d_hip_dev.so")
 
 _lib = None
 
@@ -26,6 +29,7 @@ _HI = POINTER(c_int)    # host int array
 # name -> (restype, argtypes); must list every symbol include/srfdet3d.h declares
 SIGNATURES = {
     "srf_abi_version": (c_int, []),
+    "srf_build_flavour": (c_int, []),
     "srf_error_string": (c_char_p, [c_int]),
     "srf_device_count": (c_int, []),
     "srf_points_filter_workspace_bytes": (c_size_t, [c_int]),
@@ -137,15 +141,24 @@ def lib():
     """The loaded library; raises RuntimeError if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        want_dev = os.environ.get("SRF_DEV_LIB", "0") == "1"
+        path = DEV_LIB_PATH if want_dev else LIB_PATH
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -m srfdet3d_amd.build` "
-                "(or __graft_entry__.build()). srfdet3d_amd has no CPU fallback.")
-        handle = ctypes.CDLL(LIB_PATH)
+                f"{path} is missing: the HIP extension has not been built. Run `python -m srfdet3d_amd.build"
+                f"{' --dev' if want_dev else ''}` (or __graft_entry__.build()). srfdet3d_amd has no CPU fallback.")
+        handle = ctypes.CDLL(path)
+        flavour = getattr(handle, "srf_build_flavour", None)
+        if flavour is None:
+            raise RuntimeError(f"{path} does not export srf_build_flavour; rebuild it")
+        flavour.restype = c_int
+        if flavour() != (1 if want_dev else 0):
+            raise RuntimeError(f"{path} is a {'production' if want_dev else 'DEVELOPER (-DSRF_DEV, wrong-by-design ablation kernels)'} "
+                               "build under the other's name; rebuild with `python -m srfdet3d_amd.build --force`")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name, None)
             if fn is None:
-                raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it")
+                raise RuntimeError(f"{path} does not export {name}; rebuild it")
             fn.restype = res
             fn.argtypes = args
         _lib = handle

@@ -7,6 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrfdet3d_hip.so")
+DEV_LIB = os.path.join(HERE, "libsrfdet3d_hip_dev.so")   # never the production path
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math",
          "-ffp-contract=off",  # kernels write their fma chains explicitly (parity with the oracle)
@@ -27,14 +28,17 @@ def stale():
 
 def build(force=False, verbose=False, dev=False):
     """dev=True (`--dev`): -DSRF_DEV, the developer build with the timing-ablation kernels (wrong outputs by design), the stamp
-    hooks and their knobs (SRF_WINO_DBG); never the library that ships or that the tests and bench.py load."""
+    hooks and their knobs (SRF_WINO_DBG); written to libsrfdet3d_hip_dev.so (own object directory), never to the path of the
+    library that ships and that the tests and bench.py load; `_lib.py` loads it only under SRF_DEV_LIB=1 and checks
+    srf_build_flavour() either way."""
     if not force and not dev and not stale():
         return LIB
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    objdir = os.path.join(HERE, "build", "dev" if dev else "prod")
+    os.makedirs(objdir, exist_ok=True)
     for src in sources():
-        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + (["-DSRF_DEV=1"] if dev else []) + ["-c", src, "-o", obj]
         if verbose:
@@ -46,8 +50,9 @@ def build(force=False, verbose=False, dev=False):
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    out = DEV_LIB if dev else LIB
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
 
 
 if __name__ == "__main__":

@@ -3,6 +3,17 @@
 
 extern "C" int srf_abi_version(void) { return 1; }
 
+// 0 = production; 1 = developer build (-DSRF_DEV: timing-ablation kernels with wrong outputs by design, stamp hooks).  The
+// Python loader refuses a library that answers 1 unless the caller asked for the developer library by name.
+extern "C" int srf_build_flavour(void)
+{
+#ifdef SRF_DEV
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" const char *srf_error_string(int code)
 {
     switch (code) {

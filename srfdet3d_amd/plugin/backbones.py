@@ -29,7 +29,7 @@ class SECONDCustom(BaseModule):
     def forward(self, x):
         from .. import nhwc
         if nhwc.enabled() and nhwc.second_supported(self, x):
-            return nhwc.second_forward(self, x)   # fp32 inference on the GPU: channels-last, 3x3 layers on srf_wino3x3
+            return nhwc.second_forward(self, x)   # fp32 inference on the GPU: channels-last, 3x3 / stride-1 layers on srf_wino43 (F(4x4, 3x3)), stride-2 on srf_conv_gemm_nhwc
         outs = []
         for stage in self.blocks:
             x = run_sequential(stage, x)

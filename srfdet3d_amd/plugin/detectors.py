@@ -61,6 +61,7 @@ class SRFDet(BaseModule):
         to the eager path; opt-in because a graph pins its buffers for the lifetime of the model.  img_overlap=True
         replays the image graph on a side stream beside the eager LiDAR half."""
         from ..graphs import GraphedFrame, GraphedImageBranch, GraphedTail
+        self._graph_cfg = dict(enabled=enabled, img_overlap=img_overlap, whole_frame=whole_frame)
         self._graphed_tail = GraphedTail(self) if enabled else None
         self._graphed_img = GraphedImageBranch(self, overlap=img_overlap) if (enabled and self.use_img) else None
         # hard voxelization: the whole LiDAR frame replays as one graph (no host read-back inside the frame); with
@@ -68,18 +69,28 @@ class SRFDet(BaseModule):
         self._graphed_frame = GraphedFrame(self) if (enabled and whole_frame and GraphedFrame.eligible(self)) else None
         return self
 
-    def train(self, mode=True):
-        """Also drops the packed-weight images the channels-last executor cached on the convolutions (nhwc.invalidate_caches):
-        whatever was done to the weights before a mode switch -- incl. in-place updates through `.data`, which the caches'
-        (version, pointer) key cannot see -- the next inference pass packs them afresh."""
+    def _drop_derived_state(self):
+        """Packed-weight images cached on the convolutions AND the captured hipGraphs.  A graph holds the raw device pointers of
+        the packed weights of its warm-up pass; once those tensors are dropped their blocks return to the caching allocator, and a
+        replay would read whatever lives there next as weights.  So both go together: the next inference pass packs
+        afresh and recaptures."""
         from .. import nhwc
         nhwc.invalidate_caches(self)
+        cfg = getattr(self, "_graph_cfg", None)
+        if cfg is not None and (self._graphed_tail is not None or self._graphed_img is not None or self._graphed_frame is not None):
+            self._graphed_tail = self._graphed_img = self._graphed_frame = None   # release the old graphs and their pools first
+            self.enable_hip_graphs(**cfg)
+
+    def train(self, mode=True):
+        """Also drops what was derived from the weights (`_drop_derived_state`): whatever was done to them before a mode switch --
+        incl. in-place updates through `.data`, which the caches' (version, pointer) key cannot see -- the next inference pass
+        packs them afresh and recaptures its graphs."""
+        self._drop_derived_state()
         return super().train(mode)
 
     def load_state_dict(self, *args, **kwargs):
-        from .. import nhwc
         out = super().load_state_dict(*args, **kwargs)
-        nhwc.invalidate_caches(self)
+        self._drop_derived_state()
         return out
 
     def init_weights(self):

@@ -495,9 +495,9 @@ class SRFDetHead(BaseModule):
     @staticmethod
     def _channel_sum(x):
         """(bs, C, H, W) -> (bs, H*W), summed over channels (srfdet_head.py:537).  On the GPU it is done as a row
-        reduction: torch's strided `sum(dim=1)` can become a multi-block "global reduce" that clears its semaphores with
-        a memset -- a memset NODE once captured, and those do not reliably take effect on hipGraph replay
-        (graphs._validate caught this on the image DPG and on the KITTI / Waymo BEV sizes)."""
+        reduction: torch's strided `sum(dim=1)` can become a multi-block "global reduce" whose captured form failed the
+        replay validation (graphs._validate caught it on the image DPG and on the KITTI / Waymo BEV sizes; the cause inside
+        torch is not established -- memset nodes themselves do replay correctly)."""
         if x.is_cuda and not torch.is_grad_enabled():
             return x.flatten(2).transpose(1, 2).contiguous().sum(dim=-1)
         return x.sum(dim=1).flatten(1, 2)

@@ -1,8 +1,11 @@
 """`VoVNet` image backbone (mmdet3d_plugin/models/backbones/vovnet.py:269-374): one-shot-aggregation stages with eSE
 attention; V-99-eSE feeds the LC configs (configs/nus/srfdet_voxel_nusc_LC.py:44-54).
 
-Plain dense convolutions (torch -> MIOpen): SURVEY.md ranks it "next" (8f-2), not a hand-kernel target.  It is here
-so that the LC workload runs end to end; module and parameter names follow the reference so its checkpoints load
+The modules own the parameters; fp32 inference on the GPU executes them channels-last on the hand-written kernels
+(`nhwc.vovnet_forward`: srf_stem_conv_nchw, srf_wino43 / srf_wino3x3, srf_conv_gemm_nhwc, srf_conv1x1_nhwc*, the streaming
+kernels of csrc/nhwc.hip -- SURVEY.md 8f-2, 90 % of the LC frame); training and the optional autocast mode go through the
+modules as written (torch -> MIOpen, `train_conv.py` for the trainable 3x3 layers).  Module and parameter names follow the
+reference so its checkpoints load
 (`stem.stem_1/conv.weight`, `stage3.OSA3_2.layers.0.OSA3_2_0/conv.weight`, `...concat.OSA3_2_concat/conv.weight`,
 `...ese.fc.weight`).
 """

@@ -83,3 +83,27 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_developer_build_is_refused_as_the_product_library(monkeypatch, tmp_path):
+    """`build --dev` (ablation kernels, wrong outputs by design) writes libsrfdet3d_hip_dev.so; a library
+    that answers srf_build_flavour() == 1 under the production name is refused (and the reverse under SRF_DEV_LIB=1)."""
+    import shutil
+    import subprocess
+    from srfdet3d_amd import build as B
+    assert os.path.basename(B.DEV_LIB) != os.path.basename(B.LIB)
+    assert _lib.lib().srf_build_flavour() == 0
+    src = tmp_path / "fake.c"
+    src.write_text("int srf_build_flavour(void) { return 1; }\n")
+    fake = tmp_path / "libsrfdet3d_hip.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(fake), str(src)])
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(fake))
+    with pytest.raises(RuntimeError, match="DEVELOPER"):
+        _lib.lib()
+    # and the production library is not accepted where the developer library was asked for
+    monkeypatch.setenv("SRF_DEV_LIB", "1")
+    monkeypatch.setattr(_lib, "DEV_LIB_PATH", str(tmp_path / "prod_as_dev.so"))
+    shutil.copy(B.LIB, str(tmp_path / "prod_as_dev.so"))
+    with pytest.raises(RuntimeError, match="production"):
+        _lib.lib()

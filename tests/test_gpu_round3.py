@@ -279,33 +279,6 @@ def test_packed_weight_caches_are_dropped_on_mode_switch(dev):
     torch.testing.assert_close(y1, 2 * y0, rtol=1e-5, atol=1e-6)
 
 
-def test_camera_branch_at_full_size_matches_torch_cpu(dev):
-    """BASELINE.json's full camera input (six 928 x 1600 views) through VoVNet-99 -> image FPN -> the head's img_convs on the HIP
-    channels-last executor (srf_stem_conv_nchw, srf_wino43 on every 3x3 layer from stage 2 on, srf_wino3x3, srf_conv_gemm_nhwc,
-    srf_conv1x1_nhwc_direct / _pooled / _topdown, the streaming kernels) against the SAME modules run by torch on the CPU
-    (its own direct convolutions): every level of the pyramid within 2e-4 of its maximum.  The kernels that are 90 % of the
-    headline frame at the size the headline is quoted on, against an implementation that shares no code with them (VERDICT r2,
-    weak 2 / 3: until now the full sizes were checked per layer against this repo's own direct kernel and rocBLAS)."""
-    torch.manual_seed(0)
-    cpu = workloads.build("srfdet_voxel_nusc_LC", 16).eval()
-    _randomize_bn(cpu, 0)
-    img = torch.from_numpy(S.camera_images(3000))                      # (1, 6, 3, 928, 1600)
-    metas = [dict(box_type_3d=LiDARInstance3DBoxes, lidar2img=[m for m in S.camera_rig()])]
-    gpu = copy.deepcopy(cpu).to(dev)
-    with torch.no_grad():
-        got = gpu.extract_img_feat(img.to(dev), copy.deepcopy(metas))
-        got = gpu.bbox_head._img_convs_only(got)
-        got = [g.float().cpu() for g in got]
-        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
-        want = cpu.bbox_head._img_convs_only(cpu.extract_img_feat(img, copy.deepcopy(metas)))
-    assert len(got) == len(want) == 4
-    for lvl, (a, b) in enumerate(zip(got, want)):
-        assert a.shape == b.shape == (1, 6, 128, 232 >> lvl, 400 >> lvl)
-        err = (a - b).abs().max().item()
-        assert err <= 2e-4 * b.abs().max().item(), (lvl, err, b.abs().max().item())
-        assert b.abs().max().item() > 1e-3
-
-
 def test_lc_frame_at_full_size_graphs_equal_eager(dev):
     """The headline configuration at the headline size (30k points, six 928 x 1600 views, np = 200): the three-graph frame
     (camera graph beside the BEV half, decoder half after the join) against the eager frame -- pre-NMS scores within 1e-5, box
@@ -334,6 +307,44 @@ def test_lc_frame_at_full_size_graphs_equal_eager(dev):
                 torch.testing.assert_close(e["scores"], w[0], rtol=0, atol=1e-5)
                 torch.testing.assert_close(e["boxes"], w[1], rtol=2e-5, atol=1e-4)
     assert g._graphed_frame.stats["replays"] >= 4
+    g._graphed_frame = g._graphed_img = g._graphed_tail = None
+    del g
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_graphs_are_recaptured_when_the_packed_weights_are_dropped(dev):
+    """`eval()` / `train()` / `load_state_dict` drop the packed-weight images (nhwc.invalidate_caches); a captured
+    hipGraph holds their raw pointers, so the graphs must go with them.  Capture, switch modes, let the allocator hand the freed
+    blocks to something else, run again: the frame must equal the eager frame, not read recycled memory as weights."""
+    torch.manual_seed(0)
+    cpu = workloads.build("srfdet_voxel_nusc_L", 32).eval()
+    _randomize_bn(cpu, 0)
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes)]
+    pts = torch.from_numpy(S.nuscenes_sweep(2000, 8000)).to(dev)
+    eager = copy.deepcopy(cpu).to(dev)
+    with torch.no_grad():
+        f = eager.extract_point_features([pts])
+        want = [t.clone() for t in eager.bbox_head.decode(*eager.bbox_head(None, f, metas))]
+    g = copy.deepcopy(cpu).to(dev).enable_hip_graphs(whole_frame=True)
+    with torch.no_grad():
+        for _ in range(3):
+            g.simple_test(None, [pts], copy.deepcopy(metas))
+        first = g._graphed_frame
+        assert first.stats["replays"] >= 1
+        g.eval()                                           # drops the packed weights -> must drop the graphs too
+        assert g._graphed_frame is not first and g._graphed_frame.entry is None
+        junk = [torch.full((1 << 20,), float("nan"), device=dev) for _ in range(64)]   # recycle the freed blocks
+        for _ in range(3):
+            g.simple_test(None, [pts], copy.deepcopy(metas))
+        e = g._graphed_frame.entry
+        assert g._graphed_frame.stats["replays"] >= 1
+        torch.testing.assert_close(e["scores"], want[0], rtol=0, atol=1e-5)
+        torch.testing.assert_close(e["boxes"], want[1], rtol=2e-5, atol=1e-4)
+        sd = {k: v.clone() for k, v in g.state_dict().items()}
+        g.load_state_dict(sd)
+        assert g._graphed_frame.entry is None
+    del junk
     g._graphed_frame = g._graphed_img = g._graphed_tail = None
     del g
     gc.collect()

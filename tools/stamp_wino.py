@@ -5,6 +5,7 @@ import os
 import sys
 
 os.environ["SRF_WINO_DBG"] = "8"
+os.environ["SRF_DEV_LIB"] = "1"   # load libsrfdet3d_hip_dev.so (never the production library)
 os.environ["SRF_WINO_W8"] = "0"
 import torch
 
@@ -20,8 +21,7 @@ out = torch.empty(N, H, W, Cout, device="cuda")
 nblk = 40000
 stamps = torch.zeros(nblk * 4, dtype=torch.int64, device="cuda")
 L = _lib.lib()
-L._handle if False else None
-fn = ctypes.CDLL(_lib.LIB_PATH).srf_dev_set_stamp_buffer
+fn = ctypes.CDLL(_lib.DEV_LIB_PATH).srf_dev_set_stamp_buffer
 fn.argtypes = [ctypes.c_void_p]
 fn(ctypes.c_void_p(stamps.data_ptr()))
 for _ in range(3):
