@@ -31,8 +31,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA": ~2.5 PF dense (the 5 PF headline includes 2:1 sparsity)
 HBM_PEAK_GBS = 8000.0         # same guide, "HBM3E peak BW" (spec)
-ROUND = "r03"                 # prefix of the profiles/ files this build's counter numbers live in
+ROUND = "r04"                 # prefix of the profiles/ files this build's counter numbers live in
 
 WORKLOADS = {
     "nusc_L": dict(cfg="srfdet_voxel_nusc_L", desc="srfdet_voxel_nusc_L inference (LiDAR-only), synthetic 30k-pt sweep, "
@@ -64,6 +65,8 @@ def main():
                     help="default: the configuration BASELINE.json's metric is quoted on (srfdet_voxel_nusc_LC)")
     ap.add_argument("--np", type=int, default=200, help="num_proposals override (BASELINE.json: np~200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-mfma-line", action="store_true",
+                    help="LC only: skip the second timed loop that runs the same frames with SRF_GEMM_SPLIT=0 (f32_mfma_only in the line)")
     ap.add_argument("--eager", action="store_true", help="do not replay the static tail as a hipGraph")
     ap.add_argument("--whole-frame", default="auto", choices=["auto", "on", "off"],
                     help="replay voxelization + sparse encoder + tail as hipGraphs with capacity-padded static shapes (one graph "
@@ -152,7 +155,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ops.KERNEL_TIMING = {"spconv": [], "wino": [], "gemm": [], "w43x": [], "w43m": []}  # HIP-event pairs around every launch of the timed region
+    ops.KERNEL_TIMING = {"spconv": [], "wino": [], "gemm": [], "gsplit": [], "w43x": [], "w43m": []}  # HIP-event pairs around every launch of the timed region
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -185,7 +188,7 @@ def main():
                     model.bbox_head._img_convs_only(feats_)  # the head's 3x3 convolutions on the camera levels: same kernel
         torch.cuda.synchronize()
         model._graphed_img = gi
-    wino_rec, gemm_rec = ops.KERNEL_TIMING["wino"], ops.KERNEL_TIMING["gemm"]
+    wino_rec, gemm_rec, gsplit_rec = ops.KERNEL_TIMING["wino"], ops.KERNEL_TIMING["gemm"], ops.KERNEL_TIMING["gsplit"]
     w43x_rec, w43m_rec = ops.KERNEL_TIMING["w43x"], ops.KERNEL_TIMING["w43m"]
     ops.KERNEL_TIMING = None
     if world > 1:
@@ -217,14 +220,19 @@ def main():
             return d.get("traffic_bytes_per_launch")
 
         def _in_graph(name):
-            """ms per frame of a kernel family inside the timed hipGraphs, from the tracked rocprofv3 kernel trace of the same
-            command (profiles/<round>_in_graph_summary.json, written by tools/in_graph_summary.py): kernels of the camera graph
-            share the chip with the BEV half there, so this is larger than the serial event time."""
+            """ms per frame of a kernel family inside the timed hipGraphs, QUOTED from the tracked rocprofv3 kernel trace of the same
+            command (profiles/<round>_in_graph_summary.json, written by tools/in_graph_summary.py with the sha of the kernel sources it
+            ran): not measured in this run, labelled `quoted_from`, and dropped when the sources have changed since (like `traffic`)."""
             path = os.path.join(ROOT, "profiles", f"{ROUND}_in_graph_summary.json")
             if not os.path.exists(path):
                 return None
             with open(path) as fh:
-                return json.load(fh).get(args.workload, {}).get(name)
+                d = json.load(fh)
+            if d.get("kernel_source_sha16") != _source_id() and not os.environ.get("SRF_BENCH_ANY_TRAFFIC"):
+                return None
+            return d.get(args.workload, {}).get(name)
+
+        IN_GRAPH_FILE = f"profiles/{ROUND}_in_graph_summary.json"
 
         # the dominant sparse-conv shape = the (Cin, Cout, K) group with the most time: the 128 -> 128, 27-offset SubM conv on
         # nuScenes / Waymo (4 launches per frame on the 5x184x184 level), 64 -> 64 on KITTI's narrower encoder
@@ -265,15 +273,15 @@ def main():
                          gbs=round(by / (ms * 1e-3) / 1e9, 1), frac_hbm=round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          measured=roofline_source)
 
-        def _dense(recs, kernel, name, passes=1):
+        def _dense(recs, kernel, name, passes=1, peak=F32_MFMA_PEAK_TFLOPS):
             if not recs:
                 return None
             t_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             direct, executed, byts = sum(r[3] for r in recs), sum(r[4] for r in recs), sum(r[5] for r in recs)
             worst = max(recs, key=lambda r: r[0].elapsed_time(r[1]))
             ach = executed / (t_ms * 1e-3) / 1e12
-            d = dict(kernel=kernel, bound="mfma", achieved=round(ach, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                     frac=round(ach / F32_MFMA_PEAK_TFLOPS, 4), traffic=_traffic(name), launches=len(recs),
+            d = dict(kernel=kernel, bound="mfma", achieved=round(ach, 3), peak=peak, unit="TFLOP/s",
+                     frac=round(ach / peak, 4), traffic=_traffic(name), launches=len(recs),
                      avg_us=round(t_ms * 1e3 / len(recs), 2), serial_ms_per_frame=round(t_ms / passes, 3), measured=dense_source,
                      algorithmic_flops_per_launch=int(executed / len(recs)),
                      direct_equivalent_tflops=round(direct / (t_ms * 1e-3) / 1e12, 3),
@@ -281,10 +289,13 @@ def main():
                      longest_launch=dict(layer=worst[2], us=round(worst[0].elapsed_time(worst[1]) * 1e3, 1)),
                      note="aggregate over all launches of the kernel in a frame: sum of FLOPs over sum of event times; traffic and "
                           "algorithmic bytes are averages over the same launches")
+            if d["traffic"] is not None:
+                d["traffic_quoted_from"] = f"profiles/{ROUND}_pmc_{name}_traffic.json"
             ig = _in_graph(name)
             if ig is not None:
                 d["in_graph_ms_per_frame"] = ig
-                d["in_graph_frac"] = round(executed / passes / (ig * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)
+                d["in_graph_frac"] = round(executed / passes / (ig * 1e-3) / 1e12 / peak, 4)
+                d["in_graph_quoted_from"] = IN_GRAPH_FILE
             return d
 
         def _stream(recs, kernel, name, passes=1):
@@ -297,9 +308,12 @@ def main():
             d = dict(kernel=kernel, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                      traffic=_traffic(name), launches=len(recs), avg_us=round(t_ms * 1e3 / len(recs), 2),
                      serial_ms_per_frame=round(t_ms / passes, 3), measured=dense_source, algorithmic_bytes_per_launch=int(byts / len(recs)))
+            if d["traffic"] is not None:
+                d["traffic_quoted_from"] = f"profiles/{ROUND}_pmc_{name}_traffic.json"
             ig = _in_graph(name)
             if ig is not None:
                 d["in_graph_ms_per_frame"] = ig
+                d["in_graph_quoted_from"] = IN_GRAPH_FILE
             return d
 
         cam_passes = 3 if dense_source != roofline_source else max(1, args.steps)
@@ -310,8 +324,16 @@ def main():
                         "wino43xf", cam_passes)
         wino = _dense(wino_rec, "srf_wino3x3_k (Winograd F(2x2,3x3): the 3x3 layers below 96 input channels -- VoVNet stem_2; `achieved` "
                                 "counts the FLOPs it executes on the MFMA = direct FLOPs / 2.25)", "wino3x3", cam_passes)
-        gemm = _dense(gemm_rec, "srf_conv1x1_nhwc_k (the OSA concat 1x1 convolutions and the FPN laterals as one GEMM each)", "conv1x1",
-                      cam_passes)
+        gemm = _dense(gemm_rec, "srf_conv1x1_nhwc_k / srf_gemm_direct_k (the OSA concat 1x1 convolutions and the FPN laterals as one GEMM "
+                                "each, on the f32 MFMA)", "conv1x1", cam_passes)
+        gsplit = _dense(gsplit_rec, "srf_gemm_split_k (the same 1x1 convolutions as f32 GEMMs on the bf16 MFMA: exact three-way bf16 split of "
+                                    "both operands, six of the nine partial products accumulated in f32; `achieved` = the bf16 FLOPs it issues = "
+                                    "6 x the f32 GEMM's, against the dense bf16 peak; direct_equivalent_tflops = the f32 GEMM's own rate)",
+                        "gemmsplit", cam_passes, peak=BF16_MFMA_PEAK_TFLOPS)
+        if gsplit is not None and gemm is None:
+            gemm = gsplit
+        elif gsplit is not None:
+            gemm["split"] = gsplit
         if w43m is not None or wino is not None:   # LC: the camera branch dominates the frame
             roofline = w43m if w43m is not None else wino
             if w43m is not None:
@@ -323,6 +345,33 @@ def main():
             roofline = spconv128
         if roofline is not None:
             roofline["stage"] = stage
+        # the same frames with the 1x1 convolutions on the f32-MFMA kernels (SRF_GEMM_SPLIT=0): a second model instance with its own
+        # graphs, timed like the headline right after it -- so that the line carries both arithmetic routes measured in one run
+        f32_mfma_only = None
+        split_on = ops.gemm_split_enabled() and nhwc_on
+        if (world == 1 and model.use_img and split_on and not args.img_precomputed and not args.eager and args.img_dtype == "fp32"
+                and not args.no_f32_mfma_line):
+            os.environ["SRF_GEMM_SPLIT"] = "0"
+            try:
+                m2 = copy.deepcopy(model_cpu).to(dev)
+                m2.enable_hip_graphs(img_overlap=args.img_overlap, whole_frame=args.whole_frame != "off")
+                with torch.no_grad():
+                    for i in range(max(4, args.warmup)):
+                        m2.simple_test(img, [frames[i % n_pool]], metas)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for i in range(args.steps):
+                        m2.simple_test(img, [frames[(args.warmup + i) % n_pool]], metas)
+                    torch.cuda.synchronize()
+                    el2 = time.perf_counter() - t1
+                f32_mfma_only = dict(value=round(args.steps / el2, 3), unit="frames/s", ms_per_step=round(el2 / args.steps * 1e3, 3),
+                                     steps=args.steps, note="same frames, same process, SRF_GEMM_SPLIT=0: every GEMM of the frame on "
+                                     "v_mfma_f32_32x32x2_f32 (one k-ordered fma chain per output)")
+                m2._graphed_frame = m2._graphed_img = m2._graphed_tail = None
+                del m2
+                torch.cuda.empty_cache()
+            finally:
+                os.environ.pop("SRF_GEMM_SPLIT", None)
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pipeline
@@ -359,10 +408,15 @@ def main():
                                whole_frame_graph=bool(getattr(model, "_graphed_frame", None) is not None), img_branch_overlap=bool(args.img_overlap and model.use_img),
                                img_features_precomputed=bool(args.img_precomputed and model.use_img),
                                img_branch=("channels-last on srf_wino43 / srf_wino3x3 / srf_conv1x1_nhwc" if nhwc.wino43_enabled() else "channels-last on srf_wino3x3 / srf_conv1x1_nhwc") if (model.use_img and nhwc_on) else ("MIOpen" if model.use_img else None),
+                               gemm_1x1=(("f32 GEMM on the bf16 MFMA (srf_gemm_split_k): every f32 operand split EXACTLY into three bf16 values, six of "
+                                          "the nine exact partial products accumulated in f32, dropped terms < 2^-23 of a product = one f32 "
+                                          "rounding; error vs float64 equal to the f32 fma chain's (tests/test_gpu_gemm_split.py); "
+                                          "SRF_GEMM_SPLIT=0 -> f32_mfma_only") if split_on else "f32 MFMA (k-ordered fma chain)")
+                               if (model.use_img and nhwc_on) else None,
                                graph_validation_failures=len(graphs.VALIDATION_LOG),
                                weights="seeded random init, randomised BN statistics",
                                parallelism=f"replica per GPU x{world}, frames sharded, no data-path collective"),
-                   roofline=roofline, cpu_baseline=cpu_baseline)
+                   roofline=roofline, cpu_baseline=cpu_baseline, f32_mfma_only=f32_mfma_only)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -410,6 +410,25 @@ int srf_conv1x1_nhwc_direct_topdown(const float *x, int N, int H, int W, int K, 
 int srf_conv1x1_nhwc_direct_pooled(const float *x, int N, long long HW, int K, long long x_ld, const float *W_packed, int Cout,
                                    const float *scale, const float *shift, int relu, float *y, long long y_ld, float *mean, void *workspace,
                                    size_t workspace_bytes, srf_stream_t stream);
+/* srf_conv1x1_nhwc_split*: the same three operations as an f32 GEMM computed on the bf16 MFMA (csrc/gemm_split.hip).  Every f32
+ * operand is the exact sum of three bf16 values (x = xh + xm + xl); of the nine exact partial products of a b the six of relative
+ * magnitude >= 2^-16 are accumulated in f32 on v_mfma_f32_32x32x16_bf16, the three dropped ones are together below 2^-23 |a b| (one
+ * f32 rounding of the product).  Error against float64 = that of the f32 fma chain (measured 2.0-2.8e-7 of sum |a b| against 1.7-3.0e-7);
+ * NOT bit-identical to srf_conv1x1_nhwc (another summation order), deterministic.  189-199 TFLOP/s f32-equivalent where the f32 MFMA
+ * kernels reach 122-135.  W_packed (bf16 planes, 6 bytes per weight) comes from srf_conv1x1_nhwc_split_pack_weights; x stays f32 and
+ * is split while it is staged.  Same arguments and limits as the _direct forms; workspace of the pooled form:
+ * srf_conv1x1_nhwc_pooled_workspace_bytes. */
+size_t srf_conv1x1_nhwc_split_packed_weight_bytes(int Cout, int K);
+int srf_conv1x1_nhwc_split_pack_weights(const float *W, int Cout, int K, void *packed, srf_stream_t stream);
+int srf_conv1x1_nhwc_split(const float *x, long long M, int K, long long x_ld, const void *W_packed, int Cout, const float *scale,
+                           const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream);
+int srf_conv1x1_nhwc_split_topdown(const float *x, int N, int H, int W, int K, long long x_ld, const void *W_packed, int Cout,
+                                   const float *scale, const float *shift, int relu, const float *top, int Ht, int Wt, long long top_ld,
+                                   float *y, long long y_ld, srf_stream_t stream);
+int srf_conv1x1_nhwc_split_pooled(const float *x, int N, long long HW, int K, long long x_ld, const void *W_packed, int Cout,
+                                  const float *scale, const float *shift, int relu, float *y, long long y_ld, float *mean,
+                                  void *workspace, size_t workspace_bytes, srf_stream_t stream);
+
 
 /* srf_conv1x1_nhwc_topdown: an FPN lateral convolution with the top-down step in its epilogue (mmdet FPN.forward:
  * `laterals[i - 1] += F.interpolate(laterals[i], size=..., mode="nearest")`, necks of configs/nus/srfdet_voxel_nusc_LC.py:55-64

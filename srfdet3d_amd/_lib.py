@@ -105,6 +105,13 @@ SIGNATURES = {
     "srf_conv1x1_nhwc_direct_pooled": (c_int, [_P, c_int, c_longlong, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_longlong, _P, _P,
                                                c_size_t, _P]),
     "srf_conv1x1_nhwc": (c_int, [_P, c_longlong, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_longlong, _P]),
+    "srf_conv1x1_nhwc_split_packed_weight_bytes": (c_size_t, [c_int, c_int]),
+    "srf_conv1x1_nhwc_split_pack_weights": (c_int, [_P, c_int, c_int, _P, _P]),
+    "srf_conv1x1_nhwc_split": (c_int, [_P, c_longlong, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_longlong, _P]),
+    "srf_conv1x1_nhwc_split_topdown": (c_int, [_P, c_int, c_int, c_int, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_longlong,
+                                               _P, c_longlong, _P]),
+    "srf_conv1x1_nhwc_split_pooled": (c_int, [_P, c_int, c_longlong, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_longlong, _P, _P,
+                                              c_size_t, _P]),
     "srf_conv1x1_nhwc_topdown": (c_int, [_P, c_int, c_int, c_int, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_longlong,
                                          _P, c_longlong, _P]),
     "srf_conv1x1_nhwc_pooled_workspace_bytes": (c_size_t, [c_int, c_longlong, c_int]),

@@ -55,7 +55,7 @@ def _cached(mod, key, vers, make):
     return cache[1]
 
 
-_CACHE_KEYS = ("_srf_wino", "_srf_wino43", "_srf_gemm", "_srf_gemm_direct", "_srf_cgemm", "_srf_packed")
+_CACHE_KEYS = ("_srf_wino", "_srf_wino43", "_srf_gemm", "_srf_gemm_direct", "_srf_gemm_split", "_srf_cgemm", "_srf_packed")
 
 
 def invalidate_caches(model):
@@ -124,11 +124,16 @@ def _gemm_direct_weights(conv):
     return _cached(conv, "_srf_gemm_direct", (w._version, w.data_ptr()), lambda: ops.pack_conv1x1_nhwc_direct_weights(w.detach()))
 
 
+def _gemm_split_weights(conv):
+    w = conv.weight
+    return _cached(conv, "_srf_gemm_split", (w._version, w.data_ptr()), lambda: ops.pack_conv1x1_nhwc_split_weights(w.detach()))
+
+
 def conv1x1(x, conv, bn=None, relu=False, out=None, pool=False, top=None):
     scale, shift = _affine_of(conv, bn)
-    # both operand orders are packed lazily: a layer only ever packs the one its launch size selects
+    # the operand orders are packed lazily: a layer only ever packs the one its launch selects
     return ops.conv1x1_nhwc(x, lambda: _gemm_weights(conv), conv.out_channels, scale, shift, relu, out=out, pool=pool, top=top,
-                            packed_direct=lambda: _gemm_direct_weights(conv))
+                            packed_direct=lambda: _gemm_direct_weights(conv), packed_split=lambda: _gemm_split_weights(conv))
 
 
 def wino_ok(conv, cin):

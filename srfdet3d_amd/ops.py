@@ -1042,7 +1042,9 @@ def wino43(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None)
     direct = 2.0 * 9 * Cin * Cout * N * H * W
     label = f"{Cin}->{Cout} @{N}x{H}x{W}"
     # transform: reads the input once, writes V (2.25x the input, padded to whole tile blocks)
-    KERNEL_TIMING["w43x"].append((timing[0], ev1, label, 0.0, 0.0, 4.0 * N * H * W * Cin + ws_bytes))
+    xrec = KERNEL_TIMING.get("w43x")
+    if xrec is not None:
+        xrec.append((timing[0], ev1, label, 0.0, 0.0, 4.0 * N * H * W * Cin + ws_bytes))
     # multiply: executes direct / 4 FLOPs on the MFMA; reads V and U once, writes the output
     timing[1].append((ev1, ev2, label, direct, direct / 4.0, float(ws_bytes) + 4.0 * 36 * Cin * Cout + 4.0 * N * H * W * Cout))
     return out
@@ -1074,6 +1076,28 @@ def pack_conv1x1_nhwc_direct_weights(weight):
     return packed
 
 
+def pack_conv1x1_nhwc_split_weights(weight):
+    """(Cout, K) or (Cout, K, 1, 1) -> the three bf16 planes of the weight (w = wh + wm + wl exactly) in the LDS operand order
+    srf_conv1x1_nhwc_split copies (once per layer); an int16 tensor (6 bytes per weight)."""
+    weight = _dev(weight.reshape(weight.shape[0], -1), "weight", torch.float32)
+    Cout, K = weight.shape
+    L = _lib.lib()
+    nbytes = L.srf_conv1x1_nhwc_split_packed_weight_bytes(Cout, K)
+    if nbytes == 0:
+        raise ValueError("conv1x1_nhwc: K must be a multiple of 32")
+    packed = _empty((nbytes // 2,), torch.int16, weight.device)
+    check(L.srf_conv1x1_nhwc_split_pack_weights(_ptr(weight), Cout, K, _ptr(packed), _stream()), "conv1x1_nhwc_split_pack_weights")
+    return packed
+
+
+def gemm_split_enabled():
+    """SRF_GEMM_SPLIT=0 keeps the 1x1 convolutions on the f32-MFMA kernels (`srf_conv1x1_nhwc` / `_direct`: one k-ordered fma chain per
+    output); the default runs them on `srf_conv1x1_nhwc_split` -- the same f32 GEMM through an exact three-way bf16 split of both
+    operands on the bf16 MFMA (csrc/gemm_split.hip: error against float64 equal to the f32 chain's, 1.4-1.5x its rate)."""
+    import os
+    return os.environ.get("SRF_GEMM_SPLIT", "1") != "0"
+
+
 GEMM_DIRECT_MIN_TILES = 1024   # 128 x 128 tiles of a launch from which the LDS-free kernel wins (tools/micro/gemm_direct_bench.hip)
 
 
@@ -1088,13 +1112,16 @@ def conv1x1_direct_wanted(M, Cout):
     return ((M + 127) // 128) * ((Cout + 127) // 128) >= GEMM_DIRECT_MIN_TILES
 
 
-def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None, pool=False, top=None, packed_direct=None):
+def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out=None, pool=False, top=None, packed_direct=None,
+                 packed_split=None):
     """1x1 convolution of the NHWC slice x (N, H, W, K) + per-channel scale / shift + ReLU into `out` ((N, H, W, Cout) slice
     of an NHWC buffer; new contiguous tensor when None).  pool=True: returns (out, mean (N, Cout) over the pixels of each
     image) from the same pass (`srf_conv1x1_nhwc_pooled`).  top: an (N, Ht, Wt, Cout) NHWC slice whose nearest-neighbour
     upsampling to (H, W) is added to the result in the epilogue (`srf_conv1x1_nhwc_topdown`: the FPN top-down step).
     packed_direct: the same weight packed by `pack_conv1x1_nhwc_direct_weights`, or a callable returning it; large launches then
-    run on the LDS-free kernel (`srf_conv1x1_nhwc_direct*`: the same bits in `out`)."""
+    run on the LDS-free kernel (`srf_conv1x1_nhwc_direct*`: the same bits in `out`).  packed_split: the weight packed by
+    `pack_conv1x1_nhwc_split_weights` (or a callable): unless SRF_GEMM_SPLIT=0 the layer runs on `srf_conv1x1_nhwc_split*` (f32 GEMM
+    on the bf16 MFMA through an exact three-way split; f32-accurate, not the bits of the fma chain)."""
     x_ld = nhwc_ld(x)
     N, H, W, K = x.shape
     if out is None:
@@ -1103,8 +1130,15 @@ def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out
         raise ValueError("conv1x1_nhwc: out has the wrong shape")
     y_ld = nhwc_ld(out)
     L = _lib.lib()
-    direct = packed_direct is not None and conv1x1_direct_wanted(N * H * W, Cout) and max(x_ld, y_ld) * 512 < (1 << 31)
-    if direct:
+    split = packed_split is not None and gemm_split_enabled() and max(x_ld, y_ld) * 512 < (1 << 31)
+    direct = not split and packed_direct is not None and conv1x1_direct_wanted(N * H * W, Cout) and max(x_ld, y_ld) * 512 < (1 << 31)
+    if split:
+        if callable(packed_split):
+            packed_split = packed_split()
+        if packed_split.numel() * 2 != L.srf_conv1x1_nhwc_split_packed_weight_bytes(Cout, K):
+            raise ValueError("conv1x1_nhwc: split-packed weight does not match (Cout, K)")
+        wp = _ptr(packed_split)
+    elif direct:
         if callable(packed_direct):
             packed_direct = packed_direct()
         if packed_direct.numel() * 4 != L.srf_conv1x1_nhwc_direct_packed_weight_bytes(Cout, K):
@@ -1116,32 +1150,33 @@ def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out
         if packed_weight.numel() * 4 != L.srf_conv1x1_nhwc_packed_weight_bytes(Cout, K):
             raise ValueError("conv1x1_nhwc: packed weight does not match (Cout, K)")
         wp = _ptr(packed_weight)
-    timing = _dense_timing("gemm")
+    timing = _dense_timing("gsplit" if split else "gemm")
     sc = None if scale is None else _ptr(_dev(scale, "scale", torch.float32))
     sh = None if shift is None else _ptr(_dev(shift, "shift", torch.float32))
     mean = None
     if top is not None:
         if pool or top.dim() != 4 or top.shape[0] != N or top.shape[3] != Cout:
             raise ValueError("conv1x1_nhwc: top must be (N, Ht, Wt, Cout) and excludes pool")
-        fn = L.srf_conv1x1_nhwc_direct_topdown if direct else L.srf_conv1x1_nhwc_topdown
+        fn = L.srf_conv1x1_nhwc_split_topdown if split else (L.srf_conv1x1_nhwc_direct_topdown if direct else L.srf_conv1x1_nhwc_topdown)
         check(fn(_ptr(x), N, H, W, K, x_ld, wp, Cout, sc, sh, int(bool(relu)), _ptr(top), top.shape[1], top.shape[2], nhwc_ld(top), _ptr(out),
                  y_ld, _stream()), "conv1x1_nhwc_topdown")
     elif pool:
         mean = _empty((N, Cout), torch.float32, x.device)
         nbytes = L.srf_conv1x1_nhwc_pooled_workspace_bytes(N, H * W, Cout)
         ws = _empty((max(nbytes, 4) // 4,), torch.float32, x.device)
-        fn = L.srf_conv1x1_nhwc_direct_pooled if direct else L.srf_conv1x1_nhwc_pooled
+        fn = L.srf_conv1x1_nhwc_split_pooled if split else (L.srf_conv1x1_nhwc_direct_pooled if direct else L.srf_conv1x1_nhwc_pooled)
         check(fn(_ptr(x), N, H * W, K, x_ld, wp, Cout, sc, sh, int(bool(relu)), _ptr(out), y_ld, _ptr(mean), _ptr(ws), nbytes, _stream()),
               "conv1x1_nhwc_pooled")
     else:
-        fn = L.srf_conv1x1_nhwc_direct if direct else L.srf_conv1x1_nhwc
+        fn = L.srf_conv1x1_nhwc_split if split else (L.srf_conv1x1_nhwc_direct if direct else L.srf_conv1x1_nhwc)
         check(fn(_ptr(x), N * H * W, K, x_ld, wp, Cout, sc, sh, int(bool(relu)), _ptr(out), y_ld, _stream()), "conv1x1_nhwc")
     if timing is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
         fl = 2.0 * K * Cout * N * H * W
-        timing[1].append((timing[0], ev1, f"{K}->{Cout} @{N}x{H}x{W}" + (" direct" if direct else ""), fl, fl,
-                          4.0 * N * H * W * (K + Cout) + 4.0 * K * Cout))
+        # split: six bf16 products per f32 product are issued on the bf16 MFMA; the weights are 6 bytes each
+        timing[1].append((timing[0], ev1, f"{K}->{Cout} @{N}x{H}x{W}" + (" split" if split else (" direct" if direct else "")), fl,
+                          6.0 * fl if split else fl, 4.0 * N * H * W * (K + Cout) + (6.0 if split else 4.0) * K * Cout))
     return (out, mean) if pool else out
 
 

@@ -1,0 +1,272 @@
+// gemm_split_bench.hip -- developer micro-benchmark: is an f32 GEMM through the bf16 MFMA worth building?
+//
+// Every f32 value is the EXACT sum of three bf16 values (8 + 8 + 8 significant bits, round-to-nearest at each step):
+// x = xh + xm + xl.  A product a b is then the sum of nine bf16 x bf16 products, each exact in f32; the six of magnitude
+// >= 2^-16 |a b| (hh, hm, mh, mm, hl, lh) are accumulated on v_mfma_f32_32x32x16_bf16 (f32 accumulate), the three dropped
+// ones sum to < 2^-23 |a b|, the size of one f32 rounding.  The bf16 MFMA does 16x the FLOPs per clock of the f32 MFMA, so
+// six products cost 6/16 of the f32 MFMA's cycles -- IF the operands can be fed.  This file measures exactly that for the
+// 1x1-convolution GEMMs of the camera branch (y[p][co] = sum_k x[p][k] W[co][k], vovnet.py:222-223): A split on the fly from
+// the f32 activations while it is staged to LDS, B pre-split once per layer; and the error against float64 next to the f32
+// MFMA chain's.  Build: hipcc --offload-arch=gfx950 -O3 -o gemm_split_bench.bin gemm_split_bench.hip
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b)
+{
+    f2 v = {a, b};
+    bf2 h = __builtin_convertvector(v, bf2);
+    return *reinterpret_cast<unsigned *>(&h);
+}
+
+// (x0, x1) -> packed (h, m, l) pairs
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l)
+{
+    h = pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = pk_bf16(s0, s1);
+}
+
+// B image per (chunk of 32 k, column tile of 128): [plane 3][col 128][slot 4][8 bf16], slot s of column n holds oct s ^ ((n >> 2) & 3)
+__global__ __launch_bounds__(256) void pack_b(const float *__restrict__ W, int Cout, int K, int nct, unsigned short *__restrict__ P, long long total)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int e = (int)(t & 7), s = (int)((t >> 3) & 3), n = (int)((t >> 5) & 127);
+    long long rest = t >> 12;
+    const int p = (int)(rest % 3);
+    rest /= 3;
+    const int ct = (int)(rest % nct), c = (int)(rest / nct);
+    const int oct = s ^ ((n >> 2) & 3);
+    const int k = c * 32 + oct * 8 + e, co = ct * 128 + n;
+    const float x = co < Cout ? W[(size_t)co * K + k] : 0.f;
+    unsigned h, m, l;
+    split2(x, 0.f, h, m, l);
+    P[t] = (unsigned short)((p == 0 ? h : p == 1 ? m : l) & 0xffffu);
+}
+
+template <int WPE>
+__global__ __launch_bounds__(256, WPE) void gemm_split(const float *__restrict__ x, long long M, int K, long long x_ld, const unsigned short *__restrict__ Bp,
+                                                       int Cout, float *__restrict__ y, long long y_ld, int nct)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 24576];   // A planes | B planes
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const int ct = jq % nct;
+    const long long mblocks = (M + 127) / 128;
+    const long long mb = (long long)(jq / nct) * 8 + xcd;
+    if (mb >= mblocks) return;
+    const long long p0 = mb * 128;
+    const long long rows_here = M - p0 < 128 ? M - p0 : 128;
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x) + p0 * x_ld, 0, (int)(rows_here * x_ld * 4), 0x00020000);
+    const int nchunk = K / 32;
+    const size_t chunk_stride = (size_t)nct * 24576;   // bytes
+    const unsigned char *bsrc = reinterpret_cast<const unsigned char *>(Bp) + (size_t)ct * 24576 + (size_t)tid * 16;
+
+    const int q = tid & 7, r0 = tid >> 3;
+    const unsigned aoff0 = (unsigned)((r0 * x_ld + q * 4) * 4), aoff_step = (unsigned)(32 * x_ld * 4);
+    f4 araw[4];
+    u4 braw[6];
+    unsigned sp[3][4][2];
+#define LOAD(C)                                                                                                            \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                 \
+            auto v_ = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(aoff0 + j_ * aoff_step), (C) * 128, 0);              \
+            araw[j_] = *reinterpret_cast<f4 *>(&v_);                                                                       \
+        }                                                                                                                  \
+        const u4 *bb_ = reinterpret_cast<const u4 *>(bsrc + (size_t)(C) * chunk_stride);                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) braw[i_] = bb_[i_ * 256];                                         \
+    } while (0)
+#define SPLIT()                                                                                                            \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                 \
+            split2(araw[j_][0], araw[j_][1], sp[0][j_][0], sp[1][j_][0], sp[2][j_][0]);                                    \
+            split2(araw[j_][2], araw[j_][3], sp[0][j_][1], sp[1][j_][1], sp[2][j_][1]);                                    \
+        }                                                                                                                  \
+    } while (0)
+    // A slot of (row, oct) = oct ^ ((row >> 2) & 3); this thread's 4 floats are half `q & 1` of oct `q >> 1`
+#define STORE()                                                                                                            \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                 \
+            const int row_ = r0 + 32 * j_;                                                                                 \
+            const int off_ = row_ * 64 + (((q >> 1) ^ ((row_ >> 2) & 3)) << 4) + (q & 1) * 8;                              \
+            _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) { const u2 w_ = {sp[p_][j_][0], sp[p_][j_][1]}; *reinterpret_cast<u2 *>(lds + p_ * 8192 + off_) = w_; } \
+        }                                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) *reinterpret_cast<u4 *>(lds + 24576 + (tid + i_ * 256) * 16) = braw[i_]; \
+    } while (0)
+
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    int a_off[2], b_off[2], swz_a[2], swz_b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wm * 64 + i * 32 + li, col = wn * 64 + i * 32 + li;
+        a_off[i] = row * 64;
+        b_off[i] = 24576 + col * 64;
+        swz_a[i] = (row >> 2) & 3;
+        swz_b[i] = (col >> 2) & 3;
+    }
+    f16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf8 fa[3][2], fb[3][2];
+#define READ(S)                                                                                                            \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_)                                                                   \
+            _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                             \
+                fa[p_][i_] = *reinterpret_cast<const bf8 *>(lds + p_ * 8192 + a_off[i_] + (((2 * (S) + lh) ^ swz_a[i_]) << 4)); \
+                fb[p_][i_] = *reinterpret_cast<const bf8 *>(lds + p_ * 8192 + b_off[i_] + (((2 * (S) + lh) ^ swz_b[i_]) << 4)); \
+            }                                                                                                              \
+    } while (0)
+#define MM(PA, PB)                                                                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                   \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][i_], fb[PB][j_], acc[i_][j_], 0, 0, 0)
+    // smallest terms first: l h, h l, m m, then m h, h m, then h h
+#define MFMA6() do { MM(2, 0); MM(0, 2); MM(1, 1); MM(1, 0); MM(0, 1); MM(0, 0); } while (0)
+
+    const int last = nchunk - 1;
+    LOAD(0);
+    SPLIT();
+    STORE();
+    LOAD(last < 1 ? last : 1);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int c2 = c + 2 < nchunk ? c + 2 : last;
+        READ(0);
+        MFMA6();
+        SPLIT();
+        READ(1);
+        MFMA6();
+        __syncthreads();
+        STORE();
+        LOAD(c2);
+        __syncthreads();
+    }
+    // epilogue: lane = channel li of block j; accumulator register r = row (r & 3) + 8 (r >> 2) + 4 lh of block i
+    const int co0 = ct * 128 + wn * 64 + li;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = p0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int co = co0 + j * 32;
+                if (row < M && co < Cout) y[row * y_ld + co] = acc[i][j][r];
+            }
+        }
+}
+
+// the f32 MFMA chain for comparison of the error only (one wave per 32 x 32 outputs, operands from global memory)
+__global__ __launch_bounds__(64) void gemm_f32_chain(const float *__restrict__ x, int K, long long x_ld, const float *__restrict__ W, float *__restrict__ y,
+                                                     long long y_ld)
+{
+    const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+    const long long r0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    f16v acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k = 0; k < K; k += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[(r0 + li) * x_ld + k + lh], W[(size_t)(c0 + li) * K + k + lh], acc, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) y[(r0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * y_ld + c0 + li] = acc[r];
+}
+
+int main(int argc, char **argv)
+{
+    struct Shape { long long M; int K, N; const char *what; };
+    const Shape shapes[] = {{556800, 768, 256, "stage 2 concat (6 x 232 x 400)"}, {139200, 1312, 512, "stage 3 concat"},
+                            {34800, 1728, 768, "stage 4 concat"}, {8700, 2144, 1024, "stage 5 concat"},
+                            {556800, 256, 256, "finest FPN lateral"}};
+    for (const Shape &s : shapes) {
+        const long long M = s.M;
+        const int K = s.K, N = s.N, nct = (N + 127) / 128;
+        std::vector<float> hx((size_t)M * K), hw((size_t)N * K);
+        unsigned seed = 12345u;
+        auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 65536.0f; };
+        for (auto &v : hx) { const float u = rnd(); v = u < 0.45f ? 0.f : (u - 0.45f) * 3.7f; }   // post-ReLU-like: 45 % zeros
+        for (auto &v : hw) v = (rnd() - 0.5f) * 0.08f;
+        float *dx, *dw, *dy, *dy32;
+        unsigned short *dp;
+        const size_t pbytes = (size_t)(K / 32) * nct * 24576;
+        CK(hipMalloc(&dx, hx.size() * 4));
+        CK(hipMalloc(&dw, hw.size() * 4));
+        CK(hipMalloc(&dy, (size_t)M * N * 4));
+        CK(hipMalloc(&dy32, (size_t)1024 * N * 4));
+        CK(hipMalloc(&dp, pbytes));
+        CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+        const long long ptotal = (long long)(pbytes / 2);
+        hipLaunchKernelGGL(pack_b, dim3((unsigned)((ptotal + 255) / 256)), dim3(256), 0, 0, dw, N, K, nct, dp, ptotal);
+        const long long mblocks = (M + 127) / 128;
+        const unsigned grid = (unsigned)(((mblocks + 7) / 8) * 8 * nct);
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        for (int wpe = 2; wpe <= 3; ++wpe) {
+            auto launch = [&]() {
+                if (wpe == 2) hipLaunchKernelGGL((gemm_split<2>), dim3(grid), dim3(256), 0, 0, dx, M, K, (long long)K, dp, N, dy, (long long)N, nct);
+                else hipLaunchKernelGGL((gemm_split<3>), dim3(grid), dim3(256), 0, 0, dx, M, K, (long long)K, dp, N, dy, (long long)N, nct);
+            };
+            for (int i = 0; i < 3; ++i) launch();
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            const int reps = 10;
+            for (int i = 0; i < reps; ++i) launch();
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            ms /= reps;
+            const double fl = 2.0 * M * K * N;
+            printf("%-32s M %7lld K %5d N %5d  %d wg/CU: %8.1f us  %7.1f TFLOP/s f32-equivalent (%.0f bf16 TFLOP/s issued)\n", s.what, M, K, N, wpe, ms * 1e3,
+                   fl / ms / 1e9, 6 * fl / ms / 1e9);
+        }
+        // error against float64 on the first 1024 rows, next to the f32 MFMA chain's
+        hipLaunchKernelGGL(gemm_f32_chain, dim3(32, N / 32), dim3(64), 0, 0, dx, K, (long long)K, dw, dy32, (long long)N);
+        std::vector<float> gy((size_t)1024 * N), gy32((size_t)1024 * N);
+        CK(hipMemcpy(gy.data(), dy, gy.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gy32.data(), dy32, gy32.size() * 4, hipMemcpyDeviceToHost));
+        double es = 0, e32 = 0, mx = 0, rs = 0, r32 = 0;
+        for (int r = 0; r < 1024; r += 7)
+            for (int c = 0; c < N; c += 3) {
+                double ref = 0, mag = 0;
+                for (int k = 0; k < K; ++k) {
+                    const double p = (double)hx[(size_t)r * K + k] * (double)hw[(size_t)c * K + k];
+                    ref += p;
+                    mag += fabs(p);
+                }
+                const double a = fabs(gy[(size_t)r * N + c] - ref), b = fabs(gy32[(size_t)r * N + c] - ref);
+                es = fmax(es, a);
+                e32 = fmax(e32, b);
+                rs = fmax(rs, a / mag);
+                r32 = fmax(r32, b / mag);
+                mx = fmax(mx, fabs(ref));
+            }
+        printf("    max |err| vs float64: split %.3e  f32 MFMA chain %.3e  (max |y| %.3f);  max err / sum|a b|: split %.2e  f32 chain %.2e\n", es, e32, mx, rs, r32);
+        CK(hipFree(dx));
+        CK(hipFree(dw));
+        CK(hipFree(dy));
+        CK(hipFree(dy32));
+        CK(hipFree(dp));
+    }
+    return 0;
+}
