@@ -428,6 +428,13 @@ int srf_conv1x1_nhwc_split_topdown(const float *x, int N, int H, int W, int K, l
 int srf_conv1x1_nhwc_split_pooled(const float *x, int N, long long HW, int K, long long x_ld, const void *W_packed, int Cout,
                                   const float *scale, const float *shift, int relu, float *y, long long y_ld, float *mean,
                                   void *workspace, size_t workspace_bytes, srf_stream_t stream);
+/* srf_conv_gemm_nhwc_split: srf_conv_gemm_nhwc (Conv2d with stride / padding as an implicit-im2col GEMM: VoVNet stem_3, SECONDCustom's
+ * stride-2 layers, the BEV FPN extras) on the split GEMM kernel.  W_packed = srf_conv1x1_nhwc_split_pack_weights of the weight reordered
+ * to (Cout, kh * kw * Cin), tap index slowest.  Cin % 32 == 0, the input below 2 GB, else SRF_EUNSUPPORTED. */
+int srf_conv_gemm_nhwc_split(const float *x, int N, int H, int W, int Cin, long long x_ld, const void *W_packed, int Cout, int kh, int kw,
+                             int stride, int pad, const float *scale, const float *shift, int relu, float *y, long long y_ld,
+                             srf_stream_t stream);
+
 
 
 /* srf_conv1x1_nhwc_topdown: an FPN lateral convolution with the top-down step in its epilogue (mmdet FPN.forward:

@@ -110,6 +110,8 @@ SIGNATURES = {
     "srf_conv1x1_nhwc_split": (c_int, [_P, c_longlong, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_longlong, _P]),
     "srf_conv1x1_nhwc_split_topdown": (c_int, [_P, c_int, c_int, c_int, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_longlong,
                                                _P, c_longlong, _P]),
+    "srf_conv_gemm_nhwc_split": (c_int, [_P, c_int, c_int, c_int, c_int, c_longlong, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P,
+                                         c_longlong, _P]),
     "srf_conv1x1_nhwc_split_pooled": (c_int, [_P, c_int, c_longlong, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_longlong, _P, _P,
                                               c_size_t, _P]),
     "srf_conv1x1_nhwc_topdown": (c_int, [_P, c_int, c_int, c_int, c_int, c_longlong, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_longlong,

@@ -58,10 +58,15 @@ struct GsArgs {
     long long top_ld;
     int mapH, mapW, topH, topW;
     float sy, sx;
+    // GS_CONV: rows are OUTPUT pixels (n, oy, ox) of a Conv2d(Cin, Cout, (kh, kw), stride, pad), k runs over (tap, input channel): implicit
+    // im2col as in srf_conv_gemm_nhwc (conv.hip); a chunk of 32 channels lies inside one tap (Cin % 32 == 0)
+    int H, W, Ho, Wo, kw, stride, pad, cin_chunks;
+    long long x_bytes;
 };
 #define GS_PLAIN 0
 #define GS_POOL 1
 #define GS_TOPDOWN 2
+#define GS_CONV 3
 
 __device__ __forceinline__ unsigned gs_pk_bf16(float a, float b)
 {
@@ -101,9 +106,9 @@ __global__ __launch_bounds__(256) void srf_gemm_split_pack_k(const float *__rest
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256, 3) void srf_gemm_split_k(GsArgs a)
+__global__ __launch_bounds__(256, MODE == GS_CONV ? 2 : 3) void srf_gemm_split_k(GsArgs a)
 {
-    constexpr bool POOL = MODE == GS_POOL, TOPDOWN = MODE == GS_TOPDOWN;
+    constexpr bool POOL = MODE == GS_POOL, TOPDOWN = MODE == GS_TOPDOWN, CONV = MODE == GS_CONV;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * GS_IMG];   // A planes | B planes
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // work item -> (column tile, row block): items b and b + 8 share an XCD, the column tiles of a row block sit on one L2
@@ -120,7 +125,8 @@ __global__ __launch_bounds__(256, 3) void srf_gemm_split_k(GsArgs a)
         slot = n * a.bpi + lb;
     }
     const long long rows_here = rows_blk < 128 ? rows_blk : 128;
-    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x) + p0 * a.x_ld, 0, (int)(rows_here * a.x_ld * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t xr = CONV ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000)
+                                     : __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x) + p0 * a.x_ld, 0, (int)(rows_here * a.x_ld * 4), 0x00020000);
     const int nchunk = a.nchunk;
     const size_t chunk_stride = (size_t)a.nct * GS_IMG;
     const unsigned char *bsrc = a.Wp + (size_t)ct * GS_IMG + (size_t)tid * 16;
@@ -130,11 +136,39 @@ __global__ __launch_bounds__(256, 3) void srf_gemm_split_k(GsArgs a)
     gs_f4 araw[4];
     gs_u4 braw[6];
     unsigned sp[3][4][2];
+    // CONV: the output pixel of each of this thread's rows, as the input coordinates of tap (0, 0)
+    int cy[CONV ? 4 : 1], cx[CONV ? 4 : 1], cn[CONV ? 4 : 1];
+    if (CONV) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long p = p0 + r0 + 32 * j;
+            const long long hw = (long long)a.Ho * a.Wo;
+            const int n = (int)(p / hw);
+            const int rem = (int)(p - n * hw);
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            cn[j] = p < a.M ? n : -1;
+            cy[j] = oy * a.stride - a.pad;
+            cx[j] = ox * a.stride - a.pad;
+        }
+    }
 #define GS_LOAD(C)                                                                                                         \
     do {                                                                                                                   \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                 \
-            auto v_ = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(aoff0 + j_ * aoff_step), (C) * 128, 0);              \
-            araw[j_] = *reinterpret_cast<gs_f4 *>(&v_);                                                                    \
+        if (CONV) {                                                                                                        \
+            const int tap_ = (C) / a.cin_chunks, cc_ = (C) - tap_ * a.cin_chunks;                                          \
+            const int ky_ = tap_ / a.kw, kx_ = tap_ - ky_ * a.kw;                                                          \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                             \
+                const int iy_ = cy[j_] + ky_, ix_ = cx[j_] + kx_;                                                          \
+                const bool ok_ = cn[j_] >= 0 && iy_ >= 0 && iy_ < a.H && ix_ >= 0 && ix_ < a.W;                            \
+                const unsigned off_ = ok_ ? (unsigned)(((((long long)cn[j_] * a.H + iy_) * a.W + ix_) * a.x_ld + cc_ * 32 + q * 4) * 4) \
+                                          : 0x80000000u;                                                                   \
+                auto v_ = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off_, 0, 0);                                      \
+                araw[j_] = *reinterpret_cast<gs_f4 *>(&v_);                                                                \
+            }                                                                                                              \
+        } else {                                                                                                           \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                             \
+                auto v_ = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(aoff0 + j_ * aoff_step), (C) * 128, 0);          \
+                araw[j_] = *reinterpret_cast<gs_f4 *>(&v_);                                                                \
+            }                                                                                                              \
         }                                                                                                                  \
         const gs_u4 *bb_ = reinterpret_cast<const gs_u4 *>(bsrc + (size_t)(C) * chunk_stride);                             \
         _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) braw[i_] = bb_[i_ * 256];                                         \
@@ -338,6 +372,8 @@ static int gs_launch(const float *x, long long M, int K, long long x_ld, const v
     a.topW = td ? td->topW : 0;
     a.sy = td ? (float)td->topH / (float)td->mapH : 0.f;
     a.sx = td ? (float)td->topW / (float)td->mapW : 0.f;
+    a.H = a.W = a.Ho = a.Wo = a.kw = a.stride = a.pad = a.cin_chunks = 0;
+    a.x_bytes = 0;
     if (colsum) {
         a.bpi = (int)srf_ceil_div(HW, 128);
         a.mblocks = (M / HW) * a.bpi;
@@ -354,6 +390,61 @@ static int gs_launch(const float *x, long long M, int K, long long x_ld, const v
         hipLaunchKernelGGL((srf_gemm_split_k<GS_TOPDOWN>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL((srf_gemm_split_k<GS_PLAIN>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// srf_conv_gemm_nhwc_split: Conv2d(Cin, Cout, (kh, kw), stride, padding) on channels-last activations as the split GEMM with an
+// implicit im2col (the stride-2 3x3 layers: VoVNet stem_3, SECONDCustom's second block, the BEV FPN extras -- the layers
+// srf_conv_gemm_nhwc runs on the f32 MFMA).  W_packed = srf_conv1x1_nhwc_split_pack_weights of the weight reordered to
+// (Cout, kh * kw * Cin), tap index slowest.
+extern "C" int srf_conv_gemm_nhwc_split(const float *x, int N, int H, int W, int Cin, long long x_ld, const void *W_packed, int Cout, int kh,
+                                        int kw, int stride, int pad, const float *scale, const float *shift, int relu, float *y,
+                                        long long y_ld, srf_stream_t stream)
+{
+    if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0 || x_ld < Cin || y_ld < Cout)
+        return SRF_EINVAL;
+    if (N == 0) return SRF_OK;
+    if (!x || !W_packed || !y) return SRF_EINVAL;
+    if ((Cin & 31) || (x_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)W_packed & 15)) return SRF_EUNSUPPORTED;
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return SRF_EINVAL;
+    const long long x_bytes = (long long)N * H * W * x_ld * 4;
+    if (x_bytes >= (1ll << 31) || y_ld * 128 * 4 >= (1ll << 31)) return SRF_EUNSUPPORTED;
+    GsArgs a;
+    a.x = x;
+    a.y = y;
+    a.Wp = (const unsigned char *)W_packed;
+    a.scale = scale;
+    a.shift = shift;
+    a.x_ld = x_ld;
+    a.y_ld = y_ld;
+    a.M = (long long)N * Ho * Wo;
+    a.K = kh * kw * Cin;
+    a.Cout = Cout;
+    a.nchunk = a.K / 32;
+    a.nct = srf_ceil_div(Cout, 128);
+    a.relu = relu;
+    a.colsum = nullptr;
+    a.HW = 0;
+    a.bpi = 0;
+    a.top = nullptr;
+    a.top_ld = 0;
+    a.mapH = a.mapW = a.topH = a.topW = 0;
+    a.sy = a.sx = 0.f;
+    a.H = H;
+    a.W = W;
+    a.Ho = Ho;
+    a.Wo = Wo;
+    a.kw = kw;
+    a.stride = stride;
+    a.pad = pad;
+    a.cin_chunks = Cin / 32;
+    a.x_bytes = x_bytes;
+    a.mblocks = srf_ceil_div(a.M, 128);
+    const long long blocks = ((a.mblocks + 7) / 8) * 8 * a.nct;
+    if (blocks >= (1ll << 31)) return SRF_EUNSUPPORTED;
+    hipLaunchKernelGGL((srf_gemm_split_k<GS_CONV>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

@@ -55,7 +55,7 @@ def _cached(mod, key, vers, make):
     return cache[1]
 
 
-_CACHE_KEYS = ("_srf_wino", "_srf_wino43", "_srf_gemm", "_srf_gemm_direct", "_srf_gemm_split", "_srf_cgemm", "_srf_packed")
+_CACHE_KEYS = ("_srf_wino", "_srf_wino43", "_srf_gemm", "_srf_gemm_direct", "_srf_gemm_split", "_srf_cgemm", "_srf_cgemm_split", "_srf_packed")
 
 
 def invalidate_caches(model):
@@ -294,6 +294,11 @@ def _strided_weights(conv):
     return _cached(conv, "_srf_cgemm", (w._version, w.data_ptr()), lambda: ops.pack_conv_gemm_weights(w))
 
 
+def _strided_split_weights(conv):
+    w = conv.weight
+    return _cached(conv, "_srf_cgemm_split", (w._version, w.data_ptr()), lambda: ops.pack_conv_gemm_split_weights(w))
+
+
 def strided_ok(conv, cin):
     return (isinstance(conv, nn.Conv2d) and conv.groups == 1 and conv.dilation == (1, 1) and conv.stride[0] == conv.stride[1]
             and conv.padding[0] == conv.padding[1] and cin % 32 == 0)
@@ -303,8 +308,8 @@ def conv_strided(x, conv, bn=None, relu=False, out=None):
     """A convolution the Winograd kernel does not cover (stride 2) as an implicit-im2col GEMM on the f32 MFMA
     (`srf_conv_gemm_nhwc`): deterministic, where MIOpen's channels-last choice is an atomic split-K kernel."""
     scale, shift = _affine_of(conv, bn)
-    return ops.conv_gemm_nhwc(x, _strided_weights(conv), conv.out_channels, conv.kernel_size, conv.stride[0], conv.padding[0],
-                              scale, shift, relu, out=out)
+    return ops.conv_gemm_nhwc(x, lambda: _strided_weights(conv), conv.out_channels, conv.kernel_size, conv.stride[0], conv.padding[0],
+                              scale, shift, relu, out=out, packed_split=lambda: _strided_split_weights(conv))
 
 
 def to_nhwc(x):

@@ -1259,8 +1259,16 @@ def pack_conv_gemm_weights(weight):
     return pack_conv1x1_nhwc_weights(weight.detach().permute(0, 2, 3, 1).reshape(Cout, -1).contiguous())
 
 
-def conv_gemm_nhwc(x, packed_weight, Cout, ksize, stride, pad, scale=None, shift=None, relu=False, out=None):
-    """Conv2d on an NHWC slice as an implicit-im2col GEMM on the f32 MFMA (the strided 3x3 layers); -> (N, Ho, Wo, Cout)."""
+def pack_conv_gemm_split_weights(weight):
+    """(Cout, Cin, kh, kw) -> packed operand of srf_conv_gemm_nhwc_split (bf16 planes): k = (tap, input channel), tap slowest."""
+    Cout = weight.shape[0]
+    return pack_conv1x1_nhwc_split_weights(weight.detach().permute(0, 2, 3, 1).reshape(Cout, -1).contiguous())
+
+
+def conv_gemm_nhwc(x, packed_weight, Cout, ksize, stride, pad, scale=None, shift=None, relu=False, out=None, packed_split=None):
+    """Conv2d on an NHWC slice as an implicit-im2col GEMM (the strided 3x3 layers); -> (N, Ho, Wo, Cout).  On the f32 MFMA
+    (`srf_conv_gemm_nhwc`, packed_weight) or, when packed_split (from `pack_conv_gemm_split_weights`, or a callable) is given and
+    SRF_GEMM_SPLIT is not 0, on the split GEMM (`srf_conv_gemm_nhwc_split`: f32-accurate on the bf16 MFMA)."""
     x_ld = nhwc_ld(x)
     N, H, W, Cin = x.shape
     kh, kw = ksize
@@ -1270,8 +1278,19 @@ def conv_gemm_nhwc(x, packed_weight, Cout, ksize, stride, pad, scale=None, shift
     elif tuple(out.shape) != (N, Ho, Wo, Cout):
         raise ValueError("conv_gemm_nhwc: out has the wrong shape")
     L = _lib.lib()
-    if packed_weight.numel() * 4 != L.srf_conv1x1_nhwc_packed_weight_bytes(Cout, kh * kw * Cin):
-        raise ValueError("conv_gemm_nhwc: packed weight does not match the layer")
+    split = packed_split is not None and gemm_split_enabled()
+    if split:
+        if callable(packed_split):
+            packed_split = packed_split()
+        if packed_split.numel() * 2 != L.srf_conv1x1_nhwc_split_packed_weight_bytes(Cout, kh * kw * Cin):
+            raise ValueError("conv_gemm_nhwc: split-packed weight does not match the layer")
+        packed_weight, fn = packed_split, L.srf_conv_gemm_nhwc_split
+    else:
+        if callable(packed_weight):
+            packed_weight = packed_weight()
+        if packed_weight.numel() * 4 != L.srf_conv1x1_nhwc_packed_weight_bytes(Cout, kh * kw * Cin):
+            raise ValueError("conv_gemm_nhwc: packed weight does not match the layer")
+        fn = L.srf_conv_gemm_nhwc
     # the kernel addresses its whole input through ONE 32-bit buffer descriptor (N H W x_ld 4 < 2^31 bytes): larger batches
     # run in groups of images (VoVNet stem_3 reads 464 x 800 x 64 per camera: 23 images reach the limit -- LC inference at
     # batch 4, the frozen prefix of config 4 at bs >= 4)
@@ -1280,8 +1299,8 @@ def conv_gemm_nhwc(x, packed_weight, Cout, ksize, stride, pad, scale=None, shift
     sc, sh = _opt(scale, "scale"), _opt(shift, "shift")
     for n0 in range(0, max(N, 1), max(group, 1)):
         xs, os_ = x[n0:n0 + group], out[n0:n0 + group]
-        check(L.srf_conv_gemm_nhwc(_ptr(xs), xs.shape[0], H, W, Cin, x_ld, _ptr(packed_weight), Cout, kh, kw, stride, pad, sc, sh,
-                                   int(bool(relu)), _ptr(os_), nhwc_ld(out), _stream()), "conv_gemm_nhwc")
+        check(fn(_ptr(xs), xs.shape[0], H, W, Cin, x_ld, _ptr(packed_weight), Cout, kh, kw, stride, pad, sc, sh,
+                 int(bool(relu)), _ptr(os_), nhwc_ld(out), _stream()), "conv_gemm_nhwc")
     return out
 
 

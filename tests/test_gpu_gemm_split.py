@@ -130,3 +130,24 @@ def test_camera_executor_routes_1x1_layers_to_the_split_kernel_by_default(dev, m
         want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), conv.weight.double().cpu(), conv.bias.double().cpu()).permute(0, 2, 3, 1)
     assert (a.double().cpu() - want).abs().max().item() <= 3e-6 * want.abs().max().item()
     assert (b.double().cpu() - want).abs().max().item() <= 3e-6 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad", [(2, 37, 41, 64, 128, 3, 2, 1), (1, 46, 46, 128, 128, 3, 2, 1), (2, 20, 24, 32, 40, 3, 1, 1),
+                                                       (1, 33, 29, 64, 96, 1, 2, 0)])
+def test_conv_gemm_split_matches_float64(dev, N, H, W, Cin, Cout, k, stride, pad):
+    """srf_conv_gemm_nhwc_split (implicit im2col on the split GEMM: VoVNet stem_3, the stride-2 layers of SECOND / BEV FPN) against
+    torch's conv2d in float64, and against the f32-MFMA form on the same data."""
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    x = torch.relu(torch.randn(N, H, W, Cin, generator=g))
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (k * Cin ** 0.5)
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    xd, wd = x.to(dev), w.to(dev)
+    got = ops.conv_gemm_nhwc(xd, None, Cout, (k, k), stride, pad, scale.to(dev), shift.to(dev), True,
+                             packed_split=ops.pack_conv_gemm_split_weights(wd)).cpu().double()
+    f32 = ops.conv_gemm_nhwc(xd, ops.pack_conv_gemm_weights(wd), Cout, (k, k), stride, pad, scale.to(dev), shift.to(dev), True).cpu().double()
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), stride=stride, padding=pad)
+    ref = torch.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    assert got.shape == ref.shape
+    tol = 2e-6 * max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() <= tol
+    assert (got - ref).abs().max().item() <= 2.0 * (f32 - ref).abs().max().item() + 0.25 * tol

@@ -31,6 +31,34 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b)
     return *reinterpret_cast<unsigned *>(&h);
 }
 
+__device__ __forceinline__ float sub1(float a, float b)   // one v_sub_f32: keeps the compiler from SLP-packing into v_pk_add_f32
+{
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int VAR>
+__device__ __forceinline__ void split2v(float x0, float x1, unsigned &h, unsigned &m, unsigned &l)
+{
+    if (VAR == 0) {
+        h = pk_bf16(x0, x1);
+        const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+        m = pk_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+        l = pk_bf16(s0, s1);
+    } else if (VAR == 4) {   // ablation: no split arithmetic (wrong results)
+        h = __float_as_uint(x0);
+        m = __float_as_uint(x1);
+        l = h ^ m;
+    } else {
+        h = pk_bf16(x0, x1);
+        const float r0 = sub1(x0, __uint_as_float(h << 16)), r1 = sub1(x1, __uint_as_float(h & 0xffff0000u));
+        m = pk_bf16(r0, r1);
+        const float s0 = sub1(r0, __uint_as_float(m << 16)), s1 = sub1(r1, __uint_as_float(m & 0xffff0000u));
+        l = pk_bf16(s0, s1);
+    }
+}
+
 // (x0, x1) -> packed (h, m, l) pairs
 __device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l)
 {
@@ -59,7 +87,7 @@ __global__ __launch_bounds__(256) void pack_b(const float *__restrict__ W, int C
     P[t] = (unsigned short)((p == 0 ? h : p == 1 ? m : l) & 0xffffu);
 }
 
-template <int WPE>
+template <int WPE, int VAR>
 __global__ __launch_bounds__(256, WPE) void gemm_split(const float *__restrict__ x, long long M, int K, long long x_ld, const unsigned short *__restrict__ Bp,
                                                        int Cout, float *__restrict__ y, long long y_ld, int nct)
 {
@@ -94,8 +122,8 @@ __global__ __launch_bounds__(256, WPE) void gemm_split(const float *__restrict__
 #define SPLIT()                                                                                                            \
     do {                                                                                                                   \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                 \
-            split2(araw[j_][0], araw[j_][1], sp[0][j_][0], sp[1][j_][0], sp[2][j_][0]);                                    \
-            split2(araw[j_][2], araw[j_][3], sp[0][j_][1], sp[1][j_][1], sp[2][j_][1]);                                    \
+            split2v<VAR>(araw[j_][0], araw[j_][1], sp[0][j_][0], sp[1][j_][0], sp[2][j_][0]);                              \
+            split2v<VAR>(araw[j_][2], araw[j_][3], sp[0][j_][1], sp[1][j_][1], sp[2][j_][1]);                              \
         }                                                                                                                  \
     } while (0)
     // A slot of (row, oct) = oct ^ ((row >> 2) & 3); this thread's 4 floats are half `q & 1` of oct `q >> 1`
@@ -151,17 +179,173 @@ __global__ __launch_bounds__(256, WPE) void gemm_split(const float *__restrict__
     __syncthreads();
     for (int c = 0; c < nchunk; ++c) {
         const int c2 = c + 2 < nchunk ? c + 2 : last;
-        READ(0);
+        if (VAR != 5 || c == 0) READ(0);
         MFMA6();
         SPLIT();
-        READ(1);
+        if (VAR != 5) READ(1);
+        if (VAR == 2 || VAR == 3) {   // phase 1: the 12 fragment reads, then every MFMA followed by four of the split's vector instructions
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+            for (int i_ = 0; i_ < 24; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         MFMA6();
+        if (VAR == 6) continue;
         __syncthreads();
         STORE();
         LOAD(c2);
+        if (VAR == 3) {   // phase 2: MFMAs spread over the stores and the loads
+#pragma unroll
+            for (int i_ = 0; i_ < 18; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 1);
+            }
+#pragma unroll
+            for (int i_ = 0; i_ < 6; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x20, 2, 1);
+            }
+        }
         __syncthreads();
     }
     // epilogue: lane = channel li of block j; accumulator register r = row (r & 3) + 8 (r >> 2) + 4 lh of block i
+    const int co0 = ct * 128 + wn * 64 + li;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = p0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int co = co0 + j * 32;
+                if (row < M && co < Cout) y[row * y_ld + co] = acc[i][j][r];
+            }
+        }
+}
+
+// ---- v2: B never touches LDS (fragment-ordered image, L2 -> registers, reloaded in place one step ahead, as srf_gemm_direct_k);
+// A split once per workgroup into a DOUBLE-buffered LDS image: one barrier per chunk, the stores of chunk c + 1 anywhere in chunk c
+// B image per (chunk, column tile): [wn 2][step 2][j 2][plane 3][lane 64][8 bf16]
+__global__ __launch_bounds__(256) void pack_b2(const float *__restrict__ W, int Cout, int K, int nct, unsigned short *__restrict__ P, long long total)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int e = (int)(t & 7), lane = (int)((t >> 3) & 63);
+    long long rest = t >> 9;
+    const int p = (int)(rest % 3);
+    rest /= 3;
+    const int j = (int)(rest & 1), st = (int)((rest >> 1) & 1), wn = (int)((rest >> 2) & 1);
+    rest >>= 3;
+    const int ct = (int)(rest % nct), c = (int)(rest / nct);
+    const int co = ct * 128 + wn * 64 + j * 32 + (lane & 31), k = c * 32 + st * 16 + (lane >> 5) * 8 + e;
+    const float x = co < Cout ? W[(size_t)co * K + k] : 0.f;
+    unsigned h, m, l;
+    split2(x, 0.f, h, m, l);
+    P[t] = (unsigned short)((p == 0 ? h : p == 1 ? m : l) & 0xffffu);
+}
+
+template <int VAR>
+__global__ __launch_bounds__(256, 3) void gemm_split2(const float *__restrict__ x, long long M, int K, long long x_ld, const unsigned short *__restrict__ Bp,
+                                                      int Cout, float *__restrict__ y, long long y_ld, int nct)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 24576];   // A planes, two stages
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const int ct = jq % nct;
+    const long long mblocks = (M + 127) / 128;
+    const long long mb = (long long)(jq / nct) * 8 + xcd;
+    if (mb >= mblocks) return;
+    const long long p0 = mb * 128;
+    const long long rows_here = M - p0 < 128 ? M - p0 : 128;
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x) + p0 * x_ld, 0, (int)(rows_here * x_ld * 4), 0x00020000);
+    const int nchunk = K / 32;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const size_t chunk_stride = (size_t)nct * 24576;   // bytes
+    __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned char *>(reinterpret_cast<const unsigned char *>(Bp)) + (size_t)ct * 24576 + (size_t)wn * 12288, 0,
+        (int)((size_t)nchunk * chunk_stride - (size_t)ct * 24576 - (size_t)wn * 12288), 0x00020000);
+    const int boff = lane * 16;
+
+    const int q = tid & 7, r0 = tid >> 3;
+    const unsigned aoff0 = (unsigned)((r0 * x_ld + q * 4) * 4), aoff_step = (unsigned)(32 * x_ld * 4);
+    f4 araw[4];
+    unsigned sp[3][4][2];
+    bf8 fb[2][2][3];   // [step][j][plane]
+#define LOADA(C)                                                                                                           \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                     \
+        auto v_ = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(aoff0 + j_ * aoff_step), (C) * 128, 0);                  \
+        araw[j_] = *reinterpret_cast<f4 *>(&v_);                                                                           \
+    }
+#define LOADB(S, C)                                                                                                        \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                       \
+        _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) {                                                                 \
+            auto v_ = __builtin_amdgcn_raw_buffer_load_b128(br, boff, (int)((C) * chunk_stride) + (((S) * 2 + j_) * 3 + p_) * 1024, 0); \
+            fb[S][j_][p_] = *reinterpret_cast<bf8 *>(&v_);                                                                 \
+        }
+#define SPLIT2()                                                                                                           \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                     \
+        split2v<VAR>(araw[j_][0], araw[j_][1], sp[0][j_][0], sp[1][j_][0], sp[2][j_][0]);                                  \
+        split2v<VAR>(araw[j_][2], araw[j_][3], sp[0][j_][1], sp[1][j_][1], sp[2][j_][1]);                                  \
+    }
+#define STOREA(BUF)                                                                                                        \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                     \
+        const int row_ = r0 + 32 * j_;                                                                                     \
+        const int off_ = (BUF) * 24576 + row_ * 64 + (((q >> 1) ^ ((row_ >> 2) & 3)) << 4) + (q & 1) * 8;                  \
+        _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) { const u2 w_ = {sp[p_][j_][0], sp[p_][j_][1]}; *reinterpret_cast<u2 *>(lds + p_ * 8192 + off_) = w_; } \
+    }
+    int a_off[2], swz_a[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wm * 64 + i * 32 + li;
+        a_off[i] = row * 64;
+        swz_a[i] = (row >> 2) & 3;
+    }
+    f16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf8 fa[3][2];
+#define READA(BUF, S)                                                                                                      \
+    _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_)                                                                       \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                                   \
+            fa[p_][i_] = *reinterpret_cast<const bf8 *>(lds + (BUF) * 24576 + p_ * 8192 + a_off[i_] + (((2 * (S) + lh) ^ swz_a[i_]) << 4));
+#define MM2(S, PA, PB)                                                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                   \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA][i_], fb[S][j_][PB], acc[i_][j_], 0, 0, 0)
+#define MFMA6B(S) do { MM2(S, 2, 0); MM2(S, 0, 2); MM2(S, 1, 1); MM2(S, 1, 0); MM2(S, 0, 1); MM2(S, 0, 0); } while (0)
+
+    const int last = nchunk - 1;
+    LOADA(0);
+    LOADB(0, 0);
+    LOADB(1, 0);
+    SPLIT2();
+    STOREA(0);
+    LOADA(last < 1 ? last : 1);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int cur = c & 1;
+        const int c1 = c + 1 < nchunk ? c + 1 : last, c2 = c + 2 < nchunk ? c + 2 : last;
+        READA(cur, 0);
+        MFMA6B(0);
+        LOADB(0, c1);
+        __builtin_amdgcn_sched_barrier(0);
+        SPLIT2();
+        READA(cur, 1);
+        MFMA6B(1);
+        LOADB(1, c1);
+        STOREA(cur ^ 1);
+        LOADA(c2);
+        __syncthreads();
+    }
     const int co0 = ct * 128 + wn * 64 + li;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -205,41 +389,67 @@ int main(int argc, char **argv)
         for (auto &v : hx) { const float u = rnd(); v = u < 0.45f ? 0.f : (u - 0.45f) * 3.7f; }   // post-ReLU-like: 45 % zeros
         for (auto &v : hw) v = (rnd() - 0.5f) * 0.08f;
         float *dx, *dw, *dy, *dy32;
-        unsigned short *dp;
+        unsigned short *dp, *dp2;
         const size_t pbytes = (size_t)(K / 32) * nct * 24576;
         CK(hipMalloc(&dx, hx.size() * 4));
         CK(hipMalloc(&dw, hw.size() * 4));
         CK(hipMalloc(&dy, (size_t)M * N * 4));
         CK(hipMalloc(&dy32, (size_t)1024 * N * 4));
         CK(hipMalloc(&dp, pbytes));
+        CK(hipMalloc(&dp2, pbytes));
         CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
         const long long ptotal = (long long)(pbytes / 2);
         hipLaunchKernelGGL(pack_b, dim3((unsigned)((ptotal + 255) / 256)), dim3(256), 0, 0, dw, N, K, nct, dp, ptotal);
+        hipLaunchKernelGGL(pack_b2, dim3((unsigned)((ptotal + 255) / 256)), dim3(256), 0, 0, dw, N, K, nct, dp2, ptotal);
         const long long mblocks = (M + 127) / 128;
         const unsigned grid = (unsigned)(((mblocks + 7) / 8) * 8 * nct);
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
-        for (int wpe = 2; wpe <= 3; ++wpe) {
-            auto launch = [&]() {
-                if (wpe == 2) hipLaunchKernelGGL((gemm_split<2>), dim3(grid), dim3(256), 0, 0, dx, M, K, (long long)K, dp, N, dy, (long long)N, nct);
-                else hipLaunchKernelGGL((gemm_split<3>), dim3(grid), dim3(256), 0, 0, dx, M, K, (long long)K, dp, N, dy, (long long)N, nct);
-            };
-            for (int i = 0; i < 3; ++i) launch();
-            CK(hipDeviceSynchronize());
-            CK(hipEventRecord(e0));
-            const int reps = 10;
-            for (int i = 0; i < reps; ++i) launch();
-            CK(hipEventRecord(e1));
-            CK(hipEventSynchronize(e1));
-            float ms;
-            CK(hipEventElapsedTime(&ms, e0, e1));
-            ms /= reps;
-            const double fl = 2.0 * M * K * N;
-            printf("%-32s M %7lld K %5d N %5d  %d wg/CU: %8.1f us  %7.1f TFLOP/s f32-equivalent (%.0f bf16 TFLOP/s issued)\n", s.what, M, K, N, wpe, ms * 1e3,
-                   fl / ms / 1e9, 6 * fl / ms / 1e9);
+        const int NV = 9;
+        double best[NV], med[NV][5];
+        for (int v = 0; v < NV; ++v) best[v] = 1e30;
+        auto launch = [&](int var) {
+#define LV(V) hipLaunchKernelGGL((gemm_split<3, V>), dim3(grid), dim3(256), 0, 0, dx, M, K, (long long)K, dp, N, dy, (long long)N, nct)
+            switch (var) {
+            case 0: LV(0); break;
+            case 1: LV(1); break;
+            case 2: LV(2); break;
+            case 3: LV(3); break;
+            case 4: LV(4); break;
+            case 5: LV(5); break;
+            case 6: LV(6); break;
+            case 7: hipLaunchKernelGGL((gemm_split2<0>), dim3(grid), dim3(256), 0, 0, dx, M, K, (long long)K, dp2, N, dy, (long long)N, nct); break;
+            default: hipLaunchKernelGGL((gemm_split2<1>), dim3(grid), dim3(256), 0, 0, dx, M, K, (long long)K, dp2, N, dy, (long long)N, nct); break;
+            }
+        };
+        for (int i = 0; i < 6; ++i) launch(1);   // clocks settle
+        for (int round = 0; round < 5; ++round)
+            for (int var = 0; var < NV; ++var) {
+                launch(var);
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0));
+                const int reps = 4;
+                for (int i = 0; i < reps; ++i) launch(var);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                ms /= reps;
+                med[var][round] = ms;
+                if (ms < best[var]) best[var] = ms;
+            }
+        const double fl = 2.0 * M * K * N;
+        const char *names[NV] = {"baseline", "v_sub asm", "sched groups ph1", "sched groups ph1+2", "ABL no split", "ABL no frag reads", "ABL no stage", "v2 B direct, A 2-stage", "v2 + v_sub asm"};
+        for (int var = 0; var < NV; ++var) {
+            double m5[5];
+            for (int i = 0; i < 5; ++i) m5[i] = med[var][i];
+            for (int i = 0; i < 5; ++i) for (int j = i + 1; j < 5; ++j) if (m5[j] < m5[i]) { double t = m5[i]; m5[i] = m5[j]; m5[j] = t; }
+            printf("%-28s K %5d N %5d  %-20s min %8.1f med %8.1f us  %7.1f TFLOP/s f32-eq (%.0f bf16 issued)\n", s.what, K, N, names[var], best[var] * 1e3,
+                   m5[2] * 1e3, fl / m5[2] / 1e9, 6 * fl / m5[2] / 1e9);
         }
+        launch(7);   // the error check below reads v2's output
         // error against float64 on the first 1024 rows, next to the f32 MFMA chain's
         hipLaunchKernelGGL(gemm_f32_chain, dim3(32, N / 32), dim3(64), 0, 0, dx, K, (long long)K, dw, dy32, (long long)N);
         std::vector<float> gy((size_t)1024 * N), gy32((size_t)1024 * N);
@@ -267,6 +477,7 @@ int main(int argc, char **argv)
         CK(hipFree(dy));
         CK(hipFree(dy32));
         CK(hipFree(dp));
+        CK(hipFree(dp2));
     }
     return 0;
 }
