@@ -601,17 +601,25 @@ class SRFDetHead(BaseModule):
         return self.loss_ota(out, gt_bboxes, gt_labels)
 
     def loss_ota(self, outputs, gt_bboxes_list, gt_labels_list):
+        """srfdet_head.py:1041-1201.  The reference calls `reduce_mean` twice per decoder layer (the matched-pair count of the
+        classification and of the box loss: 10 blocking all-reduces + `.item()` per iteration, :1134, :1178).  Both counts of a layer are
+        the same number and every one of them is known once the assignments are made, so here the layers are assigned first and
+        ALL counts travel in ONE all-reduce with ONE read-back (collective C4)."""
+        from .training import reduce_mean
         dev = gt_labels_list[0].device
         gts = [torch.cat((g.gravity_center, g.tensor[:, 3:]), dim=1).to(dev) for g in gt_bboxes_list]
         losses = {}
         layers = [(outputs, self.num_heads, "")] + [(aux, i + 1, f"s.{i}.") for i, aux in enumerate(outputs.get("aux_outputs", []))]
-        for out, head_idx, prefix in layers:
-            idx = self.assigner(out, gts, gt_labels_list, head_idx)
-            losses[prefix + "loss_cls"] = self.loss_classification(out, gt_labels_list, idx)
-            losses[prefix + "loss_bbox"] = self.loss_boxes(out, gts, idx)
+        assigned = [self.assigner(out, gts, gt_labels_list, head_idx) for out, head_idx, _ in layers]
+        local = [float(sum(int(j.numel()) for _, j in idx)) for idx in assigned]          # host-known: no synchronisation
+        reduced = reduce_mean(torch.tensor(local, dtype=torch.float32, device=dev)).tolist()   # one collective, one read-back
+        for (out, _, prefix), idx, n_local, n_mean in zip(layers, assigned, local, reduced):
+            n_cls = n_mean if self.sync_cls_avg_factor else n_local
+            losses[prefix + "loss_cls"] = self.loss_classification(out, gt_labels_list, idx, num=max(n_cls, 1.0))
+            losses[prefix + "loss_bbox"] = self.loss_boxes(out, gts, idx, num=max(n_mean, 1.0))
         return losses
 
-    def loss_classification(self, outputs, gt_labels_list, indices):
+    def loss_classification(self, outputs, gt_labels_list, indices, num=None):
         from .training import reduce_mean
         logits = outputs["pred_logits"]
         target = torch.full(logits.shape[:2], self.num_classes, dtype=torch.int64, device=logits.device)
@@ -619,13 +627,15 @@ class SRFDetHead(BaseModule):
         for b, (labels, (fg, j)) in enumerate(zip(gt_labels_list, indices)):
             target[b, fg] = labels[j]
             n += int(j.numel())
-        num = logits.new_tensor([float(n)])
-        if self.sync_cls_avg_factor:
-            num = reduce_mean(num)
-        loss = self.loss_cls(logits.flatten(0, 1), target.flatten(0, 1)) / num.clamp(min=1).item()
+        if num is None:   # stand-alone call: the reference's own sequence (one all-reduce for this layer)
+            t = logits.new_tensor([float(n)])
+            if self.sync_cls_avg_factor:
+                t = reduce_mean(t)
+            num = t.clamp(min=1).item()
+        loss = self.loss_cls(logits.flatten(0, 1), target.flatten(0, 1)) / num
         return torch.nan_to_num(loss)
 
-    def loss_boxes(self, outputs, gt_bboxes_list, indices):
+    def loss_boxes(self, outputs, gt_bboxes_list, indices, num=None):
         from .bbox_util import normalize_bbox
         from .training import reduce_mean
         pred = outputs["pred_boxes"]
@@ -633,7 +643,8 @@ class SRFDetHead(BaseModule):
         t = torch.cat([g[j] for g, (_, j) in zip(gt_bboxes_list, indices)])
         if len(p) == 0:
             return torch.nan_to_num(pred.sum() * 0)
-        num = torch.clamp(reduce_mean(p.new_tensor([float(p.shape[0])])), min=1).item()
+        if num is None:
+            num = torch.clamp(reduce_mean(p.new_tensor([float(p.shape[0])])), min=1).item()
         tn = normalize_bbox(t, self.pc_range)
         ok = torch.isfinite(tn).all(dim=-1)
         D = self.code_weights.numel()

@@ -109,3 +109,81 @@ def test_frame_sharding_and_end_of_run_gather_two_ranks():
     assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5, 0]
     assert res[1][2] is None
     assert res[0][2] == [(i, float(i)) for i in range(n)]
+
+
+def _loss_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from srfdet3d_amd.plugin import heads, training
+
+    class _Gt:
+        def __init__(self, t):
+            self.tensor, self.gravity_center = t, t[:, :3]
+
+    g = torch.Generator().manual_seed(100 + rank)
+    n_p, n_cls, layers = 16, 10, 3
+    n_match = [[3 + rank, 2], [1 + 2 * rank, 4], [5, 1 + rank]]          # pairs per (layer, sample): different on the two ranks
+    outs = [dict(pred_logits=torch.randn(2, n_p, n_cls, generator=g), pred_boxes=torch.randn(2, n_p, 10, generator=g)) for _ in range(layers)]
+    gts = [torch.cat([torch.rand(8, 3, generator=g) * 40 - 20, torch.rand(8, 3, generator=g) + 0.5, torch.randn(8, 3, generator=g)], 1)
+           for _ in range(2)]
+    labels = [torch.randint(0, n_cls, (8,), generator=g) for _ in range(2)]
+    calls = {"assign": 0}
+
+    def assigner(out, gts_, labels_, head_idx):
+        li = calls["assign"] % layers
+        calls["assign"] += 1
+        return [(torch.arange(n_match[li][b]), torch.arange(n_match[li][b])) for b in range(2)]
+
+    hd = object.__new__(heads.SRFDetHead)
+    torch.nn.Module.__init__(hd)
+    hd.assigner, hd.num_heads, hd.deep_supervision, hd.num_classes, hd.sync_cls_avg_factor = assigner, layers, True, n_cls, True
+    hd.pc_range = [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0]
+    hd.code_weights = torch.nn.Parameter(torch.tensor([1.0] * 8 + [0.2, 0.2]), requires_grad=False)
+    hd.loss_cls = training.FocalLoss(use_sigmoid=True, gamma=2.0, alpha=0.25, reduction="sum", loss_weight=2.0)
+    hd.loss_bbox = training.L1Loss(reduction="sum", loss_weight=0.25)
+    n_allreduce = {"n": 0}
+    real = dist.all_reduce
+
+    def counting(*a, **k):
+        n_allreduce["n"] += 1
+        return real(*a, **k)
+
+    dist.all_reduce = counting
+    outputs = dict(outs[0], aux_outputs=outs[1:])
+    batched = hd.loss_ota(outputs, [_Gt(t) for t in gts], labels)
+    n_batched = n_allreduce["n"]
+    # the reference's own sequence: one reduce_mean per loss and layer
+    n_allreduce["n"] = 0
+    seq = {}
+    order = [(outs[0], ""), (outs[1], "s.0."), (outs[2], "s.1.")]
+    for li, (o, prefix) in enumerate(order):
+        idx = [(torch.arange(n_match[li][b]), torch.arange(n_match[li][b])) for b in range(2)]
+        gl = [torch.cat((t[:, :3], t[:, 3:]), 1) for t in gts]
+        seq[prefix + "loss_cls"] = hd.loss_classification(o, labels, idx)
+        seq[prefix + "loss_bbox"] = hd.loss_boxes(o, gl, idx)
+    dist.all_reduce = real
+    q.put((rank, n_batched, n_allreduce["n"], {k: float(v) for k, v in batched.items()}, {k: float(v) for k, v in seq.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_loss_counts_travel_in_one_all_reduce_two_ranks():
+    """SURVEY 8e / collective C4: the matched-pair counts of all decoder layers in ONE all-reduce (the reference: two
+    `reduce_mean` + `.item()` per layer, srfdet_head.py:1134, :1178) -- same losses as the per-layer sequence, on ranks whose
+    counts differ."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loss_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, n_batched, n_seq, batched, seq in res:
+        assert n_batched == 1 and n_seq == 6
+        assert set(batched) == set(seq)
+        for k in seq:
+            assert abs(batched[k] - seq[k]) <= 1e-6 * max(1.0, abs(seq[k])), (k, batched[k], seq[k])

@@ -55,6 +55,23 @@ def main():
     training.freeze_lidar_components(model)
     model = model.to(dev).train()
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=True) if world > 1 else model
+    # gradient all-reduce time (collective C1): a DDP communication hook that brackets every bucket's all-reduce with
+    # events on the stream it runs on; the buckets overlap with the rest of backward, so this is time ON the communication stream, not
+    # time added to the step
+    comm_events = []
+    if world > 1:
+        def timed_allreduce(state, bucket):
+            t = bucket.buffer()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fut = dist.all_reduce(t.div_(world), async_op=True).get_future()
+
+            def done(f):
+                e1.record()
+                comm_events.append((e0, e1, t.numel() * 4))
+                return f.value()[0]
+            return fut.then(done)
+        net.register_comm_hook(None, timed_allreduce)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.01)
     rng = np.random.default_rng(rank)
@@ -65,14 +82,26 @@ def main():
     gts = [random_gt(dev, 20, rng) for _ in range(a.bs)]
     metas = [dict(box_type_3d=LiDARInstance3DBoxes, lidar2img=[m for m in rig]) for _ in range(a.bs)]
 
-    def step():
+    phases = []   # (forward, backward, optimiser) event triples of the timed iterations
+
+    def step(record=False):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if record else None
+        if record:
+            ev[0].record()
         losses = net(return_loss=True, img=img, points=pts, img_metas=metas, gt_bboxes_3d=[g[0] for g in gts],
                      gt_labels_3d=[g[1] for g in gts])
         total = sum(losses.values())
         opt.zero_grad(set_to_none=True)
-        total.backward()
+        if record:
+            ev[1].record()
+        total.backward()           # under DDP the bucketed gradient all-reduce runs inside (overlapped with) this call
+        if record:
+            ev[2].record()
         torch.nn.utils.clip_grad_norm_(params, 35.0)
         opt.step()
+        if record:
+            ev[3].record()
+            phases.append(ev)
         return total.item()
 
     for _ in range(a.warmup):
@@ -83,18 +112,35 @@ def main():
         train_conv._DEBUG.clear()   # the warm-up iterations contain MIOpen's solver search
     if world > 1:
         dist.barrier()
+    comm_events.clear()
     t0 = time.perf_counter()
     for _ in range(a.iters):
-        loss = step()
+        loss = step(record=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     if rank == 0:
         ntrain = sum(p.numel() for p in params)
+        fwd = sum(e[0].elapsed_time(e[1]) for e in phases) / len(phases)
+        bwd = sum(e[1].elapsed_time(e[2]) for e in phases) / len(phases)
+        optm = sum(e[2].elapsed_time(e[3]) for e in phases) / len(phases)
+        step_ms = dt / a.iters * 1e3
+        comm_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in comm_events) / a.iters if comm_events else 0.0
+        comm_bytes = sum(n for _, _, n in comm_events) / a.iters if comm_events else 0
         print(json.dumps(dict(metric="training iterations/s, srfdet_voxel_nusc_LC", value=round(a.iters / dt, 3), n_gpus=world,
                               frames_per_s=round(a.iters * a.bs * world / dt, 3), bs_per_gpu=a.bs, num_proposals=a.np,
-                              image=f"{h}x{w}", trainable_params=ntrain, grad_bytes_per_step=4 * ntrain, last_loss=round(loss, 4))))
+                              image=f"{h}x{w}", trainable_params=ntrain, grad_bytes_per_step=4 * ntrain, last_loss=round(loss, 4),
+                              ms_per_step=round(step_ms, 2),
+                              phases_ms=dict(forward_and_loss=round(fwd, 2), backward_incl_overlapped_allreduce=round(bwd, 2),
+                                             clip_and_optimizer=round(optm, 2)),
+                              backward_share_of_step=round(bwd / step_ms, 4),
+                              grad_allreduce=dict(ms_on_comm_stream_per_step=round(comm_ms, 3), bytes_per_step=int(comm_bytes),
+                                                  buckets_per_step=round(len(comm_events) / a.iters, 1),
+                                                  share_of_step=round(comm_ms / step_ms, 4),
+                                                  note="RCCL all-reduce of the DDP buckets, HIP events on the stream they run on; they overlap "
+                                                       "with backward (world == 1: no collective)"),
+                              loss_scalar_allreduces_per_step=1 if world > 1 else 0)))
     if rank == 0 and a.kernel_table:
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
