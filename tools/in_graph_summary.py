@@ -18,7 +18,20 @@ FAMILIES = {   # bench.py name -> kernel-name substrings
     "wino3x3": ("srf_wino3x3_k<", "srf_wino3x3_mixed_k<"),
     "conv1x1": ("srf_conv1x1_nhwc_k<1, 1, 4, false>", "srf_conv1x1_nhwc_k<2, 2, 3, false>", "srf_conv1x1_nhwc_k<4, 4, 1, false>",
                 "srf_conv1x1_nhwc_mixed_k", "srf_gemm_direct_k<"),
+    "gemmsplit": ("srf_gemm_split_k<",),
 }
+
+
+def source_id():
+    """sha of the kernel sources (bench.py quotes this file only for the build it was measured on, as for the traffic files)"""
+    import glob
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "srfdet3d_amd", "csrc", "*.h*"))):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -38,6 +51,7 @@ def main():
     res[workload] = {k: round(v[1] / 1e6 / frames, 3) for k, v in tot.items() if frames and v[0]}
     res[workload]["_frames_in_trace"] = frames
     res[workload]["_source"] = os.path.basename(path)
+    res["kernel_source_sha16"] = source_id()
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res[workload]))
 

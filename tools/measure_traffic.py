@@ -4,9 +4,9 @@
 `--pmc` passes (each with --kernel-trace only), read bytes = 2 x FETCH_SIZE x 1024 on gfx950 (128-B requests are tallied
 as 64 B), WRITE_SIZE x 1024 exact.  Run on the GPU box from the repo root:
 
-    python tools/measure_traffic.py            # writes gpurun_out/traffic/r03_pmc_<name>_traffic.json
+    python tools/measure_traffic.py            # writes gpurun_out/traffic/r04_pmc_<name>_traffic.json
 
-and copy the files into profiles/ (bench.py reads profiles/r03_pmc_<name>_traffic.json -> roofline.traffic).
+and copy the files into profiles/ (bench.py reads profiles/r04_pmc_<name>_traffic.json -> roofline.traffic).
 This process never touches the GPU itself: every pass is `rocprofv3 ... -- python3 <tool>` started as a child.
 """
 import csv
@@ -23,7 +23,7 @@ SQ = ("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY S
       "SQ_LDS_BANK_CONFLICT").split()
 
 # name -> (program after `--`, kernel-name substring, description, algorithmic bytes note)
-ROUND = "r03"
+ROUND = "r04"
 TARGETS = {
     "wino43mm": (["tools/prof_img_branch.py", "3"], ("srf_wino43_mm_k<",),
                  "every srf_wino43_mm_k launch of 3 eager passes of the LC camera branch (88 per frame: VoVNet-99 from stage 2 on, image FPN, img_convs)"),
@@ -35,6 +35,18 @@ TARGETS = {
                                                      "srf_conv1x1_nhwc_k<4, 4, 1, false>", "srf_conv1x1_nhwc_mixed_k", "srf_gemm_direct_k<"),
                 "EVERY srf_conv1x1_nhwc launch of the same passes, whatever its tile form (20 per frame: OSA concat convolutions + FPN "
                 "laterals) -- the launch set bench.py's roofline.gemm aggregates"),
+    "gemmsplit": (["tools/prof_img_branch.py", "3"], ("srf_gemm_split_k<",),
+                  "every srf_gemm_split_k launch of the same passes (21 per frame: the OSA concat convolutions, the FPN laterals and stem_3 as "
+                  "f32 GEMMs on the bf16 MFMA) -- the launch set bench.py's roofline.gemm aggregates"),
+    # the scatter / gather stages north_star asks HBM GB/s for: 3 eager LiDAR frames (30k points, np = 200), traffic PER FRAME
+    "voxelize": (["tools/prof_lidar_frame.py", "3"], ("srf_hv_insert_k", "srf_hv_gather_k", "srf_scan_reduce_k<HvFlag", "srf_scan_apply_k<HvFlag"),
+                 "hard voxelization + per-voxel mean (K1 + a3): insert, first-seen numbering scan, gather; per frame", 3),
+    "rulebook": (["tools/prof_lidar_frame.py", "3"], ("srf_bm_", "srf_scan_reduce_k<BmPop", "srf_scan_apply_k<BmPop"),
+                 "bitmap-rank rulebooks of the whole encoder (K4): mark / rank scans / place / subm / strided mark, emit, pairs; per frame", 3),
+    "densify": (["tools/prof_lidar_frame.py", "3"], ("srf_densify_k",),
+                "densify (K6) without its zero fill (srf_fill_words_k is shared with other clears); per frame", 3),
+    "roi": (["tools/prof_lidar_frame.py", "3"], ("srf_roi_extract_k",),
+            "multi-level RoIAlign gather (K7), 5 stages x 200 RoIs on the channels-last BEV pyramid; per frame", 3),
     "spconv128": (["tools/bench_spconv.py", "--levels", "4", "--reps", "8"], "srf_spconv_gs_k<4, 128>",
                   "SubM 128->128 on the 5x184x184 level of frame 2000 (A=34992), BN + residual + ReLU epilogue"),
     "spconv64": (["tools/bench_spconv.py", "--levels", "3", "--reps", "8"], "srf_spconv_gs_k<2, 64>",
@@ -88,7 +100,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     cache = {}
     for name in want:
-        prog, sub, desc = TARGETS[name]
+        prog, sub, desc = TARGETS[name][:3]
+        per_frames = TARGETS[name][3] if len(TARGETS[name]) > 3 else 0
         key = " ".join(prog)
         if key not in cache:
             tag = prog[0].split("/")[-1].replace(".py", "") + "_" + "_".join(p.strip("-") for p in prog[1:])
@@ -123,10 +136,22 @@ def main():
         if s.get("SQ_VALU_MFMA_BUSY_CYCLES") and s.get("SQ_BUSY_CYCLES"):
             # SQ_BUSY_CYCLES is summed over the 32 shader engines, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
             out["derived"] = {"mfma_busy_fraction_per_simd": round(s["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (s["SQ_BUSY_CYCLES"] / 32), 4)}
+        if per_frames:
+            # a family of different kernels: totals per frame instead of averages per launch (no cold pass dropped: nothing is packed here)
+            dur_all = durations_of(ds, sub)
+            rd, wr = 2 * sum(fetch) * 1024 / per_frames, sum(write) * 1024 / per_frames
+            ms = sum(dur_all) / 1e6 / per_frames
+            out.update(launches_averaged=len(fetch), frames=per_frames, launches_per_frame=len(fetch) / per_frames,
+                       read_bytes_per_frame=int(rd), write_bytes_per_frame=int(wr), traffic_bytes_per_frame=int(rd + wr),
+                       kernel_ms_per_frame_under_pmc=round(ms, 4), hbm_gbs_of_counted_traffic=round((rd + wr) / (ms * 1e-3) / 1e9, 1) if ms else None,
+                       frac_of_8000_gbs_peak=round((rd + wr) / (ms * 1e-3) / 1e9 / 8000.0, 4) if ms else None)
+            for k in ("FETCH_SIZE_KB", "WRITE_SIZE_KB", "read_bytes_per_launch", "write_bytes_per_launch", "traffic_bytes_per_launch", "avg_duration_us_under_pmc"):
+                out.pop(k, None)
         path = os.path.join(OUT, f"{ROUND}_pmc_{name}_traffic.json")
         with open(path, "w") as fh:
             json.dump(out, fh, indent=1)
-        print(name, json.dumps({k: out[k] for k in ("launches_averaged", "traffic_bytes_per_launch", "avg_duration_us_under_pmc")}), flush=True)
+        print(name, json.dumps({k: out[k] for k in ("launches_averaged", "traffic_bytes_per_launch", "avg_duration_us_under_pmc",
+                                                     "traffic_bytes_per_frame", "kernel_ms_per_frame_under_pmc", "hbm_gbs_of_counted_traffic") if k in out}), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects the measurements of a round on the GPU box into gpurun_out/<round>/ (copy what is to be judged into profiles/).
-# usage (from the repo root, through gpurun):  bash tools/round_profiles.sh r03
+# usage (from the repo root, through gpurun):  bash tools/round_profiles.sh r04
 set -o pipefail
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out/$R
 mkdir -p $O
 export TMPDIR=/tmp
