@@ -100,7 +100,9 @@ class ConvModule(nn.Module):
         else:
             x = self.conv(x)
         if self.with_norm:
-            x = getattr(self, self.norm_name)(x)
+            from .. import train_conv
+            norm = getattr(self, self.norm_name)
+            x = norm(train_conv.bn_train_input(norm, x))   # a train-mode BatchNorm never sees a channels-last tensor (MIOpen crash)
         if self.with_activation:
             x = self.activate(x)
         return x

@@ -163,4 +163,18 @@ def bn_eval(bn, y):
         s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
         t = bn.bias - bn.running_mean * s
         return y * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)
-    return bn(y)
+    return bn(bn_train_input(bn, y))
+
+
+def bn_train_input(bn, y):
+    """What a BatchNorm in TRAINING mode may be handed.  MIOpen's training batch-norm dies with a host segmentation fault on a
+    channels-last tensor of batch size 1 -- (1, 128, 23, 23) with strides (67712, 1, 2944, 128); the same tensor at batch size 2, the
+    same shape NCHW-contiguous and eval mode are all fine (tools/bn_channels_last_probe.py, every case in its own process;
+    profiles/r04_bn_channels_last_probe.txt).  That was the round-3 crash: a bs = 1 LiDAR-only training step whose BEV FPN extras
+    (stride-2 Conv2d -> BatchNorm2d in train mode) received channels-last tensors from `_Wino43Conv`.  Guarded here, at the one
+    place every module-path BatchNorm goes through: a non-contiguous 4-D GPU tensor is made NCHW-contiguous before a train-mode
+    BatchNorm sees it (any batch size: the trigger is a library bug, not something to steer around case by case).  Eval-mode
+    BatchNorms (the camera branch's `norm_eval=True`) never get here with a copy."""
+    if (isinstance(bn, nn.modules.batchnorm._BatchNorm) and bn.training and y.is_cuda and y.dim() == 4 and not y.is_contiguous()):
+        return y.contiguous()
+    return y

@@ -244,3 +244,49 @@ def test_training_depthwise_and_1x1_routes_match_autograd(dev):
         for got, want in pairs:
             err = (got.detach().double().cpu() - want.detach()).abs().max().item()
             assert err <= 1e-4 * max(want.detach().abs().max().item(), 1e-3), (err,)
+
+
+def test_train_mode_batchnorm_never_sees_a_channels_last_tensor(dev):
+    """ADVICE r3 / the round-3 crash: MIOpen's TRAINING batch-norm segfaults (host side) on a channels-last tensor of batch size 1
+    (tools/bn_channels_last_probe.py: (1, 128, 23, 23) crashes, batch size 2 / NCHW / eval mode do not).  The guard sits where every
+    module-path BatchNorm passes (`train_conv.bn_train_input`, used by ConvModule, run_sequential and conv_bn_act): the exact
+    failing chain -- channels-last input, 3x3 ConvModule with BN in train mode, two stride-2 ConvModules with BN in train mode, batch
+    size 1 -- runs forward and backward and matches the same modules on an NCHW-contiguous input."""
+    from srfdet3d_amd import train_conv
+    from srfdet3d_amd.compat.cnn import ConvModule
+    torch.manual_seed(0)
+    norm = dict(type="BN2d", eps=1e-3, momentum=0.01)
+    mods = torch.nn.Sequential(ConvModule(128, 128, 3, padding=1, norm_cfg=norm), ConvModule(128, 128, 3, stride=2, padding=1, norm_cfg=norm),
+                               ConvModule(128, 128, 3, stride=2, padding=1, norm_cfg=norm, act_cfg=None)).to(dev).train()
+    x = torch.randn(1, 128, 92, 92, device=dev)
+    xc = x.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xn = x.clone().requires_grad_(True)
+    seen = []
+    orig = torch.nn.functional.batch_norm
+
+    def spy(t, *a, **k):
+        seen.append((tuple(t.shape), t.is_contiguous(), bool(a[4] if len(a) > 4 else k.get("training", False))))
+        return orig(t, *a, **k)
+
+    torch.nn.functional.batch_norm = spy
+    try:
+        yc = mods(xc)
+        yc.square().mean().backward()
+    finally:
+        torch.nn.functional.batch_norm = orig
+    assert len(seen) == 3 and all(contig and training for _, contig, training in seen), seen
+    assert seen[-1][0] == (1, 128, 23, 23)
+    state = {k: v.clone() for k, v in mods.state_dict().items()}
+    gc = xc.grad.clone()
+    for m in mods.modules():          # same running statistics for the second pass
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.reset_running_stats()
+    yn = mods(xn)
+    yn.square().mean().backward()
+    torch.testing.assert_close(yc, yn, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gc, xn.grad, rtol=1e-3, atol=1e-5)
+    # the helper itself: only a train-mode BatchNorm triggers the copy
+    bn = torch.nn.BatchNorm2d(128).to(dev)
+    t = torch.randn(1, 128, 23, 23, device=dev).contiguous(memory_format=torch.channels_last)
+    assert train_conv.bn_train_input(bn.train(), t).is_contiguous()
+    assert train_conv.bn_train_input(bn.eval(), t) is t

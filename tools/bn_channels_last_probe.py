@@ -16,6 +16,11 @@ CASES = {
     "bn_train_on_cl_46": "x = cl(torch.randn(2, 128, 46, 46, device='cuda')).requires_grad_(True); z = bn2(x); z.sum().backward()",
     "bn_train_on_cl_bs1_23": "x = cl(torch.randn(1, 128, 23, 23, device='cuda')).requires_grad_(True); z = bn2(x); z.sum().backward()",
     "bn_train_on_cl_bs1_1x1": "x = cl(torch.randn(1, 128, 1, 1, device='cuda')).requires_grad_(True); z = bn2(x); z.sum().backward()",
+    "bn_train_on_cl_bs1_46": "x = cl(torch.randn(1, 128, 46, 46, device='cuda')).requires_grad_(True); z = bn2(x); z.sum().backward()",
+    "bn_train_on_cl_bs1_24": "x = cl(torch.randn(1, 128, 24, 24, device='cuda')).requires_grad_(True); z = bn2(x); z.sum().backward()",
+    "bn_train_on_cl_bs1_c64": "bn2 = torch.nn.BatchNorm2d(64).cuda().train(); x = cl(torch.randn(1, 64, 23, 23, device='cuda')).requires_grad_(True); z = bn2(x); z.sum().backward()",
+    "bn_train_on_nchw_bs1_23": "x = torch.randn(1, 128, 23, 23, device='cuda').requires_grad_(True); z = bn2(x); z.sum().backward()",
+    "bn_train_on_cl_bs1_23_no_grad": "x = cl(torch.randn(1, 128, 23, 23, device='cuda')); z = bn2(x)",
     "bn_eval_on_cl_23": "bn2.eval(); x = cl(torch.randn(2, 128, 23, 23, device='cuda')); z = bn2(x)",
     # the same chain with the conv output made NCHW-contiguous before the norm (the guard under consideration)
     "chain_cl_contig_before_bn": "x = cl(torch.randn(2, 128, 92, 92, device='cuda')).requires_grad_(True); y = bn1(c1(x).contiguous()); z = bn2(c2(y).contiguous()); z.sum().backward()",
