@@ -117,3 +117,41 @@ def test_hungarian_assigner_one_to_one():
     assert (empty.gt_inds == 0).all() and empty.num_gts == 0
     default = BBOX_ASSIGNERS.build(dict(type="HungarianAssignerSRFDet"))     # mmdet's default cost names resolve too
     assert (default.assign(pred, logits, gt, gt_labels).gt_inds > 0).sum() == 4
+
+
+def test_results_from_static_host_unpacking():
+    """Host side of the fixed-shape NMS selection (heads.results_from_static, numpy on the read-back rows): survivors, the
+    max_per_img cut in descending score, the post_center_range filter, and None on a capacity overflow -- against the plain torch
+    formulation of srfdet_head.py:1288-1310."""
+    import numpy as np
+    import torch
+    from srfdet3d_amd.compat.boxes import LiDARInstance3DBoxes
+    from srfdet3d_amd.plugin import heads
+    hd = object.__new__(heads.SRFDetHead)
+    torch.nn.Module.__init__(hd)
+    hd.test_cfg = dict(max_per_img=5, post_center_range=[-10.0, -10.0, -5.0, 10.0, 10.0, 5.0])
+    g = torch.Generator().manual_seed(0)
+    L, D = 16, 9
+    packed = torch.zeros(2, L, D + 2)
+    packed[..., :3] = torch.rand(2, L, 3, generator=g) * 30 - 15
+    packed[..., 3:D] = torch.rand(2, L, D - 3, generator=g)
+    packed[..., D] = torch.rand(2, L, generator=g)
+    packed[..., D + 1] = torch.randint(0, 10, (2, L), generator=g).float()
+    counts = torch.tensor([[9, 12], [3, 3]], dtype=torch.int32)
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes)] * 2
+    res = hd.results_from_static(packed, counts, metas)
+    for i in range(2):
+        rows = packed[i, :int(counts[i, 0])]
+        boxes, scores, labels = rows[:, :D], rows[:, D], rows[:, D + 1].long()
+        if len(rows) > 5:
+            top = scores.sort(descending=True)[1][:5]
+            boxes, scores, labels = boxes[top], scores[top], labels[top]
+        rng = torch.tensor(hd.test_cfg["post_center_range"])
+        keep = (boxes[:, :3] >= rng[:3]).all(1) & (boxes[:, :3] <= rng[3:]).all(1)
+        assert torch.equal(res[i][0].tensor, boxes[keep]) and torch.equal(res[i][1], scores[keep]) and torch.equal(res[i][2], labels[keep])
+        assert res[i][2].dtype == torch.int64
+    # the rows are copies: the read-back buffer may be overwritten by the next frame
+    before = res[0][1].clone()
+    packed.zero_()
+    assert torch.equal(res[0][1], before)
+    assert hd.results_from_static(packed, torch.tensor([[3, L + 1], [0, 0]], dtype=torch.int32), metas) is None
