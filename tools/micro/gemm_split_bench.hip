@@ -195,9 +195,9 @@ __global__ __launch_bounds__(256, WPE) void gemm_split(const float *__restrict__
         }
         MFMA6();
         if (VAR == 6) continue;
-        __syncthreads();
-        STORE();
-        LOAD(c2);
+        if (VAR != 12 && VAR != 13) __syncthreads();
+        if (VAR != 11) STORE();
+        if (VAR != 10) LOAD(c2);
         if (VAR == 3) {   // phase 2: MFMAs spread over the stores and the loads
 #pragma unroll
             for (int i_ = 0; i_ < 18; ++i_) {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, WPE) void gemm_split(const float *__restrict__
                 __builtin_amdgcn_sched_group_barrier(0x20, 2, 1);
             }
         }
-        __syncthreads();
+        if (VAR != 12) __syncthreads();
     }
     // epilogue: lane = channel li of block j; accumulator register r = row (r & 3) + 8 (r >> 2) + 4 lh of block i
     const int co0 = ct * 128 + wn * 64 + li;
@@ -407,7 +407,7 @@ int main(int argc, char **argv)
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
-        const int NV = 9;
+        const int NV = 13;
         double best[NV], med[NV][5];
         for (int v = 0; v < NV; ++v) best[v] = 1e30;
         auto launch = [&](int var) {
@@ -420,8 +420,12 @@ int main(int argc, char **argv)
             case 4: LV(4); break;
             case 5: LV(5); break;
             case 6: LV(6); break;
+            case 9: LV(10); break;
+            case 10: LV(11); break;
+            case 11: LV(12); break;
+            case 12: LV(13); break;
             case 7: hipLaunchKernelGGL((gemm_split2<0>), dim3(grid), dim3(256), 0, 0, dx, M, K, (long long)K, dp2, N, dy, (long long)N, nct); break;
-            default: hipLaunchKernelGGL((gemm_split2<1>), dim3(grid), dim3(256), 0, 0, dx, M, K, (long long)K, dp2, N, dy, (long long)N, nct); break;
+            case 8: hipLaunchKernelGGL((gemm_split2<1>), dim3(grid), dim3(256), 0, 0, dx, M, K, (long long)K, dp2, N, dy, (long long)N, nct); break;
             }
         };
         for (int i = 0; i < 6; ++i) launch(1);   // clocks settle
@@ -441,7 +445,7 @@ int main(int argc, char **argv)
                 if (ms < best[var]) best[var] = ms;
             }
         const double fl = 2.0 * M * K * N;
-        const char *names[NV] = {"baseline", "v_sub asm", "sched groups ph1", "sched groups ph1+2", "ABL no split", "ABL no frag reads", "ABL no stage", "v2 B direct, A 2-stage", "v2 + v_sub asm"};
+        const char *names[NV] = {"baseline", "v_sub asm", "sched groups ph1", "sched groups ph1+2", "ABL no split", "ABL no frag reads", "ABL no stage", "v2 B direct, A 2-stage", "v2 + v_sub asm", "ABL no global loads", "ABL no LDS stores", "ABL no barriers", "ABL one barrier"};
         for (int var = 0; var < NV; ++var) {
             double m5[5];
             for (int i = 0; i < 5; ++i) m5[i] = med[var][i];
