@@ -251,6 +251,15 @@ int srf_roi_extract(const srf_featmap *levels /*host[num_levels]*/, int num_leve
                     int R, int pooled, int sampling_ratio, float finest_scale, float *out, int64_t out_stride_r,
                     int64_t out_stride_c, int64_t out_stride_bin, int accumulate, int *levels_out /* R or NULL */,
                     srf_stream_t stream);
+/* srf_roi_extract_sum: output row r (R rows) = the sum over s = 0 .. n_sum - 1, added in that order, of the gathers of the RoIs
+ * rois[s * R + r] (n_sum * R RoIs, group-major): the per-camera image RoIs of a proposal summed over the cameras
+ * (srfdet_head.py:2543-2562: pooler over all n_cam * R RoIs, then .sum over the camera axis) in one launch, without the
+ * (n_cam * R, S, C) intermediate.  Same sampling arithmetic as srf_roi_extract; out is addressed through the three strides, so it may
+ * be a channel slice of the fused (R, S, 2 C) operand of `output_fused_proj` (:2255-2329). */
+int srf_roi_extract_sum(const srf_featmap *levels /*host[num_levels]*/, int num_levels, int C, const float *rois /* (n_sum R) x 5 */,
+                        int R, int n_sum, int pooled, int sampling_ratio, float finest_scale, float *out, int64_t out_stride_r,
+                        int64_t out_stride_c, int64_t out_stride_bin, srf_stream_t stream);
+
 
 /* Backward of srf_roi_extract with respect to the feature maps (training of the image branch; RoIs carry no
  * gradient, as in mmcv's roi_align_backward).  grad_levels[i] has the layout of levels[i] and must be zeroed by

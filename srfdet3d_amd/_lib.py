@@ -64,6 +64,7 @@ SIGNATURES = {
     "srf_densify": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "srf_roi_extract": (c_int, [POINTER(FeatMap), c_int, c_int, _P, c_int, c_int, c_int, c_float, _P, c_int64,
                                 c_int64, c_int64, c_int, _P, _P]),
+    "srf_roi_extract_sum": (c_int, [POINTER(FeatMap), c_int, c_int, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, c_int64, c_int64, _P]),
     "srf_linear_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "srf_linear": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, c_float, c_int, _P, c_int, _P, _P, c_float,
                            c_int, _P, c_int, _P, c_size_t, _P]),

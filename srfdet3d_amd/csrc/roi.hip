@@ -30,15 +30,21 @@ __device__ __forceinline__ int srf_roi_level(const float *b, int num_levels, flo
     return t < 0.0f ? 0 : (t > (float)(num_levels - 1) ? num_levels - 1 : (int)t);
 }
 
+// n_sum > 1 (srf_roi_extract_sum): output row r is the SUM over s = 0 .. n_sum - 1 of the gathers of the RoIs s * R + r, added in
+// that order -- the per-camera image RoIs of a proposal (srfdet_head.py:2543-2562 gathers all n_cam * R RoIs and then sums the
+// cameras): one launch and no (n_cam * R, S, C) intermediate instead of gather -> sum.  n_sum == 1 is the plain gather.
 __global__ __launch_bounds__(128) void srf_roi_extract_k(RoiLevels L, int C, const float *__restrict__ rois, int R,
                                                        int pooled, int sr, float finest_scale, float *__restrict__ out,
                                                        long long so_r, long long so_c, long long so_b, int accumulate,
-                                                       int *__restrict__ levels_out)
+                                                       int *__restrict__ levels_out, int n_sum)
 {
     __shared__ long long s_off[SRF_MAX_POOLED * SRF_MAX_SR * SRF_MAX_SR][4];
     __shared__ float s_w[SRF_MAX_POOLED * SRF_MAX_SR * SRF_MAX_SR][4];
     __shared__ int s_lvl;
-    const int r = blockIdx.x, ph = blockIdx.y;
+    const int r_out = blockIdx.x, ph = blockIdx.y;
+    for (int sidx = 0; sidx < n_sum; ++sidx) {
+    const int r = sidx * R + r_out;
+    if (sidx > 0) __syncthreads();   // the previous RoI's sample table is no longer read
     const float *b = rois + (size_t)r * 5;
     if (threadIdx.x == 0) {
         int l = srf_roi_level(b, L.num, finest_scale);
@@ -115,9 +121,11 @@ __global__ __launch_bounds__(128) void srf_roi_extract_k(RoiLevels L, int C, con
                 acc = __fadd_rn(acc, v);
             }
             const float res = __fdiv_rn(acc, count);
-            float *dst = out + (long long)r * so_r + (long long)c * so_c + (long long)(ph * pooled + pw) * so_b;
-            *dst = accumulate ? __fadd_rn(*dst, res) : res;
+            float *dst = out + (long long)r_out * so_r + (long long)c * so_c + (long long)(ph * pooled + pw) * so_b;
+            // the running sum over the n_sum RoIs lives in the output element itself: written by this thread only, in order
+            *dst = (accumulate || sidx > 0) ? __fadd_rn(*dst, res) : res;
         }
+    }
     }
 }
 
@@ -141,7 +149,31 @@ extern "C" int srf_roi_extract(const srf_featmap *levels, int num_levels, int C,
     for (int i = num_levels; i < SRF_MAX_LEVELS; ++i) L.lv[i] = levels[0];
     hipLaunchKernelGGL(srf_roi_extract_k, dim3(R, pooled), dim3(128), 0, (hipStream_t)stream, L, C, rois, R, pooled,
                        sampling_ratio, finest_scale, out, (long long)out_stride_r, (long long)out_stride_c,
-                       (long long)out_stride_bin, accumulate, levels_out);
+                       (long long)out_stride_bin, accumulate, levels_out, 1);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+extern "C" int srf_roi_extract_sum(const srf_featmap *levels, int num_levels, int C, const float *rois, int R, int n_sum, int pooled,
+                                   int sampling_ratio, float finest_scale, float *out, int64_t out_stride_r, int64_t out_stride_c,
+                                   int64_t out_stride_bin, srf_stream_t stream)
+{
+    if (!levels || num_levels <= 0 || num_levels > SRF_MAX_LEVELS || C <= 0 || R < 0 || n_sum <= 0 || pooled <= 0 ||
+        pooled > SRF_MAX_POOLED || sampling_ratio <= 0 || sampling_ratio > SRF_MAX_SR || !(finest_scale > 0.0f))
+        return SRF_EINVAL;
+    if (pooled * sampling_ratio * sampling_ratio > 128) return SRF_EINVAL;
+    if (R == 0) return SRF_OK;
+    if (!rois || !out) return SRF_EINVAL;
+    RoiLevels L;
+    L.num = num_levels;
+    for (int i = 0; i < num_levels; ++i) {
+        if (!levels[i].data || levels[i].N <= 0 || levels[i].H <= 0 || levels[i].W <= 0) return SRF_EINVAL;
+        L.lv[i] = levels[i];
+    }
+    for (int i = num_levels; i < SRF_MAX_LEVELS; ++i) L.lv[i] = levels[0];
+    hipLaunchKernelGGL(srf_roi_extract_k, dim3(R, pooled), dim3(128), 0, (hipStream_t)stream, L, C, rois, R, pooled,
+                       sampling_ratio, finest_scale, out, (long long)out_stride_r, (long long)out_stride_c,
+                       (long long)out_stride_bin, 0, (int *)nullptr, n_sum);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

@@ -572,20 +572,37 @@ def _featmap(t, scale):
 
 
 def roi_extract(feats, rois, strides, out_size=7, sampling_ratio=2, finest_scale=56.0, out=None, accumulate=False,
-                bin_major=False, return_levels=False):
-    """SingleRoIExtractor over len(strides) maps.  out: (R,C,out_size,out_size), or (R,out_size^2,C) if bin_major."""
+                bin_major=False, return_levels=False, n_sum=1):
+    """SingleRoIExtractor over len(strides) maps.  out: (R,C,out_size,out_size), or (R,out_size^2,C) if bin_major; a given `out` may
+    be a strided view (e.g. a channel slice of a wider buffer).  n_sum > 1: `rois` holds n_sum groups of R RoIs (group-major) and
+    row r of the result is the sum of the gathers of rois[s * R + r], s ascending (`srf_roi_extract_sum`: the camera sum of
+    srfdet_head.py:2543-2562 in the gather itself)."""
     rois = _dev(rois, "rois", torch.float32)
-    R = rois.shape[0]
+    if rois.shape[0] % n_sum:
+        raise ValueError("roi_extract: the number of RoIs must be a multiple of n_sum")
+    R = rois.shape[0] // n_sum
     C = feats[0].shape[1]
     nl = len(strides)
     fm = (FeatMap * nl)(*[_featmap(f, 1.0 / s) for f, s in zip(feats, strides)])
     bins = out_size * out_size
+    shape = (R, bins, C) if bin_major else (R, C, out_size, out_size)
     if out is None:
-        shape = (R, bins, C) if bin_major else (R, C, out_size, out_size)
         out = _empty(shape, torch.float32, rois.device)
         accumulate = False
-    so_r = C * bins
-    so_c, so_b = (1, C) if bin_major else (bins, 1)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_cuda:
+        raise ValueError(f"roi_extract: out must be a float32 GPU tensor of shape {shape}")
+    if bin_major:
+        so_r, so_b, so_c = out.stride(0) if R > 1 else bins * C, out.stride(1), out.stride(2) if C > 1 else 1
+    else:
+        if out.stride(3) != 1 or out.stride(2) != out_size:
+            raise ValueError("roi_extract: the bins of a channel must be contiguous in `out`")
+        so_r, so_c, so_b = out.stride(0) if R > 1 else C * bins, out.stride(1) if C > 1 else bins, 1
+    if n_sum > 1:
+        if accumulate or return_levels:
+            raise ValueError("roi_extract: n_sum excludes accumulate / return_levels")
+        check(_lib.lib().srf_roi_extract_sum(fm, nl, C, _ptr(rois), R, n_sum, out_size, sampling_ratio, float(finest_scale), _ptr(out),
+                                             so_r, so_c, so_b, _stream()), "roi_extract_sum")
+        return out
     lv = _empty((max(R, 1),), torch.int32, rois.device) if return_levels else None
     check(_lib.lib().srf_roi_extract(fm, nl, C, _ptr(rois), R, out_size, sampling_ratio, float(finest_scale), _ptr(out),
                                      so_r, so_c, so_b, int(bool(accumulate)), _ptr(lv), _stream()), "roi_extract")

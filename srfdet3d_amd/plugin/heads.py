@@ -320,10 +320,36 @@ class SingleSRFDetHead(_StageBase):
     def __init__(self, *args, use_fusion=False, **kwargs):
         super().__init__(*args, use_fusion=use_fusion, **kwargs)
 
+    def _fused_gather(self, img_feats, point_feats, rois_img, rois_bev, pooler_img, pooler, bs, n_p, n_cam):
+        """Both gathers of a fusion stage straight into the operand of `output_fused_proj` (srfdet_head.py:2543-2566 gathers the
+        n_cam * R image RoIs, sums the cameras, gathers the BEV RoIs and concatenates): the image gather sums the cameras itself
+        (`srf_roi_extract_sum`) into the left half of a (R, S, 2 C) buffer, the BEV gather writes the right half -- two launches
+        instead of four (gather, camera sum, gather, cat) and no (n_cam R, S, C) intermediate.  Inference on the GPU only."""
+        C = self.feat_channels_lidar
+        R = bs * n_p
+        layer = pooler.roi_layers[0]
+        S = layer.output_size ** 2
+        fused_in = torch.empty((R, S, 2 * C), dtype=torch.float32, device=rois_bev.device)
+        flat = [f.reshape(f.shape[0] * f.shape[1], *f.shape[2:]) for f in img_feats]
+        if self.corrected_cam_indexing and bs > 1:
+            ids = rois_img[:, 0]
+            rois_img = rois_img.clone()
+            rois_img[:, 0] = torch.remainder(ids, bs) * n_cam + torch.div(ids, bs, rounding_mode="floor")
+        pooler_img(_channels_last(flat[:pooler_img.num_inputs]), rois_img, out=fused_in[..., :C], bin_major=True, n_sum=n_cam)
+        pooler(_channels_last(list(point_feats[:pooler.num_inputs])), rois_bev, out=fused_in[..., C:], bin_major=True)
+        return fused_in
+
     def forward(self, img_feats, point_feats, bboxes, prop_feats, pooler, img_metas, pooler_img=None):
         bs, n_p = bboxes.shape[:2]
         l2i = self._lidar2img(img_metas, bboxes) if img_feats is not None else None
         bboxes, rois_bev, rois_img = self._geometry(bboxes, point_feats is not None, l2i)
+        if (img_feats is not None and point_feats is not None and self.use_fusion and rois_bev.is_cuda and not torch.is_grad_enabled()
+                and isinstance(pooler, SingleRoIExtractor) and isinstance(pooler_img, SingleRoIExtractor)
+                and self._hip_eligible(rois_bev.new_empty((1, pooler.roi_layers[0].output_size ** 2, 1)))):
+            fused_in = self._fused_gather(img_feats, point_feats, rois_img, rois_bev, pooler_img, pooler, bs, n_p, l2i.shape[1])
+            roi_feats = ops.linear(fused_in.view(-1, fused_in.shape[-1]), self.output_fused_proj.weight,
+                                   self.output_fused_proj.bias).view(fused_in.shape[0], fused_in.shape[1], -1)
+            return self._refine(roi_feats, bboxes, prop_feats, bs, n_p)
         img_roi = self._img_rois_feats(img_feats, rois_img, pooler_img, bs, n_p, l2i.shape[1]) \
             if img_feats is not None else None
         pts_roi = self._gather(point_feats, rois_bev, pooler) if point_feats is not None else None

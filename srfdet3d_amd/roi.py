@@ -59,9 +59,9 @@ class SingleRoIExtractor(nn.Module):
     def num_inputs(self):
         return len(self.featmap_strides)
 
-    def forward(self, feats, rois, roi_scale_factor=None, out=None, accumulate=False, bin_major=False):
+    def forward(self, feats, rois, roi_scale_factor=None, out=None, accumulate=False, bin_major=False, n_sum=1):
         assert roi_scale_factor is None
         layer = self.roi_layers[0]
         return ops.roi_extract(list(feats[:self.num_inputs]), rois, self.featmap_strides, layer.output_size,
                                layer.sampling_ratio, float(self.finest_scale), out=out, accumulate=accumulate,
-                               bin_major=bin_major)
+                               bin_major=bin_major, n_sum=n_sum)

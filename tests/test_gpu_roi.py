@@ -79,3 +79,34 @@ def test_box_rois_match_reference_fixture(dev):
     np.testing.assert_array_equal(got[:, 0], ref[:, 0])
     # projected corners reach 1e7 px when a corner sits near the camera plane: compare relatively
     np.testing.assert_allclose(got[:, 1:], ref[:, 1:], rtol=2e-4, atol=5e-2)
+
+
+def test_roi_extract_sum_is_the_ordered_camera_sum_into_a_strided_slice(dev):
+    """srf_roi_extract_sum (the image gather of a fusion stage, srfdet_head.py:2543-2562): row r = gather(roi[0 R + r]) + gather(roi[1 R + r])
+    + ... added in camera order, written into a channel slice of the (R, S, 2 C) operand of `output_fused_proj`; the plain gather into
+    the other slice.  Against the oracle's per-RoI gathers summed in the same order: exact."""
+    rng = np.random.default_rng(3)
+    n_cam, R, C = 6, 40, 128
+    feats = _pyramid(rng, C=C, sizes=(58, 29, 15, 8), N=n_cam)
+    rois = _rois(rng, n_cam * R, size=460, N=n_cam)
+    ref, _ = O.roi_extract(feats, rois, [8, 16, 32, 64])                    # (n_cam R, C, 7, 7)
+    want = ref[:R].copy()
+    for s in range(1, n_cam):
+        want = want + ref[s * R:(s + 1) * R]                                 # sequential float32 adds, camera order
+    want = want.reshape(R, C, 49).transpose(0, 2, 1)                         # bin-major (R, S, C)
+    tcl = [torch.from_numpy(f).to(dev).contiguous(memory_format=torch.channels_last) for f in feats]
+    buf = torch.full((R, 49, 2 * C), 7.0, device=dev)
+    out = ops.roi_extract(tcl, torch.from_numpy(rois).to(dev), [8, 16, 32, 64], out=buf[..., :C], bin_major=True, n_sum=n_cam)
+    assert out.data_ptr() == buf.data_ptr()
+    np.testing.assert_array_equal(buf[..., :C].cpu().numpy(), want)
+    assert torch.all(buf[..., C:] == 7.0)                                    # the other half is untouched
+    # the plain gather into the right half of the same buffer
+    bev = _pyramid(rng, C=C, sizes=(46, 23, 12, 6), N=1)
+    rb = _rois(rng, R, size=368, N=1)
+    refb, _ = O.roi_extract(bev, rb, [8, 16, 32, 64])
+    tb = [torch.from_numpy(f).to(dev).contiguous(memory_format=torch.channels_last) for f in bev]
+    ops.roi_extract(tb, torch.from_numpy(rb).to(dev), [8, 16, 32, 64], out=buf[..., C:], bin_major=True)
+    np.testing.assert_array_equal(buf[..., C:].cpu().numpy(), refb.reshape(R, C, 49).transpose(0, 2, 1))
+    np.testing.assert_array_equal(buf[..., :C].cpu().numpy(), want)
+    with pytest.raises(ValueError):
+        ops.roi_extract(tcl, torch.from_numpy(rois[:7]).to(dev), [8, 16, 32, 64], n_sum=n_cam)
