@@ -1447,7 +1447,10 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
 #define SRF_ARGS in, Cin, W_packed, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev
     switch (Cout) {
     case 32:
-        if (srf_w32_layout(K, Cin, Cout) && (long long)A_in * Cin * 4 < (1ll << 31)) {
+        // the weights of these shapes are packed for srf_spconv_w32_k alone (srf_spconv_pack_weights picks the layout from (K, Cin, Cout)):
+        // an input beyond its 32-bit descriptor range (>= 16 M rows) must not fall through to a kernel that reads the tile layout
+        if (srf_w32_layout(K, Cin, Cout) && (long long)A_in * Cin * 4 >= (1ll << 31)) return SRF_EUNSUPPORTED;
+        if (srf_w32_layout(K, Cin, Cout)) {
             int dev = 0;
             SRF_HIP_TRY(hipGetDevice(&dev));
             static bool attr_set[64] = {false};

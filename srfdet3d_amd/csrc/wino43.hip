@@ -492,10 +492,11 @@ extern "C" int srf_wino43_pack_weights(const float *W, int Cout, int Cin, float 
     return SRF_OK;
 }
 
-// Slabs.  V is 2.25x the layer's input (1.3 GB for 256 channels on six 232 x 400 maps): written to HBM by one kernel and read
-// back by the next it costs 3.25x the input in HBM traffic.  The layer therefore runs in slabs of tile blocks whose V fits the
-// Infinity Cache beside the slab's input and output: transform slab i -> multiply slab i, in ONE workspace that every slab
-// overwrites (the lines stay on the die, V never goes to HBM).  A slab is sized to whole rounds of workgroups (one per CU).
+// Slabs.  V is 2.25x the layer's input (1.3 GB for 256 channels on six 232 x 400 maps) and is addressed through 32-bit buffer
+// descriptors: a layer whose V would reach 2 GB runs in slabs of tile blocks -- transform slab i -> multiply slab i -- in ONE
+// slab-sized workspace that every slab overwrites.  (Round 3 also tried slabs small enough for V to stay in the 256 MB Infinity
+// Cache: no gain, the transform runs at the rate of its read / write mix either way, so the cut is only about the descriptor
+// range.)  A slab is sized to whole rounds of workgroups (one per CU).
 #define W43_SLAB_BYTES (2048ll << 20)
 
 static long long w43_slab_tb(long long ntb, int nchunk, int ncb)

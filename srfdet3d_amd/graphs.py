@@ -310,10 +310,13 @@ class GraphedFrame:
             # while the camera graph is still running on its own stream; the decoder graph follows the join
             with torch.no_grad(), _graph_safe_convs(safe), torch.cuda.graph(graph):
                 x, counts = self._run_bev(static_pts, caps)
+                # the LiDAR half of the proposal generator needs no image feature: it runs here, beside the camera graph, instead
+                # of on the serial tail after the join
+                dpg = m.bbox_head.dpg_lidar_logits(x) if getattr(m.bbox_head, "with_dpg", False) else None
             _validate(graph, list(x) + [counts[0]], ref_x + [ref[2]], "whole-frame graph (BEV half)")
             head_graph = torch.cuda.CUDAGraph()
             with torch.no_grad(), _graph_safe_convs(safe), torch.cuda.graph(head_graph, pool=graph.pool()):
-                scores, boxes, sel = self._run_head(x, sm.metas, img_feats)
+                scores, boxes, sel = self._run_head(x, sm.metas, img_feats, dpg)
                 host_pack = self._host_pack(sel, counts[0]) if sel is not None else None
             _validate(head_graph, [scores, boxes], ref[:2], "whole-frame graph (decoder half)")
         self.stats["captures"] += 1
@@ -332,9 +335,9 @@ class GraphedFrame:
         limits = [c[2] for c in counts]
         return tuple(x), (dev_counts, limits)
 
-    def _run_head(self, x, img_metas, img_feats=None):
+    def _run_head(self, x, img_metas, img_feats=None, dpg_lidar=None):
         m = self.model
-        logits, boxes = m.bbox_head(img_feats, x, img_metas)
+        logits, boxes = m.bbox_head(img_feats, x, img_metas) if dpg_lidar is None else m.bbox_head(img_feats, x, img_metas, dpg_lidar)
         scores, dec = m.bbox_head.decode(logits, boxes)
         sel = m.bbox_head.select_static(scores, dec) if getattr(m.bbox_head, "use_nms", False) else None
         return scores, dec, sel

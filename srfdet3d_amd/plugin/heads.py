@@ -528,14 +528,21 @@ class SRFDetHead(BaseModule):
             return x.flatten(2).transpose(1, 2).contiguous().sum(dim=-1)
         return x.sum(dim=1).flatten(1, 2)
 
-    def _get_init_proposals(self, img_feats, point_feats):
+    def dpg_lidar_logits(self, point_feats):
+        """The LiDAR half of the dynamic proposal generator (srfdet_head.py:506-512 of `_get_init_proposals`): depthwise stair over the
+        BEV pyramid -> channel sum -> fc1 -> ReLU -> fc2, (bs, E * P).  It needs no image feature, so the LC frame computes it in the
+        BEV-half graph, beside the camera graph, and hands it to `forward` (`precomputed_dpg_lidar`) instead of running its ~14
+        small launches on the serial tail after the join."""
+        w = self._channel_sum(self._stair(self.dpg_dw_convs_lidar, point_feats[:self.lidar_feat_lvls]))
+        return linear_graph_safe(self.dpg_fc2_lidar, self.dpg_act_lidar(linear_graph_safe(self.dpg_fc1_lidar, w)))
+
+    def _get_init_proposals(self, img_feats, point_feats, lidar_logits=None):
         bs = point_feats[0].shape[0]
         boxes_w, feats_w = self.init_proposal_boxes.weight, self.init_proposal_feats.weight
         if not self.with_dpg:
             return boxes_w[None].repeat(bs, 1, 1), feats_w[None].repeat(bs, 1, 1)
         E, P = self.num_dpg_exp, self.num_proposals
-        w = self._channel_sum(self._stair(self.dpg_dw_convs_lidar, point_feats[:self.lidar_feat_lvls]))
-        w = linear_graph_safe(self.dpg_fc2_lidar, self.dpg_act_lidar(linear_graph_safe(self.dpg_fc1_lidar, w))).reshape(bs, E, P)
+        w = (self.dpg_lidar_logits(point_feats) if lidar_logits is None else lidar_logits).reshape(bs, E, P)
         if self.use_img:
             flat = [f.reshape(f.shape[0] * f.shape[1], *f.shape[2:]) for f in img_feats[:self.img_feat_lvls]]
             n_cam = img_feats[0].shape[1]
@@ -574,12 +581,13 @@ class SRFDetHead(BaseModule):
         return lambda i, x: nhwc.conv3x3(x, self.img_convs[i])
 
     # ---- forward --------------------------------------------------------------------------------------------
-    def forward(self, img_feats, point_feats, img_metas):
-        """-> logits (#stage, bs, n_p, #cls), boxes (#stage, bs, n_p, D) with centres in metres, log sizes."""
+    def forward(self, img_feats, point_feats, img_metas, precomputed_dpg_lidar=None):
+        """-> logits (#stage, bs, n_p, #cls), boxes (#stage, bs, n_p, D) with centres in metres, log sizes.
+        precomputed_dpg_lidar: `dpg_lidar_logits(point_feats)` computed earlier by the caller (graphs.GraphedFrame: in the BEV half)."""
         point_feats = list(point_feats)
         if self.use_img and self.hidden_dim != self.feat_channels_img and not isinstance(img_feats, nhwc.ConsumedLevels):
             img_feats = self._img_convs_only(img_feats)
-        boxes, prop_feats = self._get_init_proposals(img_feats, point_feats)
+        boxes, prop_feats = self._get_init_proposals(img_feats, point_feats, precomputed_dpg_lidar)
         boxes = boxes.contiguous()
         boxes[..., :3] = boxes[..., :3].sigmoid()
 

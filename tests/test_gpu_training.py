@@ -188,8 +188,9 @@ def test_ddp_two_ranks_average_gradients(dev):
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=1.3e-6, atol=1e-5)  # gradients all-reduced: identical on both ranks
 
 
+@pytest.mark.parametrize("channels_last", [True, False])
 @pytest.mark.parametrize("N,Cin,Cout,H,W,bias", [(2, 64, 96, 13, 21, True), (3, 192, 192, 29, 50, False), (1, 256, 128, 58, 100, True)])
-def test_training_conv3x3_on_the_winograd_kernel_matches_autograd(dev, N, Cin, Cout, H, W, bias):
+def test_training_conv3x3_on_the_winograd_kernel_matches_autograd(dev, N, Cin, Cout, H, W, bias, channels_last):
     """train_conv._Wino43Conv (forward and data gradient on srf_wino43, weight gradient through aten.convolution_backward on the
     channels-last operands) against torch's own autograd through F.conv2d in float64: 1e-4 relative to each tensor's maximum, as
     tests/test_gpu_spconv_bwd.py holds the sparse convolution's gradients."""
@@ -197,12 +198,19 @@ def test_training_conv3x3_on_the_winograd_kernel_matches_autograd(dev, N, Cin, C
     from srfdet3d_amd import train_conv
     g = torch.Generator().manual_seed(Cin + H)
     conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1, bias=bias).to(dev)
-    x = torch.randn(N, Cin, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev)
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
     gy = torch.randn(N, Cout, H, W, generator=g).to(dev)
     assert train_conv.eligible(conv, x)
     y = train_conv.conv2d(conv, x)
-    assert y.stride(1) == 1 and y.grad_fn is not None            # channels-last, on the autograd tape
+    assert y.grad_fn is not None                                  # on the autograd tape
+    # the caller's memory format is kept (the NCHW-in / NCHW-out branch had no test): channels-last in -> channels-last out,
+    # NCHW-contiguous in -> NCHW-contiguous out, and the same for the input gradient
+    assert (y.stride(1) == 1) if channels_last else y.is_contiguous()
     y.backward(gy)
+    assert (x.grad.stride(1) == 1) if channels_last else x.grad.is_contiguous()
     xd = x.detach().double().cpu().requires_grad_(True)
     wd = conv.weight.detach().double().cpu().requires_grad_(True)
     bd = conv.bias.detach().double().cpu().requires_grad_(True) if bias else None
@@ -224,7 +232,15 @@ def test_training_depthwise_and_1x1_routes_match_autograd(dev):
     g = torch.Generator().manual_seed(9)
     for conv in (torch.nn.Conv2d(64, 64, 3, stride=2, padding=1, groups=64, bias=False), torch.nn.Conv2d(96, 160, 1, bias=True)):
         conv = conv.to(dev)
-        x = torch.randn(2, conv.in_channels, 21, 34, generator=g).to(dev).requires_grad_(True)
+        x = torch.randn(2, conv.in_channels, 21, 34, generator=g).to(dev)
+        if conv.kernel_size == (1, 1):
+            # the GEMM route is taken for channels-last tensors only (an NCHW input silently took torch's convolution)
+            x = x.contiguous(memory_format=torch.channels_last)
+        x.requires_grad_(True)
+        if conv.kernel_size == (1, 1):
+            assert train_conv.eligible_1x1(conv, x)
+        else:
+            assert train_conv.eligible_depthwise(conv, x)
         bn = torch.nn.BatchNorm2d(conv.out_channels).to(dev).eval()
         with torch.no_grad():
             bn.running_mean.normal_(0, 0.1)
