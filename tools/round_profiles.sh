@@ -1,14 +1,19 @@
 #!/bin/bash
 # Collects the measurements of a round on the GPU box into gpurun_out/<round>/ (copy what is to be judged into profiles/).
-# usage (from the repo root, through gpurun):  bash tools/round_profiles.sh r04
+# usage (from the repo root, through gpurun):  bash tools/round_profiles.sh r04 [A|B|C|all]
+#   A = bench lines + kernel traces, B = per-stage tables / host feed / training / rehearsal, C = PMC traffic (a gpurun call is limited
+#   to 20 minutes: one part per call)
 set -o pipefail
 R=${1:-r04}
+PART=${2:-all}
 O=gpurun_out/$R
 mkdir -p $O
 export TMPDIR=/tmp
+part() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
 run() { echo "== $*" >> $O/log.txt; "$@" >> $O/log.txt 2>&1; }
 line() { tail -1 "$1" > "$2"; }
 
+if part A; then
 # bench lines (one JSON line each)
 python bench.py > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line.json
 python bench.py --workload nusc_L > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_nuscL.json
@@ -29,6 +34,8 @@ cp $O/prof_l/l_kernel_stats.csv $O/${R}_bench_nuscL_np200_kernel_stats.csv
 python tools/in_graph_summary.py $O/${R}_bench_nuscLC_np200_kernel_stats.csv nusc_LC 88 $O/${R}_in_graph_summary.json >> $O/log.txt 2>&1
 rm -rf $O/prof_lc $O/prof_l $O/tmp.json
 echo "kernel traces done" >> $O/log.txt
+fi
+if part B; then
 
 # per-stage tables, host-fed rates, the memset-node test
 python tools/stage_roofline.py --workload nusc_L --md $O/${R}_stage_roofline_nuscL.md >> $O/log.txt 2>&1
@@ -42,9 +49,12 @@ python tools/train_bench.py --iters 8 --warmup 3 --kernel-table $O/${R}_train_st
 # N = 2 rehearsal of bench.py's distributed branch on the one GPU (gloo; both ranks on device 0)
 SRF_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --workload nusc_L --no-cpu-baseline 2>> $O/log.txt | tail -1 > $O/${R}_rehearsal_2ranks_sharing_one_gpu_nuscL.json
 echo "tables done" >> $O/log.txt
+fi
+if part C; then
 
 # HBM traffic of the roofline kernels (three --pmc passes per target)
 python tools/measure_traffic.py >> $O/log.txt 2>&1
 cp gpurun_out/traffic/${R}_pmc_*_traffic.json $O/ 2>/dev/null
-echo "all done" >> $O/log.txt
+fi
+echo "part $PART done" >> $O/log.txt
 tail -3 $O/log.txt
