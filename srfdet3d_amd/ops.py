@@ -1115,6 +1115,21 @@ def gemm_split_enabled():
     return os.environ.get("SRF_GEMM_SPLIT", "1") != "0"
 
 
+GEMM_SPLIT_MIN_TILES = 384   # 128 x 128 tiles of a launch from which the split kernel is taken: half a round at three workgroups per CU
+
+
+def gemm_split_wanted(M, Cout):
+    """The split GEMM has one tile form (128 x 128, three workgroups per CU); a launch of fewer than ~half a round of tiles (the BEV
+    FPN's laterals and stride-2 extras, the coarse image laterals) fills the chip better on the 64 x 64 tiles of the f32-MFMA kernels:
+    nusc_L, whose GEMMs are all of that size, ran 1.5-2 % slower with everything on the split kernel (same box, alternating runs:
+    229.7 / 233.7 against 234.8 / 237.1 frames/s).  SRF_GEMM_SPLIT_MIN overrides the threshold (A/B switch)."""
+    import os
+    if not gemm_split_enabled():
+        return False
+    thr = int(os.environ.get("SRF_GEMM_SPLIT_MIN", GEMM_SPLIT_MIN_TILES))
+    return ((M + 127) // 128) * ((Cout + 127) // 128) >= thr
+
+
 GEMM_DIRECT_MIN_TILES = 1024   # 128 x 128 tiles of a launch from which the LDS-free kernel wins (tools/micro/gemm_direct_bench.hip)
 
 
@@ -1147,7 +1162,7 @@ def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out
         raise ValueError("conv1x1_nhwc: out has the wrong shape")
     y_ld = nhwc_ld(out)
     L = _lib.lib()
-    split = packed_split is not None and gemm_split_enabled() and max(x_ld, y_ld) * 512 < (1 << 31)
+    split = packed_split is not None and gemm_split_wanted(N * H * W, Cout) and max(x_ld, y_ld) * 512 < (1 << 31)
     direct = not split and packed_direct is not None and conv1x1_direct_wanted(N * H * W, Cout) and max(x_ld, y_ld) * 512 < (1 << 31)
     if split:
         if callable(packed_split):
@@ -1295,7 +1310,7 @@ def conv_gemm_nhwc(x, packed_weight, Cout, ksize, stride, pad, scale=None, shift
     elif tuple(out.shape) != (N, Ho, Wo, Cout):
         raise ValueError("conv_gemm_nhwc: out has the wrong shape")
     L = _lib.lib()
-    split = packed_split is not None and gemm_split_enabled()
+    split = packed_split is not None and gemm_split_wanted(N * Ho * Wo, Cout)
     if split:
         if callable(packed_split):
             packed_split = packed_split()

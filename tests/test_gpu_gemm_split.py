@@ -17,6 +17,12 @@ from srfdet3d_amd import ops
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _always_split(monkeypatch):
+    """ops.conv1x1_nhwc takes the split kernel only for launches of >= 384 tiles; these tests exercise it on small shapes too"""
+    monkeypatch.setenv("SRF_GEMM_SPLIT_MIN", "0")
+
+
 def _split(x, w, **kw):
     Cout = w.shape[0]
     return ops.conv1x1_nhwc(x, None, Cout, packed_split=ops.pack_conv1x1_nhwc_split_weights(w), **kw)
@@ -130,6 +136,14 @@ def test_camera_executor_routes_1x1_layers_to_the_split_kernel_by_default(dev, m
         want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), conv.weight.double().cpu(), conv.bias.double().cpu()).permute(0, 2, 3, 1)
     assert (a.double().cpu() - want).abs().max().item() <= 3e-6 * want.abs().max().item()
     assert (b.double().cpu() - want).abs().max().item() <= 3e-6 * want.abs().max().item()
+    # with the default threshold a launch this small (15 tiles) stays on the f32-MFMA kernels (ops.gemm_split_wanted)
+    monkeypatch.delenv("SRF_GEMM_SPLIT", raising=False)
+    monkeypatch.delenv("SRF_GEMM_SPLIT_MIN", raising=False)
+    conv2 = torch.nn.Conv2d(256, 128, 1, bias=True).to(dev)
+    with torch.no_grad():
+        nhwc.conv1x1(x, conv2)
+    assert not hasattr(conv2, "_srf_gemm_split") and (hasattr(conv2, "_srf_gemm") or hasattr(conv2, "_srf_gemm_direct"))
+    assert ops.gemm_split_wanted(6 * 232 * 400, 256) and not ops.gemm_split_wanted(92 * 92, 128)
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad", [(2, 37, 41, 64, 128, 3, 2, 1), (1, 46, 46, 128, 128, 3, 2, 1), (2, 20, 24, 32, 40, 3, 1, 1),

@@ -9,10 +9,19 @@ PART=${2:-all}
 O=gpurun_out/$R
 mkdir -p $O
 export TMPDIR=/tmp
-part() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
+part() { { [ "$PART" = all ] && [ "$1" != T ]; } || [ "$PART" = "$1" ]; }
 run() { echo "== $*" >> $O/log.txt; "$@" >> $O/log.txt 2>&1; }
 line() { tail -1 "$1" > "$2"; }
 
+if part T; then   # the two kernel traces alone
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lc -o lc -- python3 bench.py --no-cpu-baseline --no-f32-mfma-line > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_under_rocprof_LC.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_l -o l -- python3 bench.py --workload nusc_L --no-cpu-baseline > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_under_rocprof_nuscL.json
+cp $O/prof_lc/lc_kernel_stats.csv $O/${R}_bench_nuscLC_np200_kernel_stats.csv
+cp $O/prof_l/l_kernel_stats.csv $O/${R}_bench_nuscL_np200_kernel_stats.csv
+rm -f $O/${R}_in_graph_summary.json
+python tools/in_graph_summary.py $O/${R}_bench_nuscLC_np200_kernel_stats.csv nusc_LC 88 $O/${R}_in_graph_summary.json >> $O/log.txt 2>&1
+rm -rf $O/prof_lc $O/prof_l $O/tmp.json
+fi
 if part A; then
 # bench lines (one JSON line each)
 python bench.py > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line.json
@@ -26,7 +35,8 @@ python bench.py --whole-frame off --no-cpu-baseline > $O/tmp.json 2>> $O/log.txt
 echo "bench lines done" >> $O/log.txt
 
 # kernel traces of the same commands
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lc -o lc -- python3 bench.py --no-cpu-baseline > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_under_rocprof_LC.json
+# (--no-f32-mfma-line: the traced process must contain the frames of the headline route only, or the per-frame sums mix both GEMM routes)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lc -o lc -- python3 bench.py --no-cpu-baseline --no-f32-mfma-line > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_under_rocprof_LC.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_l -o l -- python3 bench.py --workload nusc_L --no-cpu-baseline > $O/tmp.json 2>> $O/log.txt && line $O/tmp.json $O/${R}_bench_line_under_rocprof_nuscL.json
 cp $O/prof_lc/lc_kernel_stats.csv $O/${R}_bench_nuscLC_np200_kernel_stats.csv
 cp $O/prof_l/l_kernel_stats.csv $O/${R}_bench_nuscL_np200_kernel_stats.csv
