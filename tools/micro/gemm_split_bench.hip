@@ -360,6 +360,216 @@ __global__ __launch_bounds__(256, 3) void gemm_split2(const float *__restrict__ 
         }
 }
 
+// ---- v3: A never touches LDS.  A wave owns 32 rows x all 128 columns of the tile (1 x 4 accumulator tiles), so no other wave needs its A
+// rows: lane (row, k half) loads its 8 floats of a k-step straight from the activation (two dwordx4) and splits them in registers -- every
+// element is split exactly once per workgroup, as before, but the 24 KB A image, its 12 ds_write_b64 per thread and a third of the
+// fragment reads are gone.  B as in v1 (pre-split image copied to LDS), double buffered: one barrier per chunk.
+template <int WPE>
+__global__ __launch_bounds__(256, WPE) void gemm_split3(const float *__restrict__ x, long long M, int K, long long x_ld, const unsigned short *__restrict__ Bp,
+                                                        int Cout, float *__restrict__ y, long long y_ld, int nct)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 24576];   // B planes, two stages
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const int ct = jq % nct;
+    const long long mblocks = (M + 127) / 128;
+    const long long mb = (long long)(jq / nct) * 8 + xcd;
+    if (mb >= mblocks) return;
+    const long long p0 = mb * 128;
+    const long long rows_here = M - p0 < 128 ? M - p0 : 128;
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x) + p0 * x_ld, 0, (int)(rows_here * x_ld * 4), 0x00020000);
+    const int nchunk = K / 32;
+    const size_t chunk_stride = (size_t)nct * 24576;   // bytes
+    const unsigned char *bsrc = reinterpret_cast<const unsigned char *>(Bp) + (size_t)ct * 24576 + (size_t)tid * 16;
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned aoff = (unsigned)(((wave * 32 + li) * x_ld + lh * 8) * 4);   // + chunk * 128 + step * 64 (+ 16)
+    f4 araw[2][2];
+    u4 braw[6];
+#define LOADA3(C)                                                                                                          \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                                       \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                                 \
+            auto v_ = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)aoff, (C) * 128 + s_ * 64 + h_ * 16, 0);              \
+            araw[s_][h_] = *reinterpret_cast<f4 *>(&v_);                                                                   \
+        }
+#define LOADB3(C)                                                                                                          \
+    do {                                                                                                                   \
+        const u4 *bb_ = reinterpret_cast<const u4 *>(bsrc + (size_t)(C) * chunk_stride);                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) braw[i_] = bb_[i_ * 256];                                         \
+    } while (0)
+#define STOREB3(BUF) _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) *reinterpret_cast<u4 *>(lds + (BUF) * 24576 + (tid + i_ * 256) * 16) = braw[i_];
+    int b_off[4], swz_b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = j * 32 + li;
+        b_off[j] = col * 64;
+        swz_b[j] = (col >> 2) & 3;
+    }
+    f16v acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    bf8 pa[2][3];   // [step][plane]
+#define SPLITA3()                                                                                                          \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                     \
+        unsigned h_[4], m_[4], l_[4];                                                                                      \
+        split2v<1>(araw[s_][0][0], araw[s_][0][1], h_[0], m_[0], l_[0]);                                                   \
+        split2v<1>(araw[s_][0][2], araw[s_][0][3], h_[1], m_[1], l_[1]);                                                   \
+        split2v<1>(araw[s_][1][0], araw[s_][1][1], h_[2], m_[2], l_[2]);                                                   \
+        split2v<1>(araw[s_][1][2], araw[s_][1][3], h_[3], m_[3], l_[3]);                                                   \
+        const u4 vh_ = {h_[0], h_[1], h_[2], h_[3]}, vm_ = {m_[0], m_[1], m_[2], m_[3]}, vl_ = {l_[0], l_[1], l_[2], l_[3]}; \
+        pa[s_][0] = *reinterpret_cast<const bf8 *>(&vh_);                                                                  \
+        pa[s_][1] = *reinterpret_cast<const bf8 *>(&vm_);                                                                  \
+        pa[s_][2] = *reinterpret_cast<const bf8 *>(&vl_);                                                                  \
+    }
+    const int last = nchunk - 1;
+    LOADA3(0);
+    LOADB3(0);
+    STOREB3(0);
+    SPLITA3();
+    LOADA3(last < 1 ? last : 1);
+    LOADB3(last < 1 ? last : 1);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int cur = c & 1;
+        const int c2 = c + 2 < nchunk ? c + 2 : last;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf8 fbj[3];
+#pragma unroll
+                for (int p_ = 0; p_ < 3; ++p_)
+                    fbj[p_] = *reinterpret_cast<const bf8 *>(lds + cur * 24576 + p_ * 8192 + b_off[j] + (((2 * s + lh) ^ swz_b[j]) << 4));
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s][2], fbj[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s][0], fbj[2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s][1], fbj[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s][1], fbj[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s][0], fbj[1], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s][0], fbj[0], acc[j], 0, 0, 0);
+            }
+        STOREB3(cur ^ 1);     // chunk c + 1 (its last readers passed the barrier that ended chunk c - 1)
+        SPLITA3();            // chunk c + 1's A planes (the MFMAs above have consumed chunk c's)
+        LOADA3(c2);
+        LOADB3(c2);
+        __syncthreads();
+    }
+    const int co0 = ct * 128 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long long row = p0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = co0 + j * 32;
+            if (row < M && co < Cout) y[row * y_ld + co] = acc[j][r];
+        }
+    }
+}
+
+// ---- v4: v3 with the A loads TWO chunks ahead (two register sets, loop unrolled by two; two workgroups per CU for the registers)
+__global__ __launch_bounds__(256, 2) void gemm_split4(const float *__restrict__ x, long long M, int K, long long x_ld, const unsigned short *__restrict__ Bp,
+                                                     int Cout, float *__restrict__ y, long long y_ld, int nct)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 24576];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3;
+    const int ct = jq % nct;
+    const long long mblocks = (M + 127) / 128;
+    const long long mb = (long long)(jq / nct) * 8 + xcd;
+    if (mb >= mblocks) return;
+    const long long p0 = mb * 128;
+    const long long rows_here = M - p0 < 128 ? M - p0 : 128;
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x) + p0 * x_ld, 0, (int)(rows_here * x_ld * 4), 0x00020000);
+    const int nchunk = K / 32;
+    const size_t chunk_stride = (size_t)nct * 24576;
+    const unsigned char *bsrc = reinterpret_cast<const unsigned char *>(Bp) + (size_t)ct * 24576 + (size_t)tid * 16;
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned aoff = (unsigned)(((wave * 32 + li) * x_ld + lh * 8) * 4);
+    f4 ara[2][2], arb[2][2];
+    u4 braw[6];
+#define LOADA4(R, C)                                                                                                       \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                                       \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                                 \
+            auto v_ = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)aoff, (C) * 128 + s_ * 64 + h_ * 16, 0);              \
+            R[s_][h_] = *reinterpret_cast<f4 *>(&v_);                                                                      \
+        }
+    int b_off[4], swz_b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = j * 32 + li;
+        b_off[j] = col * 64;
+        swz_b[j] = (col >> 2) & 3;
+    }
+    f16v acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    bf8 pa[2][3];
+#define SPLITA4(R)                                                                                                         \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                                     \
+        unsigned h_[4], m_[4], l_[4];                                                                                      \
+        split2v<1>(R[s_][0][0], R[s_][0][1], h_[0], m_[0], l_[0]);                                                         \
+        split2v<1>(R[s_][0][2], R[s_][0][3], h_[1], m_[1], l_[1]);                                                         \
+        split2v<1>(R[s_][1][0], R[s_][1][1], h_[2], m_[2], l_[2]);                                                         \
+        split2v<1>(R[s_][1][2], R[s_][1][3], h_[3], m_[3], l_[3]);                                                         \
+        const u4 vh_ = {h_[0], h_[1], h_[2], h_[3]}, vm_ = {m_[0], m_[1], m_[2], m_[3]}, vl_ = {l_[0], l_[1], l_[2], l_[3]}; \
+        pa[s_][0] = *reinterpret_cast<const bf8 *>(&vh_);                                                                  \
+        pa[s_][1] = *reinterpret_cast<const bf8 *>(&vm_);                                                                  \
+        pa[s_][2] = *reinterpret_cast<const bf8 *>(&vl_);                                                                  \
+    }
+#define MULT4(CUR)                                                                                                         \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
+            bf8 fbj[3];                                                                                                    \
+            _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_)                                                               \
+                fbj[p_] = *reinterpret_cast<const bf8 *>(lds + (CUR) * 24576 + p_ * 8192 + b_off[j] + (((2 * s + lh) ^ swz_b[j]) << 4)); \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s][2], fbj[0], acc[j], 0, 0, 0);                           \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s][0], fbj[2], acc[j], 0, 0, 0);                           \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s][1], fbj[1], acc[j], 0, 0, 0);                           \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s][1], fbj[0], acc[j], 0, 0, 0);                           \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s][0], fbj[1], acc[j], 0, 0, 0);                           \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s][0], fbj[0], acc[j], 0, 0, 0);                           \
+        }
+    const int last = nchunk - 1;
+#define CL(C) ((C) < nchunk ? (C) : last)
+    LOADA4(ara, 0);
+    LOADB3(0);
+    STOREB3(0);
+    SPLITA4(ara);              // planes of chunk 0
+    LOADA4(ara, CL(1));        // ara <- chunk 1
+    LOADA4(arb, CL(2));        // arb <- chunk 2
+    LOADB3(CL(1));
+    __syncthreads();
+    for (int c = 0; c < nchunk; c += 2) {
+        // even chunk c: planes hold c; ara = c + 1, arb = c + 2; braw = B(c + 1)
+        MULT4(0);
+        STOREB3(1);
+        SPLITA4(ara);          // planes <- c + 1
+        LOADA4(ara, CL(c + 3));
+        LOADB3(CL(c + 2));
+        __syncthreads();
+        if (c + 1 >= nchunk) break;
+        // odd chunk c + 1: planes hold c + 1; arb = c + 2, ara = c + 3; braw = B(c + 2)
+        MULT4(1);
+        STOREB3(0);
+        SPLITA4(arb);          // planes <- c + 2
+        LOADA4(arb, CL(c + 4));
+        LOADB3(CL(c + 3));
+        __syncthreads();
+    }
+    const int co0 = ct * 128 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long long row = p0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = co0 + j * 32;
+            if (row < M && co < Cout) y[row * y_ld + co] = acc[j][r];
+        }
+    }
+}
+
 // the f32 MFMA chain for comparison of the error only (one wave per 32 x 32 outputs, operands from global memory)
 __global__ __launch_bounds__(64) void gemm_f32_chain(const float *__restrict__ x, int K, long long x_ld, const float *__restrict__ W, float *__restrict__ y,
                                                      long long y_ld)
@@ -407,7 +617,7 @@ int main(int argc, char **argv)
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
-        const int NV = 13;
+        const int NV = 16;
         double best[NV], med[NV][5];
         for (int v = 0; v < NV; ++v) best[v] = 1e30;
         auto launch = [&](int var) {
@@ -420,6 +630,9 @@ int main(int argc, char **argv)
             case 4: LV(4); break;
             case 5: LV(5); break;
             case 6: LV(6); break;
+            case 13: hipLaunchKernelGGL((gemm_split3<3>), dim3(grid), dim3(256), 0, 0, dx, M, K, (long long)K, dp, N, dy, (long long)N, nct); break;
+            case 14: hipLaunchKernelGGL((gemm_split3<2>), dim3(grid), dim3(256), 0, 0, dx, M, K, (long long)K, dp, N, dy, (long long)N, nct); break;
+            case 15: hipLaunchKernelGGL(gemm_split4, dim3(grid), dim3(256), 0, 0, dx, M, K, (long long)K, dp, N, dy, (long long)N, nct); break;
             case 9: LV(10); break;
             case 10: LV(11); break;
             case 11: LV(12); break;
@@ -445,7 +658,7 @@ int main(int argc, char **argv)
                 if (ms < best[var]) best[var] = ms;
             }
         const double fl = 2.0 * M * K * N;
-        const char *names[NV] = {"baseline", "v_sub asm", "sched groups ph1", "sched groups ph1+2", "ABL no split", "ABL no frag reads", "ABL no stage", "v2 B direct, A 2-stage", "v2 + v_sub asm", "ABL no global loads", "ABL no LDS stores", "ABL no barriers", "ABL one barrier"};
+        const char *names[NV] = {"baseline", "v_sub asm", "sched groups ph1", "sched groups ph1+2", "ABL no split", "ABL no frag reads", "ABL no stage", "v2 B direct, A 2-stage", "v2 + v_sub asm", "ABL no global loads", "ABL no LDS stores", "ABL no barriers", "ABL one barrier", "v3 A direct, B 2-stage (3/CU)", "v3 (2/CU)", "v4 = v3 + A two chunks ahead"};
         for (int var = 0; var < NV; ++var) {
             double m5[5];
             for (int i = 0; i < 5; ++i) m5[i] = med[var][i];
@@ -453,7 +666,7 @@ int main(int argc, char **argv)
             printf("%-28s K %5d N %5d  %-20s min %8.1f med %8.1f us  %7.1f TFLOP/s f32-eq (%.0f bf16 issued)\n", s.what, K, N, names[var], best[var] * 1e3,
                    m5[2] * 1e3, fl / m5[2] / 1e9, 6 * fl / m5[2] / 1e9);
         }
-        launch(7);   // the error check below reads v2's output
+        launch(15);   // the error check below reads v4's output
         // error against float64 on the first 1024 rows, next to the f32 MFMA chain's
         hipLaunchKernelGGL(gemm_f32_chain, dim3(32, N / 32), dim3(64), 0, 0, dx, K, (long long)K, dw, dy32, (long long)N);
         std::vector<float> gy((size_t)1024 * N), gy32((size_t)1024 * N);
