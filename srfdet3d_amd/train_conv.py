@@ -168,9 +168,9 @@ def bn_eval(bn, y):
 
 def bn_train_input(bn, y):
     """What a BatchNorm in TRAINING mode may be handed.  MIOpen's training batch-norm dies with a host segmentation fault on a
-    channels-last tensor of batch size 1 -- (1, 128, 23, 23) with strides (67712, 1, 2944, 128); the same tensor at batch size 2, the
-    same shape NCHW-contiguous and eval mode are all fine (tools/bn_channels_last_probe.py, every case in its own process;
-    profiles/r04_bn_channels_last_probe.txt).  That was the round-3 crash: a bs = 1 LiDAR-only training step whose BEV FPN extras
+    channels-last tensor of batch size 1 with a 23 x 23 map -- (1, 128, 23, 23) with strides (67712, 1, 2944, 128), also (1, 64, 23, 23),
+    forward alone included; 24 x 24 and 46 x 46 at batch size 1, the same tensor at batch size 2, the same shape NCHW-contiguous and eval
+    mode are all fine (tools/bn_channels_last_probe.py, every case in its own process; profiles/r04_bn_channels_last_probe.txt).  That was the round-3 crash: a bs = 1 LiDAR-only training step whose BEV FPN extras
     (stride-2 Conv2d -> BatchNorm2d in train mode) received channels-last tensors from `_Wino43Conv`.  Guarded here, at the one
     place every module-path BatchNorm goes through: a non-contiguous 4-D GPU tensor is made NCHW-contiguous before a train-mode
     BatchNorm sees it (any batch size: the trigger is a library bug, not something to steer around case by case).  Eval-mode

@@ -264,7 +264,7 @@ def test_training_depthwise_and_1x1_routes_match_autograd(dev):
 
 def test_train_mode_batchnorm_never_sees_a_channels_last_tensor(dev):
     """ADVICE r3 / the round-3 crash: MIOpen's TRAINING batch-norm segfaults (host side) on a channels-last tensor of batch size 1
-    (tools/bn_channels_last_probe.py: (1, 128, 23, 23) crashes, batch size 2 / NCHW / eval mode do not).  The guard sits where every
+    (tools/bn_channels_last_probe.py: (1, 128, 23, 23) and (1, 64, 23, 23) crash; 24 x 24 / 46 x 46, batch size 2, NCHW, eval mode do not).  The guard sits where every
     module-path BatchNorm passes (`train_conv.bn_train_input`, used by ConvModule, run_sequential and conv_bn_act): the exact
     failing chain -- channels-last input, 3x3 ConvModule with BN in train mode, two stride-2 ConvModules with BN in train mode, batch
     size 1 -- runs forward and backward and matches the same modules on an NCHW-contiguous input."""
