@@ -59,6 +59,10 @@ size_t srf_bitmap_workspace_bytes(size_t words);
  * sorted_indices[r] = its coordinate (both optional, pass NULL for rows that are already sorted) */
 int srf_bitmap_build(const int *indices, int A, const int *shape, int batch, void *bitmap, int *prefix, int *order,
                      int *sorted_indices, void *workspace, size_t workspace_bytes, srf_stream_t stream);
+/* the same for a capacity-sized set with padding rows: the slots of `order` / `sorted_indices` past the live count are written as
+ * 0 / (-1,-1,-1,-1) by the call itself (same launch as the bitmap clear), so the caller passes uninitialised buffers */
+int srf_bitmap_build_padded(const int *indices, int A, const int *shape, int batch, void *bitmap, int *prefix, int *order,
+                            int *sorted_indices, void *workspace, size_t workspace_bytes, srf_stream_t stream);
 int srf_bitmap_rulebook_subm(const int *sorted_indices, int A, const int *shape, int batch, const int *ksize,
                              const void *bitmap, const int *prefix, int *nbr /* K x A */, int *pair_counts /* K */,
                              srf_stream_t stream);
@@ -67,6 +71,10 @@ int srf_bitmap_rulebook_subm(const int *sorted_indices, int A, const int *shape,
 int srf_bitmap_strided_outputs(const int *indices, int A, const int *shape, int batch, const int *ksize, const int *stride,
                                const int *pad, void *out_bitmap, int *out_prefix, int *out_indices, int out_capacity,
                                int *num_out, void *workspace, size_t workspace_bytes, srf_stream_t stream);
+/* fixed-shape form: ALL out_capacity rows of out_indices are written, those past *num_out as (-1,-1,-1,-1) */
+int srf_bitmap_strided_outputs_static(const int *indices, int A, const int *shape, int batch, const int *ksize, const int *stride,
+                                      const int *pad, void *out_bitmap, int *out_prefix, int *out_indices, int out_capacity,
+                                      int *num_out, void *workspace, size_t workspace_bytes, srf_stream_t stream);
 /* phase 2: nbr (K rows of nbr_stride ints) from the INPUT level's bitmap + prefix.  The number of outputs is read on
  * the device (num_out, as written by phase 1), so this launch need not wait for the host; max_out bounds the grid (the
  * out_capacity of phase 1).  Columns >= *num_out are left untouched, or set to -1 when fill_tail != 0 (static-shape
@@ -124,6 +132,13 @@ int srf_hard_voxelize(const float *points, int n, int nf, const float *voxel_siz
                       const float *pc_range /*host[6]*/, const int *grid /*host[3]*/, int max_points, int max_voxels,
                       float *voxels, int *coors, int *num, int *voxel_num, float *mean, int mean_features,
                       void *workspace, size_t workspace_bytes, srf_stream_t stream);
+/* The fixed-shape form of K1 for a frame replayed from a hipGraph (one sample, n >= 1): ALL rows = min(n, max_voxels) rows of every
+ * output are written -- rows >= *voxel_num are padding: zeros, num 0, coordinates -1 -- and the coordinates are (rows x 4)
+ * (batch_index, z, y, x), the layout SparseEncoderCustom takes (the F.pad of srfdet.py:228-229 folded in). */
+int srf_hard_voxelize_static(const float *points, int n, int nf, const float *voxel_size /*host[3]*/,
+                             const float *pc_range /*host[6]*/, const int *grid /*host[3]*/, int max_points, int max_voxels,
+                             float *voxels, int *coors4, int *num, int *voxel_num, float *mean, int mean_features, int batch_index,
+                             void *workspace, size_t workspace_bytes, srf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K3  DynamicScatter, split in its two halves so that a caller can reuse the point->voxel map.
@@ -500,6 +515,22 @@ int srf_nhwc_upsample_add(const float *lat, long long l_ld, const float *top, lo
                           int C, float *y, long long y_ld, srf_stream_t stream);
 int srf_nhwc_dwconv3x3s2(const float *x, long long x_ld, int N, int H, int W, int C, const float *w, const float *scale,
                          const float *shift, int relu, float *y, long long y_ld, srf_stream_t stream);
+/* The proposal generator (srfdet_head.py:496-561) without its ~35 small torch launches:
+ * srf_nhwc_dwconv3x3s2_cat: one step of the stair (:525-536), x = cat([level, conv(x)], 1): the convolution writes `y` and the
+ *   pyramid level `side` (N, Ho, Wo, Cs) is copied to `side_out`, both slices of one concat buffer (row stride y_ld).
+ * srf_nhwc_pool_sum: out[b][yo * Wo + xo] = sum over the n_cam images of sample b and the C channels of x at the `nearest`
+ *   source pixel of (yo, xo) (F.interpolate to (Ho, Wo) + the camera sum + the channel sum, :537 / :548-552; Ho = H, Wo = W,
+ *   n_cam = 1 for the BEV pyramid); out rows have out_ld >= Ho * Wo floats, the tail zero-filled (K padding of fc1).
+ * srf_dpg_mix: softmax over the E experts of the logits wl (B, E * P) (with wi: of (wl + wi) / 2), the expert-weighted sums of
+ *   the proposal boxes (E * P, D) and features (E * P, C), and the sigmoid of the box centres (:957) -> boxes (B, P, D),
+ *   feats (B, P, C). */
+int srf_nhwc_dwconv3x3s2_cat(const float *x, long long x_ld, int N, int H, int W, int C, const float *w, const float *scale,
+                             const float *shift, int relu, float *y, long long y_ld, const float *side, long long side_ld, int Cs,
+                             float *side_out, srf_stream_t stream);
+int srf_nhwc_pool_sum(const float *x, long long x_ld, int B, int n_cam, int H, int W, int C, int Ho, int Wo, float *out, int out_ld,
+                      srf_stream_t stream);
+int srf_dpg_mix(const float *wl, const float *wi /*or NULL*/, int B, int E, int P, const float *boxes_w, int D, const float *feats_w,
+                int C, float *boxes, float *feats, srf_stream_t stream);
 
 /* srf_stage_tail: the row-local remainder of a stage in one launch (srfdet_head.py:1506-1520): FFN + residual + norm3,
  * classification tower + class_logits, regression tower + bboxes_delta + apply_deltas.  obj_in (R x C) is norm2's
@@ -518,6 +549,12 @@ int srf_stage_tail(const float *obj_in, int R, int C, int F, const float *w1, co
                    float *obj_out, float *logits, float *pred, void *workspace, size_t workspace_bytes, srf_stream_t stream);
 int srf_apply_deltas(const float *deltas, const float *boxes, int R, int Dd, const float *weights6 /*host[6]*/,
                      const float *pc_range /*host[6]*/, float scale_clamp, float *out, srf_stream_t stream);
+/* srf_decode_boxes: the tensors the reference hands to box3d_multiclass_nms (srfdet_head.py:1246-1271, after the
+ * centres-to-metres step that ends `forward`, :1002-1006) from the last stage's outputs in one launch: logits (R, ncls) ->
+ * scores = sigmoid; pred (R, Dd) [centres normalised to pc_range, log sizes, sin, cos, (vx, vy)] -> boxes (R, Dd - 1)
+ * [x, y, bottom-centre z in metres, w, l, h, yaw, (vx, vy)]. */
+int srf_decode_boxes(const float *logits, const float *pred, int R, int ncls, int Dd, const float *pc_range /*host[6]*/,
+                     float *scores, float *boxes, srf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K8  rotated BEV NMS.
@@ -527,6 +564,9 @@ int srf_apply_deltas(const float *deltas, const float *boxes, int R, int Dd, con
  * ------------------------------------------------------------------------------------------------------- */
 /* K9 pairwise rotated BEV IoU (n x m), boxes (cx, cy, w, h, angle): mmcv box_iou_rotated under mmdet3d
  * BboxOverlaps3D, used by OTAssignerSRFDet (mmdet3d_plugin/core/bbox/assigners/ota_srfdet.py:148-150). */
+/* srf_host_pack: the one vector a frame's host side reads back -- packed detections a (na floats), [survivors, candidates] b (nb ints),
+ * live row counts of the sparse levels c (nc ints) -> out (na + nb + nc floats; the integers are < 2^24, exact).  One launch. */
+int srf_host_pack(const float *a, int na, const int *b, int nb, const int *c, int nc, float *out, srf_stream_t stream);
 int srf_box_iou_rotated(const float *boxes_a, int n, const float *boxes_b, int m, float *iou, srf_stream_t stream);
 size_t srf_nms_rotated_workspace_bytes(int n);
 int srf_nms_rotated(const float *boxes, int n, float iou_threshold, int *keep, void *workspace, size_t workspace_bytes,

@@ -39,6 +39,8 @@ SIGNATURES = {
     "srf_hard_voxelize_workspace_bytes": (c_size_t, [c_int, c_int]),
     "srf_hard_voxelize": (c_int, [_P, c_int, c_int, _HF, _HF, _HI, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P,
                                   c_size_t, _P]),
+    "srf_hard_voxelize_static": (c_int, [_P, c_int, c_int, _HF, _HF, _HI, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P,
+                                         c_size_t, _P]),
     "srf_voxel_unique_workspace_bytes": (c_size_t, [c_int, _HI, c_int]),
     "srf_voxel_unique": (c_int, [_P, c_int, _HI, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "srf_scatter_reduce": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
@@ -75,8 +77,10 @@ SIGNATURES = {
     "srf_bitmap_pair_count_ints": (c_size_t, []),
     "srf_bitmap_workspace_bytes": (c_size_t, [c_size_t]),
     "srf_bitmap_build": (c_int, [_P, c_int, _HI, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "srf_bitmap_build_padded": (c_int, [_P, c_int, _HI, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "srf_bitmap_rulebook_subm": (c_int, [_P, c_int, _HI, c_int, _HI, _P, _P, _P, _P, _P]),
     "srf_bitmap_strided_outputs": (c_int, [_P, c_int, _HI, c_int, _HI, _HI, _HI, _P, _P, _P, c_int, _P, _P, c_size_t, _P]),
+    "srf_bitmap_strided_outputs_static": (c_int, [_P, c_int, _HI, c_int, _HI, _HI, _HI, _P, _P, _P, c_int, _P, _P, c_size_t, _P]),
     "srf_bitmap_strided_pairs": (c_int, [_P, _P, c_int, _HI, c_int, _HI, _HI, _HI, _P, _P, c_int, _P, c_int, c_int, _P, _P]),
     "srf_upsample_add": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "srf_maxpool3s2_ceil": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
@@ -129,11 +133,17 @@ SIGNATURES = {
     "srf_nhwc_maxpool3s2_ceil": (c_int, [_P, c_longlong, c_int, c_int, c_int, c_int, _P, c_longlong, _P]),
     "srf_nhwc_upsample_add": (c_int, [_P, c_longlong, _P, c_longlong, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_longlong, _P]),
     "srf_nhwc_dwconv3x3s2": (c_int, [_P, c_longlong, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_longlong, _P]),
+    "srf_nhwc_dwconv3x3s2_cat": (c_int, [_P, c_longlong, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_longlong, _P, c_longlong,
+                                         c_int, _P, _P]),
+    "srf_nhwc_pool_sum": (c_int, [_P, c_longlong, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "srf_dpg_mix": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, _P]),
     "srf_stage_tail": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_float, c_int, POINTER(c_void_p), POINTER(c_void_p),
                                POINTER(c_void_p), _HF, c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), _HF, _P, _P,
                                c_int, _P, _P, c_int, _P, _HF, _HF, c_float, _P, _P, _P, _P, c_size_t, _P]),
     "srf_stage_tail_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "srf_apply_deltas": (c_int, [_P, _P, c_int, c_int, _HF, _HF, c_float, _P, _P]),
+    "srf_host_pack": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, _P]),
+    "srf_decode_boxes": (c_int, [_P, _P, c_int, c_int, c_int, _HF, _P, _P, _P]),
     "srf_nms_rotated_workspace_bytes": (c_size_t, [c_int]),
     "srf_nms_rotated": (c_int, [_P, c_int, c_float, _P, _P, c_size_t, _P]),
     "srf_nms_rotated_counted": (c_int, [_P, c_int, _P, c_float, _P, _P, c_size_t, _P]),

@@ -89,6 +89,43 @@ static inline hipError_t srf_fill_bytes(void *ptr, int byte, size_t nbytes, hipS
     return hipGetLastError();
 }
 
+// Up to four word regions, each with its own value, in ONE launch (a frame replayed from a hipGraph pays ~5 us per launch
+// whatever its size: the bitmap clear of a sparse level and the -1 fill of its row list are one node this way).
+struct SrfFillRegions {
+    uint32_t *ptr[4];
+    uint32_t value[4];
+    size_t nwords[4];
+};
+
+static __global__ __launch_bounds__(256) void srf_fill_regions_k(SrfFillRegions r)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t *p = r.ptr[j];
+        const uint32_t v = r.value[j];
+        const size_t n = r.nwords[j];
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = v;
+    }
+}
+
+// regions with a null pointer or zero length are skipped; pointers must be 4-byte aligned
+static inline hipError_t srf_fill_regions(const SrfFillRegions &regions, hipStream_t st)
+{
+    SrfFillRegions r = regions;
+    size_t most = 0;
+    for (int j = 0; j < 4; ++j) {
+        if (!r.ptr[j]) r.nwords[j] = 0;
+        if ((uintptr_t)r.ptr[j] & 3) return hipErrorInvalidValue;
+        most = r.nwords[j] > most ? r.nwords[j] : most;
+    }
+    if (most == 0) return hipSuccess;
+    size_t blocks = (most + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(srf_fill_regions_k, dim3((unsigned)blocks), dim3(256), 0, st, r);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave / block scans (256-thread blocks)
 // ---------------------------------------------------------------------------------------------
@@ -198,11 +235,67 @@ __global__ __launch_bounds__(SRF_SCAN_THREADS) void srf_scan_apply_k(int n, ValF
     }
 }
 
+// The same scan as ONE launch of one 1024-thread workgroup, for inputs of at most SRF_SCAN_SINGLE_MAX elements (the bitmaps of
+// the coarse sparse levels: 2-45 k words; the points of a sweep): the three-launch form costs ~15 us there whatever the size
+// (three dependent graph nodes), this one 5-9 us.  Element i belongs to thread (i / ITEMS) % 1024 of round i / (1024 * ITEMS),
+// as in srf_scan_apply_k: identical prefixes, identical out() calls.
+#define SRF_SCAN_SINGLE_THREADS 1024
+#define SRF_SCAN_SINGLE_MAX (8 * SRF_SCAN_SINGLE_THREADS * SRF_SCAN_ITEMS)
+
+template <class ValF, class OutF>
+__global__ __launch_bounds__(SRF_SCAN_SINGLE_THREADS) void srf_scan_single_k(int n, ValF val, OutF out, int *__restrict__ partial_total,
+                                                                           int *__restrict__ total_out, int clamp_max)
+{
+    __shared__ int s_w[SRF_SCAN_SINGLE_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int carry = 0;
+    for (int base0 = 0; base0 < n; base0 += SRF_SCAN_SINGLE_THREADS * SRF_SCAN_ITEMS) {  // uniform trip count
+        const int base = base0 + threadIdx.x * SRF_SCAN_ITEMS;
+        int v[SRF_SCAN_ITEMS];
+        int s = 0;
+#pragma unroll
+        for (int j = 0; j < SRF_SCAN_ITEMS; ++j) {
+            const int i = base + j;
+            v[j] = i < n ? val(i) : 0;
+            s += v[j];
+        }
+        const int inc = srf_wave_inclusive_scan(s);
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        int before = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < SRF_SCAN_SINGLE_THREADS / 64; ++w) {
+            const int c = s_w[w];
+            before += w < wave ? c : 0;
+            tot += c;
+        }
+        __syncthreads();
+        int ex = carry + before + inc - s;
+#pragma unroll
+        for (int j = 0; j < SRF_SCAN_ITEMS; ++j) {
+            const int i = base + j;
+            if (i < n) out(i, v[j], ex);
+            ex += v[j];
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        *partial_total = carry;
+        if (total_out) *total_out = (clamp_max >= 0 && carry > clamp_max) ? clamp_max : carry;
+    }
+}
+
 template <class ValF, class OutF>
 static inline int srf_device_scan(int n, ValF val, OutF out, int *partial, int *total_out, int clamp_max,
                                   hipStream_t st)
 {
     const int nb = srf_scan_blocks(n);
+    if (n <= SRF_SCAN_SINGLE_MAX) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_scan_single_k<ValF, OutF>), dim3(1), dim3(SRF_SCAN_SINGLE_THREADS), 0, st, n, val, out,
+                           partial + nb, total_out, clamp_max);
+        SRF_LAUNCH_CHECK();
+        return SRF_OK;
+    }
     hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_scan_reduce_k<ValF>), dim3(nb), dim3(SRF_SCAN_THREADS), 0, st, n, val, partial);
     hipLaunchKernelGGL(srf_scan_partials_k, dim3(1), dim3(256), 0, st, nb, partial, total_out, clamp_max);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_scan_apply_k<ValF, OutF>), dim3(nb), dim3(SRF_SCAN_THREADS), 0, st, n, val,

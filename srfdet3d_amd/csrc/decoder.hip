@@ -1283,3 +1283,106 @@ extern "C" int srf_apply_deltas(const float *deltas, const float *boxes, int R, 
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// srf_decode_boxes (srfdet_head.py:1246-1271, the tensors handed to box3d_multiclass_nms): last-stage logits (R, ncls) and
+// boxes (R, Dd) [centres normalised to the range, log sizes, sin, cos, (vx, vy)] -> scores = sigmoid(logits) and boxes
+// (R, Dd - 1) [centres in metres with bottom-centre z, sizes, yaw, (vx, vy)] in ONE launch: the tail of `forward`
+// (centres * extent + lo), torch.sigmoid, denormalize_bbox (exp, atan2, cat) and the z shift are 12 launches of ~5 us as
+// torch ops.  Same operations in the same order (multiply, then add; h * 0.5 subtracted).
+// ---------------------------------------------------------------------------------------------------------------------
+struct DecodeGeom {
+    float lo[3], ext[3];
+};
+
+__global__ __launch_bounds__(128) void srf_decode_boxes_k(const float *__restrict__ logits, const float *__restrict__ pred, int R,
+                                                        int ncls, int Dd, DecodeGeom g, float *__restrict__ scores,
+                                                        float *__restrict__ boxes)
+{
+    const int r = blockIdx.x * 128 + threadIdx.x;
+    if (r >= R) return;
+    const float *lg = logits + (size_t)r * ncls;
+    float *sc = scores + (size_t)r * ncls;
+    for (int c = 0; c < ncls; ++c) sc[c] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-lg[c])));
+    const float *p = pred + (size_t)r * Dd;
+    float *o = boxes + (size_t)r * (Dd - 1);
+    const float h = expf(p[5]);
+    o[0] = __fadd_rn(__fmul_rn(p[0], g.ext[0]), g.lo[0]);
+    o[1] = __fadd_rn(__fmul_rn(p[1], g.ext[1]), g.lo[1]);
+    o[2] = __fsub_rn(__fadd_rn(__fmul_rn(p[2], g.ext[2]), g.lo[2]), __fmul_rn(h, 0.5f));
+    o[3] = expf(p[3]);
+    o[4] = expf(p[4]);
+    o[5] = h;
+    o[6] = atan2f(p[6], p[7]);
+    for (int i = 8; i < Dd; ++i) o[i - 1] = p[i];
+}
+
+extern "C" int srf_decode_boxes(const float *logits, const float *pred, int R, int ncls, int Dd, const float *pc_range,
+                                float *scores, float *boxes, srf_stream_t stream)
+{
+    if (R < 0 || ncls <= 0 || Dd < 8 || !pc_range) return SRF_EINVAL;
+    if (R == 0) return SRF_OK;
+    if (!logits || !pred || !scores || !boxes) return SRF_EINVAL;
+    DecodeGeom g;
+    for (int i = 0; i < 3; ++i) {
+        g.lo[i] = pc_range[i];
+        g.ext[i] = pc_range[3 + i] - pc_range[i];
+    }
+    hipLaunchKernelGGL(srf_decode_boxes_k, dim3(srf_ceil_div(R, 128)), dim3(128), 0, (hipStream_t)stream, logits, pred, R, ncls, Dd, g,
+                       scores, boxes);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// srf_dpg_mix: the end of the dynamic proposal generator (srfdet_head.py:514-523 / :553-561) and the sigmoid `forward` puts on
+// the proposal centres (:957): expert logits wl (+ wi of the camera half: their mean) (B, E, P) -> softmax over the E experts
+// -> boxes[b][p] = sum_e w[b][e][p] * boxes_w[e * P + p] (D columns, the first three through a sigmoid) and
+// feats[b][p] = sum_e w * feats_w[e * P + p] (C columns): one launch for softmax, two multiplies, two sums, the sigmoid and
+// its slice copy.  E <= 16; the sums run e = 0 .. E - 1.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void srf_dpg_mix_k(const float *__restrict__ wl, const float *__restrict__ wi, int E, int P,
+                                                   const float *__restrict__ boxes_w, int D, const float *__restrict__ feats_w, int C,
+                                                   float *__restrict__ boxes, float *__restrict__ feats)
+{
+    const int b = blockIdx.y, p = blockIdx.x;
+    float w[16];
+    float mx = -INFINITY;
+    for (int e = 0; e < E; ++e) {
+        float v = wl[((size_t)b * E + e) * P + p];
+        if (wi) v = __fdiv_rn(__fadd_rn(v, wi[((size_t)b * E + e) * P + p]), 2.0f);
+        w[e] = v;
+        mx = fmaxf(mx, v);
+    }
+    float sum = 0.0f;
+    for (int e = 0; e < E; ++e) {
+        w[e] = expf(__fsub_rn(w[e], mx));
+        sum = __fadd_rn(sum, w[e]);
+    }
+    for (int e = 0; e < E; ++e) w[e] = __fdiv_rn(w[e], sum);
+    for (int c = threadIdx.x; c < C + D; c += 128) {
+        const bool is_box = c >= C;
+        const int col = is_box ? c - C : c;
+        const float *src = is_box ? boxes_w : feats_w;
+        const int ld = is_box ? D : C;
+        float acc = 0.0f;
+        for (int e = 0; e < E; ++e) acc = __fadd_rn(acc, __fmul_rn(w[e], src[((size_t)e * P + p) * ld + col]));
+        if (is_box) {
+            if (col < 3) acc = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-acc)));
+            boxes[((size_t)b * P + p) * D + col] = acc;
+        } else {
+            feats[((size_t)b * P + p) * C + col] = acc;
+        }
+    }
+}
+
+extern "C" int srf_dpg_mix(const float *wl, const float *wi, int B, int E, int P, const float *boxes_w, int D, const float *feats_w, int C,
+                           float *boxes, float *feats, srf_stream_t stream)
+{
+    if (B < 0 || E <= 0 || E > 16 || P <= 0 || D < 3 || C <= 0) return SRF_EINVAL;
+    if (B == 0) return SRF_OK;
+    if (!wl || !boxes_w || !feats_w || !boxes || !feats) return SRF_EINVAL;
+    hipLaunchKernelGGL(srf_dpg_mix_k, dim3(P, B), dim3(128), 0, (hipStream_t)stream, wl, wi, E, P, boxes_w, D, feats_w, C, boxes, feats);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}

@@ -219,15 +219,24 @@ extern "C" int srf_nhwc_upsample_add(const float *lat, long long l_ld, const flo
 // Depthwise 3x3 / stride 2 / padding 1 convolution + eval BatchNorm (+ ReLU), channels-last: the stair of the proposal
 // generator on the camera levels.  Taps summed in (ky, kx) order like srf_dwconv3x3s2_k; weights w (C, 3, 3).
 // ---------------------------------------------------------------------------------------------------------------------
+// `side` (N, Ho, Wo, Csq * 4) is copied next to the result (srf_nhwc_dwconv3x3s2_cat): the threads past the convolution's own
+// channel quads move one float4 each.
 __global__ __launch_bounds__(256) void srf_nhwc_dwconv3x3s2_k(const float *__restrict__ x, long long x_ld, int N, int H, int W, int Cq, int Ho,
                                                               int Wo, const float *__restrict__ w, const float *__restrict__ scale,
-                                                              const float *__restrict__ shift, int relu, float *__restrict__ y, long long y_ld)
+                                                              const float *__restrict__ shift, int relu, float *__restrict__ y, long long y_ld,
+                                                              const float *__restrict__ side, long long side_ld, int Csq,
+                                                              float *__restrict__ side_out)
 {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)N * Ho * Wo * Cq;
+    const int Ct = Cq + Csq;
+    const long long total = (long long)N * Ho * Wo * Ct;
     if (t >= total) return;
-    const int cq = (int)(t % Cq);
-    long long r = t / Cq;
+    const int cq = (int)(t % Ct);
+    long long r = t / Ct;
+    if (cq >= Cq) {  // r = (n, yo, xo) linearised = the pixel row of both `side` and the output buffer
+        *reinterpret_cast<f32x4n *>(side_out + r * y_ld + (cq - Cq) * 4) = *reinterpret_cast<const f32x4n *>(side + r * side_ld + (cq - Cq) * 4);
+        return;
+    }
     const int xo = (int)(r % Wo);
     r /= Wo;
     const int yo = (int)(r % Ho), n = (int)(r / Ho);
@@ -271,7 +280,77 @@ extern "C" int srf_nhwc_dwconv3x3s2(const float *x, long long x_ld, int N, int H
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long total = (long long)N * Ho * Wo * (C / 4);
     hipLaunchKernelGGL(srf_nhwc_dwconv3x3s2_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld, N, H, W, C / 4, Ho, Wo,
-                       w, scale, shift, relu, y, y_ld);
+                       w, scale, shift, relu, y, y_ld, (const float *)nullptr, 0LL, 0, (float *)nullptr);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// The step of the proposal generator's stair (srfdet_head.py:525-536: x = conv(x); x = cat([level, x], 1)) as one launch:
+// the depthwise convolution writes `y` and the pyramid level `side` (N, Ho, Wo, Cs) is copied to `side_out`; both outputs
+// are slices of the same concat buffer (row stride y_ld).
+extern "C" int srf_nhwc_dwconv3x3s2_cat(const float *x, long long x_ld, int N, int H, int W, int C, const float *w, const float *scale,
+                                        const float *shift, int relu, float *y, long long y_ld, const float *side, long long side_ld,
+                                        int Cs, float *side_out, srf_stream_t stream)
+{
+    if (N < 0 || H < 1 || W < 1 || C <= 0 || Cs <= 0 || x_ld < C || y_ld < C + Cs || side_ld < Cs) return SRF_EINVAL;
+    if (N == 0) return SRF_OK;
+    if (!x || !w || !y || !side || !side_out) return SRF_EINVAL;
+    if ((C & 3) || (Cs & 3) || (x_ld & 3) || (y_ld & 3) || (side_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) ||
+        ((uintptr_t)side & 15) || ((uintptr_t)side_out & 15))
+        return SRF_EUNSUPPORTED;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo * ((C + Cs) / 4);
+    hipLaunchKernelGGL(srf_nhwc_dwconv3x3s2_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld, N, H, W, C / 4, Ho, Wo,
+                       w, scale, shift, relu, y, y_ld, side, side_ld, Cs / 4, side_out);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// srf_nhwc_pool_sum: the reduction between the stair and fc1 of the proposal generator (srfdet_head.py:537 for the BEV
+// pyramid; :548-552 for the cameras: F.interpolate(nearest) to (Ho, Wo), sum over the cameras, sum over the channels):
+//   out[b][p] = sum over cam < n_cam, c < C of x[b * n_cam + cam][sy(p)][sx(p)][c],   p = yo * Wo + xo,
+// sy / sx the `nearest` source index of torch (floor(dst * in / out) in float32, clamped); Ho = H, Wo = W, n_cam = 1 is the
+// plain channel sum.  One wave per output: lanes take float4 strides over (cam, c), then an xor-shuffle tree -- a fixed
+// order.  Row b of `out` has out_ld >= Ho * Wo floats; the columns past Ho * Wo are written as zeros (the K padding of fc1).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void srf_nhwc_pool_sum_k(const float *__restrict__ x, long long x_ld, int B, int n_cam, int H, int W, int Cq,
+                                                         int Ho, int Wo, float sy_scale, float sx_scale, float *__restrict__ out, int out_ld)
+{
+    const int lane = threadIdx.x & 63;
+    const long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= (long long)B * out_ld) return;
+    const int b = (int)(o / out_ld), p = (int)(o % out_ld);
+    if (p >= Ho * Wo) {
+        if (lane == 0) out[o] = 0.0f;
+        return;
+    }
+    const int yo = p / Wo, xo = p - yo * Wo;
+    int sy = Ho == H ? yo : (int)floorf(__fmul_rn((float)yo, sy_scale));
+    int sx = Wo == W ? xo : (int)floorf(__fmul_rn((float)xo, sx_scale));
+    sy = sy < H - 1 ? sy : H - 1;
+    sx = sx < W - 1 ? sx : W - 1;
+    float acc = 0.0f;
+    for (int e = lane; e < n_cam * Cq; e += 64) {
+        const int cam = e / Cq, cq = e - cam * Cq;
+        const f32x4n v = *reinterpret_cast<const f32x4n *>(x + ((((long long)b * n_cam + cam) * H + sy) * W + sx) * x_ld + cq * 4);
+        acc = __fadd_rn(acc, __fadd_rn(__fadd_rn(v[0], v[1]), __fadd_rn(v[2], v[3])));
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc = __fadd_rn(acc, __shfl_xor(acc, d, 64));
+    if (lane == 0) out[o] = acc;
+}
+
+extern "C" int srf_nhwc_pool_sum(const float *x, long long x_ld, int B, int n_cam, int H, int W, int C, int Ho, int Wo, float *out, int out_ld,
+                                 srf_stream_t stream)
+{
+    if (B < 0 || n_cam <= 0 || H < 1 || W < 1 || C <= 0 || Ho < 1 || Wo < 1 || x_ld < C || out_ld < Ho * Wo) return SRF_EINVAL;
+    if (B == 0) return SRF_OK;
+    if (!x || !out) return SRF_EINVAL;
+    if ((C & 3) || (x_ld & 3) || ((uintptr_t)x & 15)) return SRF_EUNSUPPORTED;
+    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;  // torch: compute_scales_value<float>(input / output)
+    hipLaunchKernelGGL(srf_nhwc_pool_sum_k, dim3(srf_ceil_div((long long)B * out_ld, 4)), dim3(256), 0, (hipStream_t)stream, x, x_ld, B, n_cam,
+                       H, W, C / 4, Ho, Wo, sy, sx, out, out_ld);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

@@ -259,6 +259,56 @@ __device__ void srf_sel_sort(float *key, int *idx, int P, bool descending)
     }
 }
 
+// exclusive scan of one flag per thread over the workgroup (thread order), and the workgroup's total
+__device__ __forceinline__ int srf_sel_scan(int v, int *s_w, int &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SRF_SEL_THREADS / 64; ++w) {
+        const int c = s_w[w];
+        base += w < wave ? c : 0;
+        tot += c;
+    }
+    total = tot;
+    __syncthreads();
+    return base + x - v;
+}
+
+// Rank sort of the m <= SRF_SEL_THREADS (key, index) pairs at the front of the LDS arrays into the order srf_sel_before defines: every
+// thread counts the entries that come before its own (broadcast reads), then all write their pair to its rank -- two barriers,
+// against the 66 barrier-separated passes a bitonic sort of 2048 pairs takes.
+__device__ __forceinline__ void srf_sel_rank_sort(float *key, int *idx, int m, bool descending)
+{
+    const int tid = threadIdx.x;
+    float k = 0.f;
+    int ix = 0, rank = 0;
+    if (tid < m) {
+        k = key[tid];
+        ix = idx[tid];
+        for (int j = 0; j < m; ++j) rank += srf_sel_before(key[j], idx[j], k, ix, descending) ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid < m) {
+        key[rank] = k;
+        idx[rank] = ix;
+    }
+    __syncthreads();
+}
+
+// Both kernels below first split their entries by a flag (above the score threshold / kept by the NMS) in ONE pass -- flagged
+// entries compacted to the front of the LDS arrays in flat order, the others to the back in reverse -- and sort only the
+// flagged ones: the unflagged entries all carry the same key, so their order in the result is their flat order, which the
+// compaction already is.  A frame has a few hundred flagged pairs among 2000-9000; with at most SRF_SEL_THREADS of them the sort
+// is the rank sort above, otherwise the full bitonic sort over all P entries (same result by construction: one total order).
 __global__ __launch_bounds__(SRF_SEL_THREADS) void srf_nms_select_k(const float *__restrict__ boxes, const float *__restrict__ scores,
                                                                   int n, int C, int D, float score_thr, int L, int P,
                                                                   float *__restrict__ cand, float *__restrict__ top_s,
@@ -268,35 +318,54 @@ __global__ __launch_bounds__(SRF_SEL_THREADS) void srf_nms_select_k(const float 
     extern __shared__ __attribute__((aligned(16))) unsigned char sel_lds[];
     float *key = reinterpret_cast<float *>(sel_lds);
     int *idx = reinterpret_cast<int *>(key + P);
-    __shared__ int s_cnt[SRF_SEL_THREADS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_w[SRF_SEL_THREADS / 64];
+    const int tid = threadIdx.x;
     const int total = n * C;
-    int cnt = 0;
-    for (int t = tid; t < P; t += SRF_SEL_THREADS) {
-        float k = -2.0f;  // padding of the power-of-two array: behind every real entry
+    int m = 0;
+    for (int c0 = 0; c0 < P; c0 += SRF_SEL_THREADS) {  // P is a multiple of the workgroup or below it: uniform trip count
+        const int t = c0 + tid;
+        float s = 0.f;
+        bool valid = false;
         if (t < total) {
-            const float s = scores[t];
-            const bool valid = s > score_thr;
-            k = valid ? s : -1.0f;
-            cnt += valid ? 1 : 0;
+            s = scores[t];
+            valid = s > score_thr;
         }
-        key[t] = k;
-        idx[t] = t;
+        int tot;
+        const int ex = srf_sel_scan(valid ? 1 : 0, s_w, tot);
+        if (valid) {
+            key[m + ex] = s;
+            idx[m + ex] = t;
+        } else if (t < total) {
+            idx[P - 1 - (t - (m + ex))] = t;  // rank among the pairs at or below the threshold, from the back
+        }
+        m += tot;
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
-    if (lane == 0) s_cnt[wave] = cnt;
+    if (tid == 0) *m_out = m;
     __syncthreads();
-    cnt = 0;
-    for (int w = 0; w < SRF_SEL_THREADS / 64; ++w) cnt += s_cnt[w];
-    if (tid == 0) *m_out = cnt;
-    srf_sel_sort(key, idx, P, true);
+    const bool compact = m <= SRF_SEL_THREADS;
+    if (compact) {
+        srf_sel_rank_sort(key, idx, m, true);
+    } else {
+        __syncthreads();
+        for (int t = tid; t < P; t += SRF_SEL_THREADS) {
+            float k = -2.0f;  // padding of the power-of-two array: behind every real entry
+            if (t < total) {
+                const float s = scores[t];
+                k = s > score_thr ? s : -1.0f;
+            }
+            key[t] = k;
+            idx[t] = t;
+        }
+        __syncthreads();
+        srf_sel_sort(key, idx, P, true);
+    }
     for (int j = tid; j < L; j += SRF_SEL_THREADS) {
-        const int flat = idx[j];
+        const bool front = !compact || j < m;
+        const int flat = front ? idx[j] : idx[P - 1 - (j - m)];
         const int bi = flat / C, ci = flat - bi * C;
         const float *p = boxes + (size_t)bi * D;
         for (int c = 0; c < D; ++c) cand[(size_t)j * D + c] = p[c];
-        top_s[j] = key[j];
+        top_s[j] = front ? key[j] : -1.0f;
         cls[j] = ci;
         float *o = bev + (size_t)j * 5;
         o[0] = p[0];
@@ -317,37 +386,52 @@ __global__ __launch_bounds__(SRF_SEL_THREADS) void srf_nms_finish_k(const float 
     extern __shared__ __attribute__((aligned(16))) unsigned char sel_lds[];
     float *key = reinterpret_cast<float *>(sel_lds);
     int *idx = reinterpret_cast<int *>(key + P);
-    __shared__ int s_cnt[SRF_SEL_THREADS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int cnt = 0;
-    for (int t = tid; t < P; t += SRF_SEL_THREADS) {
-        float k = 2.0e9f;  // padding: behind everything
-        if (t < L) {
-            const bool kp = keep[t] != 0;
+    __shared__ int s_w[SRF_SEL_THREADS / 64];
+    const int tid = threadIdx.x;
+    int kept = 0;
+    for (int c0 = 0; c0 < P; c0 += SRF_SEL_THREADS) {
+        const int t = c0 + tid;
+        const bool kp = t < L && keep[t] != 0;
+        int tot;
+        const int ex = srf_sel_scan(kp ? 1 : 0, s_w, tot);
+        if (kp) {
             float s = top_s[t];
             s = s < 0.f ? 0.f : (s > 1.f ? 1.f : s);
-            k = kp ? __fsub_rn(__fmul_rn((float)cls[t], 4.0f), __fmul_rn(s, 2.0f)) : 1.0e9f;
-            cnt += kp ? 1 : 0;
+            key[kept + ex] = __fsub_rn(__fmul_rn((float)cls[t], 4.0f), __fmul_rn(s, 2.0f));
+            idx[kept + ex] = t;
+        } else if (t < L) {
+            idx[P - 1 - (t - (kept + ex))] = t;
         }
-        key[t] = k;
-        idx[t] = t;
+        kept += tot;
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
-    if (lane == 0) s_cnt[wave] = cnt;
-    __syncthreads();
     if (tid == 0) {
-        int c = 0;
-        for (int w = 0; w < SRF_SEL_THREADS / 64; ++w) c += s_cnt[w];
-        *kept_out = c;
+        *kept_out = kept;
         if (counts) {
-            counts[0] = c;
+            counts[0] = kept;
             counts[1] = *m_in;
         }
     }
-    srf_sel_sort(key, idx, P, false);
+    __syncthreads();
+    const bool compact = kept <= SRF_SEL_THREADS;
+    if (compact) {
+        srf_sel_rank_sort(key, idx, kept, false);
+    } else {
+        __syncthreads();
+        for (int t = tid; t < P; t += SRF_SEL_THREADS) {
+            float k = 2.0e9f;  // padding: behind everything
+            if (t < L) {
+                float s = top_s[t];
+                s = s < 0.f ? 0.f : (s > 1.f ? 1.f : s);
+                k = keep[t] != 0 ? __fsub_rn(__fmul_rn((float)cls[t], 4.0f), __fmul_rn(s, 2.0f)) : 1.0e9f;
+            }
+            key[t] = k;
+            idx[t] = t;
+        }
+        __syncthreads();
+        srf_sel_sort(key, idx, P, false);
+    }
     for (int j = tid; j < L; j += SRF_SEL_THREADS) {
-        const int src = idx[j];
+        const int src = (!compact || j < kept) ? idx[j] : idx[P - 1 - (j - kept)];
         for (int c = 0; c < D; ++c) out_boxes[(size_t)j * D + c] = cand[(size_t)src * D + c];
         out_scores[j] = top_s[src];
         out_labels[j] = cls[src];
@@ -402,6 +486,32 @@ extern "C" int srf_nms_finish(const float *cand, const float *top_s, const long 
     const int P = srf_sel_pow2(L);
     hipLaunchKernelGGL(srf_nms_finish_k, dim3(1), dim3(SRF_SEL_THREADS), (size_t)P * 8, (hipStream_t)stream, cand, top_s, cls, keep, L, D, P,
                        out_boxes, out_scores, out_labels, kept_out, packed, m, counts);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// srf_host_pack: everything the host reads back from a frame as ONE float32 vector, in one launch: the packed detections `a`
+// (na floats), the [survivors, candidates] counts `b` (nb ints) and the live row counts of the sparse levels `c` (nc ints);
+// the integers are below 2^24 and exact as floats.  (As torch ops: two dtype conversions and a cat.)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void srf_host_pack_k(const float *__restrict__ a, int na, const int *__restrict__ b, int nb,
+                                                     const int *__restrict__ c, int nc, float *__restrict__ out)
+{
+    const int stride = gridDim.x * 256;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < na + nb + nc; i += stride)
+        out[i] = i < na ? a[i] : (i < na + nb ? (float)b[i - na] : (float)c[i - na - nb]);
+}
+
+extern "C" int srf_host_pack(const float *a, int na, const int *b, int nb, const int *c, int nc, float *out, srf_stream_t stream)
+{
+    if (na < 0 || nb < 0 || nc < 0 || (na && !a) || (nb && !b) || (nc && !c)) return SRF_EINVAL;
+    const int n = na + nb + nc;
+    if (n == 0) return SRF_OK;
+    if (!out) return SRF_EINVAL;
+    int blocks = srf_ceil_div(n, 256);
+    blocks = blocks > 1024 ? 1024 : blocks;
+    hipLaunchKernelGGL(srf_host_pack_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, c, nc, out);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

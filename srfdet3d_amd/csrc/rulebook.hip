@@ -540,8 +540,8 @@ extern "C" size_t srf_bitmap_words(const int *shape, int batch)
 
 extern "C" size_t srf_bitmap_workspace_bytes(size_t words) { return (size_t)(srf_scan_blocks((long long)words) + 1) * sizeof(int); }
 
-extern "C" int srf_bitmap_build(const int *indices, int A, const int *shape, int batch, void *bitmap, int *prefix, int *order,
-                                int *sorted_indices, void *workspace, size_t workspace_bytes, srf_stream_t stream)
+static int srf_bitmap_build_impl(const int *indices, int A, const int *shape, int batch, void *bitmap, int *prefix, int *order,
+                                 int *sorted_indices, void *workspace, size_t workspace_bytes, srf_stream_t stream, int padded)
 {
     const size_t words = srf_bitmap_words(shape, batch);
     if (A < 0 || words == 0 || !bitmap || !prefix || !workspace) return SRF_EINVAL;
@@ -550,7 +550,13 @@ extern "C" int srf_bitmap_build(const int *indices, int A, const int *shape, int
     const int one[3] = {1, 1, 1};
     if (!srf_fill_conv_geom(g, shape, one, one, nullptr, batch)) return SRF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    SRF_HIP_TRY(srf_fill_bytes(bitmap, 0, words * 4, st));
+    SrfFillRegions fill = {};
+    fill.ptr[0] = (uint32_t *)bitmap, fill.value[0] = 0u, fill.nwords[0] = words;
+    if (padded && A > 0 && order && sorted_indices) {  // slots of padding rows: order 0, coordinates -1 (same launch as the clear)
+        fill.ptr[1] = (uint32_t *)order, fill.value[1] = 0u, fill.nwords[1] = (size_t)A;
+        fill.ptr[2] = (uint32_t *)sorted_indices, fill.value[2] = 0xFFFFFFFFu, fill.nwords[2] = (size_t)A * 4;
+    }
+    SRF_HIP_TRY(srf_fill_regions(fill, st));
     if (A > 0) {
         if (!indices) return SRF_EINVAL;
         hipLaunchKernelGGL(srf_bm_mark_k, dim3(srf_ceil_div(A, 256)), dim3(256), 0, st, (const int4 *)indices, A, g,
@@ -563,6 +569,20 @@ extern "C" int srf_bitmap_build(const int *indices, int A, const int *shape, int
                            (const uint32_t *)bitmap, prefix, order, (int4 *)sorted_indices);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
+}
+
+extern "C" int srf_bitmap_build(const int *indices, int A, const int *shape, int batch, void *bitmap, int *prefix, int *order,
+                                int *sorted_indices, void *workspace, size_t workspace_bytes, srf_stream_t stream)
+{
+    return srf_bitmap_build_impl(indices, A, shape, batch, bitmap, prefix, order, sorted_indices, workspace, workspace_bytes, stream, 0);
+}
+
+// `indices` may hold padding rows (b < 0) of a capacity-sized set: they are not marked, and their slots in `order` /
+// `sorted_indices` (the rows past the live count) are written as 0 / (-1, -1, -1, -1) by this call
+extern "C" int srf_bitmap_build_padded(const int *indices, int A, const int *shape, int batch, void *bitmap, int *prefix, int *order,
+                                       int *sorted_indices, void *workspace, size_t workspace_bytes, srf_stream_t stream)
+{
+    return srf_bitmap_build_impl(indices, A, shape, batch, bitmap, prefix, order, sorted_indices, workspace, workspace_bytes, stream, 1);
 }
 
 extern "C" int srf_bitmap_rulebook_subm(const int *sorted_indices, int A, const int *shape, int batch, const int *ksize,
@@ -584,10 +604,10 @@ extern "C" int srf_bitmap_rulebook_subm(const int *sorted_indices, int A, const 
     return SRF_OK;
 }
 
-extern "C" int srf_bitmap_strided_outputs(const int *indices, int A, const int *shape, int batch, const int *ksize,
-                                          const int *stride, const int *pad, void *out_bitmap, int *out_prefix, int *out_indices,
-                                          int out_capacity, int *num_out, void *workspace, size_t workspace_bytes,
-                                          srf_stream_t stream)
+static int srf_bitmap_strided_outputs_impl(const int *indices, int A, const int *shape, int batch, const int *ksize,
+                                           const int *stride, const int *pad, void *out_bitmap, int *out_prefix, int *out_indices,
+                                           int out_capacity, int *num_out, void *workspace, size_t workspace_bytes,
+                                           srf_stream_t stream, int fill_tail)
 {
     ConvGeom g;
     if (A < 0 || !shape || !ksize || !stride || !pad || !num_out || !out_bitmap || !out_prefix || !workspace || out_capacity < 0)
@@ -597,7 +617,11 @@ extern "C" int srf_bitmap_strided_outputs(const int *indices, int A, const int *
     if (words == 0) return SRF_EINVAL;
     if (workspace_bytes < srf_bitmap_workspace_bytes(words)) return SRF_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    SRF_HIP_TRY(srf_fill_bytes(out_bitmap, 0, words * 4, st));
+    SrfFillRegions fill = {};
+    fill.ptr[0] = (uint32_t *)out_bitmap, fill.value[0] = 0u, fill.nwords[0] = words;
+    if (fill_tail && out_indices && out_capacity > 0)  // rows past the output count stay (-1, -1, -1, -1): same launch as the clear
+        fill.ptr[1] = (uint32_t *)out_indices, fill.value[1] = 0xFFFFFFFFu, fill.nwords[1] = (size_t)out_capacity * 4;
+    SRF_HIP_TRY(srf_fill_regions(fill, st));
     if (A > 0) {
         if (!indices || !out_indices) return SRF_EINVAL;
         hipLaunchKernelGGL(srf_bm_strided_mark_k, dim3(srf_ceil_div(A, 256), g.K), dim3(256), 0, st, (const int4 *)indices, A, g,
@@ -610,6 +634,25 @@ extern "C" int srf_bitmap_strided_outputs(const int *indices, int A, const int *
                            out_prefix, (int)words, g.oshape[0], g.oshape[1], g.oshape[2], out_capacity, (int4 *)out_indices);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
+}
+
+extern "C" int srf_bitmap_strided_outputs(const int *indices, int A, const int *shape, int batch, const int *ksize,
+                                          const int *stride, const int *pad, void *out_bitmap, int *out_prefix, int *out_indices,
+                                          int out_capacity, int *num_out, void *workspace, size_t workspace_bytes,
+                                          srf_stream_t stream)
+{
+    return srf_bitmap_strided_outputs_impl(indices, A, shape, batch, ksize, stride, pad, out_bitmap, out_prefix, out_indices,
+                                           out_capacity, num_out, workspace, workspace_bytes, stream, 0);
+}
+
+// fixed-shape form: ALL out_capacity rows of out_indices are written, those past *num_out as (-1, -1, -1, -1)
+extern "C" int srf_bitmap_strided_outputs_static(const int *indices, int A, const int *shape, int batch, const int *ksize,
+                                                 const int *stride, const int *pad, void *out_bitmap, int *out_prefix,
+                                                 int *out_indices, int out_capacity, int *num_out, void *workspace,
+                                                 size_t workspace_bytes, srf_stream_t stream)
+{
+    return srf_bitmap_strided_outputs_impl(indices, A, shape, batch, ksize, stride, pad, out_bitmap, out_prefix, out_indices,
+                                           out_capacity, num_out, workspace, workspace_bytes, stream, 1);
 }
 
 extern "C" int srf_bitmap_strided_pairs(const int *out_indices, const int *num_out, int max_out, const int *shape, int batch,

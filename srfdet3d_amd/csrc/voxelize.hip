@@ -118,6 +118,7 @@ struct HvAssign {
     int *coors;
     int max_voxels;
     int gx, gy;
+    int cols, batch;  // cols = 3: (z, y, x) rows; cols = 4: (batch, z, y, x) rows (srf_hard_voxelize_static)
     __device__ void operator()(int i, int v, int prefix) const
     {
         if (!v || prefix >= max_voxels) return;
@@ -126,9 +127,11 @@ struct HvAssign {
         uint32_t key = keys[s];
         uint32_t x = key % (uint32_t)gx;
         uint32_t t = key / (uint32_t)gx;
-        coors[3 * prefix] = (int)(t / (uint32_t)gy);
-        coors[3 * prefix + 1] = (int)(t % (uint32_t)gy);
-        coors[3 * prefix + 2] = (int)x;
+        int *c = coors + (size_t)cols * prefix + (cols - 3);
+        if (cols == 4) c[-1] = batch;
+        c[0] = (int)(t / (uint32_t)gy);
+        c[1] = (int)(t % (uint32_t)gy);
+        c[2] = (int)x;
     }
 };
 
@@ -136,13 +139,22 @@ __global__ __launch_bounds__(256) void srf_hv_gather_k(const float *__restrict__
                                                      const int *__restrict__ top, const int *__restrict__ vox_slot,
                                                      const int *__restrict__ voxel_num, int rows,
                                                      float *__restrict__ voxels, int *__restrict__ num,
-                                                     float *__restrict__ mean, int mean_features)
+                                                     float *__restrict__ mean, int mean_features, int *__restrict__ pad_coors)
 {
     const int per = max_points * nf;
     const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
     const int m = (int)(tid / per);
     const int j = (int)(tid % per);
-    if (m >= rows || m >= *voxel_num) return;
+    if (m >= rows) return;
+    if (m >= *voxel_num) {
+        if (!pad_coors) return;
+        // static form: the rows past the voxel count are padding of a fixed-shape result -- zeros, no points, coordinates -1
+        voxels[(size_t)m * per + j] = 0.0f;
+        if (j < mean_features && mean) mean[(size_t)m * mean_features + j] = 0.0f;
+        if (j == per - 1) num[m] = 0;
+        if (j == 0) pad_coors[(size_t)m * 4] = pad_coors[(size_t)m * 4 + 1] = pad_coors[(size_t)m * 4 + 2] = pad_coors[(size_t)m * 4 + 3] = -1;
+        return;
+    }
     const int *lst = top + (size_t)vox_slot[m] * max_points;
     const int s = j / nf, c = j % nf;
     int idx = lst[s];
@@ -209,10 +221,10 @@ extern "C" size_t srf_hard_voxelize_workspace_bytes(int n, int max_points)
     return b;
 }
 
-extern "C" int srf_hard_voxelize(const float *points, int n, int nf, const float *vs, const float *range,
-                                 const int *grid, int max_points, int max_voxels, float *voxels, int *coors, int *num,
-                                 int *voxel_num, float *mean, int mean_features, void *workspace,
-                                 size_t workspace_bytes, srf_stream_t stream)
+static int srf_hard_voxelize_impl(const float *points, int n, int nf, const float *vs, const float *range,
+                                  const int *grid, int max_points, int max_voxels, float *voxels, int *coors, int *num,
+                                  int *voxel_num, float *mean, int mean_features, void *workspace,
+                                  size_t workspace_bytes, srf_stream_t stream, int coor_cols, int batch_index)
 {
     if (n < 0 || nf < 3 || nf > 64 || max_points <= 0 || max_points > 64 || max_voxels <= 0 || !vs || !range ||
         !grid || !voxel_num)
@@ -242,23 +254,48 @@ extern "C" int srf_hard_voxelize(const float *points, int n, int nf, const float
     w += srf_align256((size_t)n * 4);
     int *partial = (int *)w;
 
-    SRF_HIP_TRY(srf_fill_bytes(keys, 0xFF, srf_align256(cap * 4), st));
-    // minidx and top are adjacent: one fill with the 0x7F7F7F7F sentinel
-    SRF_HIP_TRY(srf_fill_bytes(minidx, 0x7F, srf_align256(cap * 4) + srf_align256(cap * (size_t)max_points * 4), st));
+    // the table keys (0xFFFFFFFF = empty) and, adjacent to each other, minidx and top (0x7F7F7F7F sentinel): one launch
+    SrfFillRegions fill = {};
+    fill.ptr[0] = keys, fill.value[0] = 0xFFFFFFFFu, fill.nwords[0] = srf_align256(cap * 4) / 4;
+    fill.ptr[1] = (uint32_t *)minidx, fill.value[1] = 0x7F7F7F7Fu;
+    fill.nwords[1] = (srf_align256(cap * 4) + srf_align256(cap * (size_t)max_points * 4)) / 4;
+    SRF_HIP_TRY(srf_fill_regions(fill, st));
 
     hipLaunchKernelGGL(srf_hv_insert_k, dim3(srf_ceil_div(n, 256)), dim3(256), 256 * nf * sizeof(float), st, points, n,
                        nf, g, max_points, keys, (uint32_t)(cap - 1), minidx, top, pslot);
     SRF_LAUNCH_CHECK();
 
     HvFlag flag{pslot, minidx};
-    HvAssign assign{pslot, keys, vox_slot, coors, max_voxels, grid[0], grid[1]};
+    HvAssign assign{pslot, keys, vox_slot, coors, max_voxels, grid[0], grid[1], coor_cols, batch_index};
     int rc = srf_device_scan(n, flag, assign, partial, voxel_num, max_voxels, st);
     if (rc) return rc;
 
     const int rows = n < max_voxels ? n : max_voxels;
     const long long threads = (long long)rows * max_points * nf;
     hipLaunchKernelGGL(srf_hv_gather_k, dim3(srf_ceil_div(threads, 256)), dim3(256), 0, st, points, nf, max_points, top,
-                       vox_slot, voxel_num, rows, voxels, num, mean, mean ? mean_features : 0);
+                       vox_slot, voxel_num, rows, voxels, num, mean, mean ? mean_features : 0, coor_cols == 4 ? coors : (int *)nullptr);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
+}
+
+extern "C" int srf_hard_voxelize(const float *points, int n, int nf, const float *vs, const float *range,
+                                 const int *grid, int max_points, int max_voxels, float *voxels, int *coors, int *num,
+                                 int *voxel_num, float *mean, int mean_features, void *workspace,
+                                 size_t workspace_bytes, srf_stream_t stream)
+{
+    return srf_hard_voxelize_impl(points, n, nf, vs, range, grid, max_points, max_voxels, voxels, coors, num, voxel_num, mean,
+                                  mean_features, workspace, workspace_bytes, stream, 3, 0);
+}
+
+// The fixed-shape form a hipGraph replays: ALL min(n, max_voxels) rows of the outputs are written -- rows past the voxel
+// count are padding (zeros, num 0, coordinates -1) -- and the coordinates come as (batch_index, z, y, x) rows, the layout the
+// sparse encoder takes; the caller needs no fills before and no batch-column arithmetic after (10 small launches per frame).
+extern "C" int srf_hard_voxelize_static(const float *points, int n, int nf, const float *vs, const float *range,
+                                        const int *grid, int max_points, int max_voxels, float *voxels, int *coors4, int *num,
+                                        int *voxel_num, float *mean, int mean_features, int batch_index, void *workspace,
+                                        size_t workspace_bytes, srf_stream_t stream)
+{
+    if (n <= 0) return SRF_EINVAL;  // a fixed-shape result has at least one row
+    return srf_hard_voxelize_impl(points, n, nf, vs, range, grid, max_points, max_voxels, voxels, coors4, num, voxel_num, mean,
+                                  mean_features, workspace, workspace_bytes, stream, 4, batch_index);
 }

@@ -116,16 +116,19 @@ def run_sequential(seq, x):
     return x
 
 
-def linear_graph_safe(lin, x):
+def linear_graph_safe(lin, x, relu=False, act=None):
     """nn.Linear for inference on the GPU through this library's f32-MFMA GEMM (ops.linear) instead of rocBLAS / hipBLASLt.
 
     Why: for skinny problems (the DPG layers have M = batch size) the BLAS libraries pick split-K kernels that accumulate
     with atomics into an output they clear first; captured into a hipGraph such a layer returned correct values on the first
     replay and different ones from the second on (found on `dpg_fc1_img`, 900 -> 1500 at M = 1; round 1 blamed the memset node,
     tools/micro/graph_memset.hip shows memset nodes do take effect -- the cause inside the library is not established).
-    ops.linear is one ordered fma chain per output and clears nothing.  K is zero-padded to a multiple of 4 (cached) when needed."""
+    ops.linear is one ordered fma chain per output and clears nothing.  K is zero-padded to a multiple of 4 (cached) when needed; an
+    `x` that already has the padded width (ops.nhwc_pool_sum writes it so) is taken as is.  relu: ReLU in the GEMM's epilogue (the
+    module `act` is applied instead where the layer runs on torch)."""
     if not (fusable(x) and x.dim() == 2 and lin.weight.is_cuda):
-        return lin(x)
+        y = lin(x[:, :lin.in_features])
+        return (act(y) if act is not None else torch.relu(y)) if relu else y
     K = lin.in_features
     w = lin.weight
     if K % 4:
@@ -138,5 +141,6 @@ def linear_graph_safe(lin, x):
             cache = (vers, wp)
             lin._srf_padded = cache
         w = cache[1]
-        x = torch.nn.functional.pad(x, (0, w.shape[1] - K))
-    return ops.linear(x.contiguous(), w, lin.bias)
+        if x.shape[1] != w.shape[1]:
+            x = torch.nn.functional.pad(x, (0, w.shape[1] - K))
+    return ops.linear(x.contiguous(), w, lin.bias, relu1=bool(relu))

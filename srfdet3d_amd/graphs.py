@@ -115,8 +115,7 @@ class GraphedTail:
         x = m.pts_backbone(bev)
         if m.pts_neck is not None:
             x = m.pts_neck(x)
-        logits, boxes = m.bbox_head(img_feats, x, img_metas)
-        scores, dec = m.bbox_head.decode(logits, boxes)
+        scores, dec = m.bbox_head.forward_decode(img_feats, x, img_metas)
         sel = m.bbox_head.select_static(scores, dec) if getattr(m.bbox_head, "use_nms", False) else None
         return scores, dec, sel
 
@@ -320,7 +319,8 @@ class GraphedFrame:
                 host_pack = self._host_pack(sel, counts[0]) if sel is not None else None
             _validate(head_graph, [scores, boxes], ref[:2], "whole-frame graph (decoder half)")
         self.stats["captures"] += 1
-        self.entry = dict(graph=graph, head_graph=head_graph, pts=static_pts, far=far, n_cap=n_cap, nf=pts.shape[1], caps=caps,
+        self.entry = dict(graph=graph, head_graph=head_graph, pts=static_pts, far=far, live=pts.shape[0], n_cap=n_cap, nf=pts.shape[1],
+                          caps=caps,
                           scores=scores, boxes=boxes, counts=counts[0], limits=counts[1], sel=sel, metas=sm, bev=x, host_pack=host_pack,
                           img_key=None if img_feats is None else tuple(f.data_ptr() for f in img_feats))
         return self.entry
@@ -337,8 +337,7 @@ class GraphedFrame:
 
     def _run_head(self, x, img_metas, img_feats=None, dpg_lidar=None):
         m = self.model
-        logits, boxes = m.bbox_head(img_feats, x, img_metas) if dpg_lidar is None else m.bbox_head(img_feats, x, img_metas, dpg_lidar)
-        scores, dec = m.bbox_head.decode(logits, boxes)
+        scores, dec = m.bbox_head.forward_decode(img_feats, x, img_metas, dpg_lidar)
         sel = m.bbox_head.select_static(scores, dec) if getattr(m.bbox_head, "use_nms", False) else None
         return scores, dec, sel
 
@@ -347,7 +346,8 @@ class GraphedFrame:
         """Everything the host needs from a frame in ONE float32 vector (one device -> host copy, one synchronisation instead
         of three): the packed detections, [survivors, candidates] per sample and the live row counts of the sparse levels
         (integers below 2^24, exact as floats)."""
-        return torch.cat([sel[0].reshape(-1), sel[1].reshape(-1).to(torch.float32), dev_counts.to(torch.float32)])
+        from . import ops
+        return ops.host_pack(sel[0], sel[1], dev_counts)
 
     def _eager(self, pts, img_metas, img_feats=None):
         m = self.model
@@ -356,8 +356,7 @@ class GraphedFrame:
         x = m.pts_backbone(bev)
         if m.pts_neck is not None:
             x = m.pts_neck(x)
-        logits, boxes = m.bbox_head(img_feats, x, img_metas)
-        scores, dec = m.bbox_head.decode(logits, boxes)
+        scores, dec = m.bbox_head.forward_decode(img_feats, x, img_metas)
         return scores, dec, sizes
 
     def __call__(self, pts, img_metas, img_feats=None, img_done=None):
@@ -378,8 +377,9 @@ class GraphedFrame:
             return scores, dec, None
         n = pts.shape[0]
         e["pts"][:n].copy_(pts)
-        if n < e["n_cap"]:
-            e["pts"][n:].copy_(e["far"][n:])
+        if n < e["live"]:   # rows the previous frame filled and this one does not: back to the out-of-range filler
+            e["pts"][n:e["live"]].copy_(e["far"][n:e["live"]])
+        e["live"] = n
         e["graph"].replay()
         if img_done is not None:
             cur.wait_event(img_done)   # the join: the camera graph ran beside the BEV half

@@ -99,33 +99,33 @@ def image_prepare(images_u8, mean, std, to_rgb=False, size_divisor=32, size=None
     return out
 
 
-def hard_voxelize(points, voxel_size, pc_range, max_points, max_voxels, mean_features=0, static=False):
+def hard_voxelize(points, voxel_size, pc_range, max_points, max_voxels, mean_features=0, static=False, batch_index=0):
     """-> voxels (M,max_points,nf), coors (M,3) zyx, num (M,), mean (M,mean_features) or None.  One D2H sync for M.
-    static=True: no sync; all min(n, max_voxels) rows are returned, rows >= M being padding (coors -1, num 0, zeros),
-    followed by the device scalar M -- the fixed-shape form a hipGraph can replay."""
+    static=True: no sync; all min(n, max_voxels) rows are returned, rows >= M being padding (coors -1, num 0, zeros), the coordinates
+    as (rows, 4) (batch_index, z, y, x), followed by the device scalar M -- the fixed-shape form a hipGraph can replay
+    (srf_hard_voxelize_static: the padding is written by the gather kernel itself, no fills and no batch-column ops around it)."""
     points = _dev(points, "points", torch.float32)
     n, nf = points.shape
     L = _lib.lib()
     dev = points.device
     rows = max(min(n, max_voxels), 1)
-    if static:
-        voxels = torch.zeros((rows, max_points, nf), dtype=torch.float32, device=dev)
-        coors = torch.full((rows, 3), -1, dtype=torch.int32, device=dev)
-        num = torch.zeros((rows,), dtype=torch.int32, device=dev)
-        mean = torch.zeros((rows, mean_features), dtype=torch.float32, device=dev) if mean_features else None
-    else:
-        voxels = _empty((rows, max_points, nf), torch.float32, dev)
-        coors = _empty((rows, 3), torch.int32, dev)
-        num = _empty((rows,), torch.int32, dev)
-        mean = _empty((rows, mean_features), torch.float32, dev) if mean_features else None
+    voxels = _empty((rows, max_points, nf), torch.float32, dev)
+    coors = _empty((rows, 4 if static else 3), torch.int32, dev)
+    num = _empty((rows,), torch.int32, dev)
+    mean = _empty((rows, mean_features), torch.float32, dev) if mean_features else None
     vnum = _empty((1,), torch.int32, dev)
     ws_bytes = L.srf_hard_voxelize_workspace_bytes(n, max_points)
     ws = _empty((max(ws_bytes, 1),), torch.uint8, dev)
+    if static:
+        if n < 1:
+            raise ValueError("hard_voxelize(static=True) needs at least one point row")
+        check(L.srf_hard_voxelize_static(_ptr(points), n, nf, hf(voxel_size), hf(pc_range), hi(grid_size(voxel_size, pc_range)),
+                                         max_points, max_voxels, _ptr(voxels), _ptr(coors), _ptr(num), _ptr(vnum), _ptr(mean),
+                                         mean_features, int(batch_index), _ptr(ws), ws_bytes, _stream()), "hard_voxelize_static")
+        return voxels, coors, num, mean, vnum
     check(L.srf_hard_voxelize(_ptr(points), n, nf, hf(voxel_size), hf(pc_range), hi(grid_size(voxel_size, pc_range)),
                               max_points, max_voxels, _ptr(voxels), _ptr(coors), _ptr(num), _ptr(vnum), _ptr(mean),
                               mean_features, _ptr(ws), ws_bytes, _stream()), "hard_voxelize")
-    if static:
-        return voxels, coors, num, mean, vnum
     M = int(vnum.item())
     return voxels[:M], coors[:M], num[:M], (mean[:M] if mean is not None else None)
 
@@ -279,15 +279,13 @@ def bitmap_build(indices, spatial_shape, batch, want_order=True, padded=False):
     A = indices.shape[0]
     order = sorted_idx = None
     if want_order:
-        if padded:  # rows with b < 0 are padding: their sorted slots stay (-1,-1,-1,-1) and point at row 0
-            order = torch.zeros((max(A, 1),), dtype=torch.int32, device=indices.device)
-            sorted_idx = torch.full((max(A, 1), 4), -1, dtype=torch.int32, device=indices.device)
-        else:
-            order = _empty((max(A, 1),), torch.int32, indices.device)
-            sorted_idx = _empty((max(A, 1), 4), torch.int32, indices.device)
+        # padded: rows with b < 0 are padding: their sorted slots become (-1,-1,-1,-1) and point at row 0 (written by the call)
+        order = _empty((max(A, 1),), torch.int32, indices.device)
+        sorted_idx = _empty((max(A, 1), 4), torch.int32, indices.device)
     ws, nbytes = lvl.workspace()
-    check(_lib.lib().srf_bitmap_build(_ptr(indices), A, hi(lvl.shape), lvl.batch, _ptr(lvl.bitmap), _ptr(lvl.prefix), _ptr(order),
-                                      _ptr(sorted_idx), _ptr(ws), nbytes, _stream()), "bitmap_build")
+    build = _lib.lib().srf_bitmap_build_padded if padded and want_order else _lib.lib().srf_bitmap_build
+    check(build(_ptr(indices), A, hi(lvl.shape), lvl.batch, _ptr(lvl.bitmap), _ptr(lvl.prefix), _ptr(order), _ptr(sorted_idx), _ptr(ws),
+                nbytes, _stream()), "bitmap_build")
     if not want_order:
         return lvl, None, None
     return lvl, order[:A], sorted_idx[:A]
@@ -324,10 +322,11 @@ def rulebook_strided_bitmap(indices, level, ksize, stride, pad, out_capacity=Non
     oshape = out_spatial_shape(level.shape, ksize, stride, pad)
     out_lvl = BitmapLevel(oshape, level.batch, dev)
     cap = max(bound, 1)
-    out_idx = torch.full((cap, 4), -1, dtype=torch.int32, device=dev) if static else _empty((cap, 4), torch.int32, dev)
+    out_idx = _empty((cap, 4), torch.int32, dev)   # static: the rows past the count are written as -1 by the call
     num_out = _empty((1,), torch.int32, dev)
     ws, nbytes = out_lvl.workspace()
-    check(L.srf_bitmap_strided_outputs(_ptr(indices), A, hi(level.shape), level.batch, hi(ksize), hi(stride), hi(pad),
+    outputs = L.srf_bitmap_strided_outputs_static if static else L.srf_bitmap_strided_outputs
+    check(outputs(_ptr(indices), A, hi(level.shape), level.batch, hi(ksize), hi(stride), hi(pad),
                                        _ptr(out_lvl.bitmap), _ptr(out_lvl.prefix), _ptr(out_idx), bound, _ptr(num_out), _ptr(ws),
                                        nbytes, _stream()), "bitmap_strided_outputs")
     # phase 2 reads the count on the device: it is enqueued before the host learns A_out, so the read-back below
@@ -778,6 +777,30 @@ def apply_deltas(deltas, boxes, weights6, pc_range, scale_clamp):
     check(_lib.lib().srf_apply_deltas(_ptr(deltas), _ptr(boxes), R, Dd, hf(weights6), hf(pc_range), float(scale_clamp),
                                       _ptr(out), _stream()), "apply_deltas")
     return out
+
+
+def host_pack(packed, counts, level_counts):
+    """float32 vector [packed.flatten(), counts, level_counts] (the ints converted; all < 2^24) in one launch."""
+    a = _dev(packed, "packed", torch.float32)
+    b = _dev(counts, "counts", torch.int32)
+    c = _dev(level_counts, "level_counts", torch.int32)
+    out = _empty((a.numel() + b.numel() + c.numel(),), torch.float32, a.device)
+    check(_lib.lib().srf_host_pack(_ptr(a), a.numel(), _ptr(b), b.numel(), _ptr(c), c.numel(), _ptr(out), _stream()), "host_pack")
+    return out
+
+
+def decode_boxes(logits, pred, pc_range):
+    """last-stage logits (..., ncls) and boxes (..., Dd) with normalised centres -> (scores, boxes (..., Dd - 1) in metres with
+    bottom-centre z): the end of `forward` + SRFDetHead.decode (srfdet_head.py:1002-1006, :1246-1271) as one launch."""
+    logits = _dev(logits, "logits", torch.float32)
+    pred = _dev(pred, "pred", torch.float32)
+    lead, ncls, Dd = logits.shape[:-1], logits.shape[-1], pred.shape[-1]
+    R = int(np.prod(lead)) if len(lead) else 1
+    scores = _empty((*lead, ncls), torch.float32, logits.device)
+    boxes = _empty((*lead, Dd - 1), torch.float32, logits.device)
+    check(_lib.lib().srf_decode_boxes(_ptr(logits), _ptr(pred), R, ncls, Dd, hf(pc_range), _ptr(scores), _ptr(boxes), _stream()),
+          "decode_boxes")
+    return scores, boxes
 
 
 def upsample_add_supported(lateral, top):
@@ -1283,6 +1306,50 @@ def nhwc_dwconv3x3s2(x, weight, scale=None, shift=None, relu=False, out=None):
     check(_lib.lib().srf_nhwc_dwconv3x3s2(_ptr(x), x_ld, N, H, W, C, _ptr(w), _opt(scale, "scale"), _opt(shift, "shift"),
                                           int(bool(relu)), _ptr(out), nhwc_ld(out), _stream()), "nhwc_dwconv3x3s2")
     return out
+
+
+def nhwc_dwconv3x3s2_cat(x, weight, scale, shift, relu, side, out):
+    """One step of the proposal generator's stair: out (N, Ho, Wo, Cs + C) = cat([side, dwconv(x)], -1) in one launch."""
+    x_ld = nhwc_ld(x)
+    N, H, W, C = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Cs = side.shape[3]
+    if tuple(side.shape[:3]) != (N, Ho, Wo) or tuple(out.shape) != (N, Ho, Wo, Cs + C):
+        raise ValueError("nhwc_dwconv3x3s2_cat: side / out have the wrong shape")
+    w = _dev(weight.reshape(C, 9), "weight", torch.float32)
+    check(_lib.lib().srf_nhwc_dwconv3x3s2_cat(_ptr(x), x_ld, N, H, W, C, _ptr(w), _opt(scale, "scale"), _opt(shift, "shift"),
+                                              int(bool(relu)), _ptr(out[..., Cs:]), nhwc_ld(out), _ptr(side), nhwc_ld(side), Cs,
+                                              _ptr(out), _stream()), "nhwc_dwconv3x3s2_cat")
+    return out
+
+
+def nhwc_pool_sum(x, n_cam=1, size=None, pad_to=4):
+    """x (B * n_cam, H, W, C) channels-last -> (B, pad(Ho * Wo)): per output pixel the sum over cameras and channels at its `nearest`
+    source pixel (size = (Ho, Wo); None: the map itself); columns past Ho * Wo are zeros (row length rounded up to pad_to)."""
+    x_ld = nhwc_ld(x)
+    Nimg, H, W, C = x.shape
+    B = Nimg // n_cam
+    Ho, Wo = (H, W) if size is None else (int(size[0]), int(size[1]))
+    out_ld = -(-(Ho * Wo) // pad_to) * pad_to
+    out = _empty((B, out_ld), torch.float32, x.device)
+    check(_lib.lib().srf_nhwc_pool_sum(_ptr(x), x_ld, B, n_cam, H, W, C, Ho, Wo, _ptr(out), out_ld, _stream()), "nhwc_pool_sum")
+    return out
+
+
+def dpg_mix(wl, wi, boxes_w, feats_w, E, P):
+    """expert logits (B, E * P) (+ the camera half's) -> proposal boxes (B, P, D) with sigmoid centres, features (B, P, C)."""
+    wl = _dev(wl, "wl", torch.float32)
+    wi = _dev(wi, "wi", torch.float32) if wi is not None else None
+    boxes_w = _dev(boxes_w, "boxes_w", torch.float32)
+    feats_w = _dev(feats_w, "feats_w", torch.float32)
+    B, D, C = wl.shape[0], boxes_w.shape[1], feats_w.shape[1]
+    if wl.shape[1] != E * P or boxes_w.shape[0] != E * P or feats_w.shape[0] != E * P or (wi is not None and wi.shape != wl.shape):
+        raise ValueError("dpg_mix: shapes disagree")
+    boxes = _empty((B, P, D), torch.float32, wl.device)
+    feats = _empty((B, P, C), torch.float32, wl.device)
+    check(_lib.lib().srf_dpg_mix(_ptr(wl), _ptr(wi), B, E, P, _ptr(boxes_w), D, _ptr(feats_w), C, _ptr(boxes), _ptr(feats), _stream()),
+          "dpg_mix")
+    return boxes, feats
 
 
 def pack_conv_gemm_weights(weight):

@@ -218,10 +218,8 @@ class SRFDet(BaseModule):
                 max_voxels = points.shape[0]
             voxels, coors, num, mean, vnum = ops.hard_voxelize(points, vl.voxel_size, vl.point_cloud_range, vl.max_num_points,
                                                                max_voxels, vl.fused_mean_features, static=True)
-            if mean is not None:
+            if mean is not None:                    # coors: (rows, 4) (0, z, y, x); padding rows -1
                 voxels.srf_vfe_mean = mean
-            batch = torch.where(coors[:, :1] < 0, -1, 0).to(coors.dtype)  # padding rows keep b = -1
-            coors = torch.cat([batch, coors], dim=1)
             voxel_features = self.pts_voxel_encoder(voxels, num, coors)
             rows = voxels.shape[0]
         else:  # dynamic voxelization + DynamicVFECustom: the scatter maps run at a fixed voxel capacity

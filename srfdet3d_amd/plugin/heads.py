@@ -480,8 +480,7 @@ class SRFDetHead(BaseModule):
         MIOpen resolves these depthwise convs to its naive reference kernel (34 ms on the 6 x 128 x 232 x 400 image
         level, measured), so it is kept away from the stair: in inference ConvModule hands them to srf_dwconv3x3s2
         (conv + BN + ReLU in one streaming kernel), otherwise torch's own depthwise kernel runs (0.2 ms)."""
-        if nhwc.enabled() and all(fusable(f) and nhwc.is_channels_last(f) and f.shape[1] % 4 == 0 for f in feats) \
-                and all(SRFDetHead._dw_ok(c) for c in convs):
+        if SRFDetHead._stair_fusable(convs, feats):
             return SRFDetHead._stair_nhwc(convs, feats)
         with torch.backends.cudnn.flags(enabled=not feats[0].is_cuda):
             x = convs[0](feats[0])
@@ -499,24 +498,28 @@ class SRFDetHead(BaseModule):
                 and _foldable(getattr(cm, cm.norm_name)) and cm.with_activation and isinstance(cm.activate, nn.ReLU))
 
     @staticmethod
-    def _stair_nhwc(convs, feats):
+    def _stair_nhwc(convs, feats, as_nhwc=False):
         """The same stair on channels-last levels: each depthwise conv + BN + ReLU writes its slice of the next level's
-        concat buffer, the level itself is copied into slice 0 (torch.cat([feats[lvl], x], 1) of srfdet_head.py:531)."""
+        concat buffer and copies the level itself into slice 0 in the same launch (torch.cat([feats[lvl], x], 1) of
+        srfdet_head.py:531)."""
         x = nhwc.nhwc_view(feats[0])
         for lvl in range(1, len(feats)):
             f = nhwc.nhwc_view(feats[lvl])
             cm = convs[lvl - 1]
             c_lvl, c_x = f.shape[3], x.shape[3]
             buf = torch.empty((*f.shape[:3], c_lvl + c_x), dtype=torch.float32, device=f.device)
-            buf[..., :c_lvl].copy_(f)
             scale, shift = _fold_bn2d(getattr(cm, cm.norm_name))
-            ops.nhwc_dwconv3x3s2(x, cm.conv.weight, scale, shift, True, out=buf[..., c_lvl:])
-            x = buf
+            x = ops.nhwc_dwconv3x3s2_cat(x, cm.conv.weight, scale, shift, True, f, buf)
             if lvl == len(feats) - 1 and lvl < len(convs):
                 cm = convs[lvl]
                 scale, shift = _fold_bn2d(getattr(cm, cm.norm_name))
                 x = ops.nhwc_dwconv3x3s2(x, cm.conv.weight, scale, shift, True)
-        return nhwc.nchw_view(x)
+        return x if as_nhwc else nhwc.nchw_view(x)
+
+    @staticmethod
+    def _stair_fusable(convs, feats):
+        return (nhwc.enabled() and all(fusable(f) and nhwc.is_channels_last(f) and f.shape[1] % 4 == 0 for f in feats)
+                and all(SRFDetHead._dw_ok(c) for c in convs))
 
     @staticmethod
     def _channel_sum(x):
@@ -531,10 +534,28 @@ class SRFDetHead(BaseModule):
     def dpg_lidar_logits(self, point_feats):
         """The LiDAR half of the dynamic proposal generator (srfdet_head.py:506-512 of `_get_init_proposals`): depthwise stair over the
         BEV pyramid -> channel sum -> fc1 -> ReLU -> fc2, (bs, E * P).  It needs no image feature, so the LC frame computes it in the
-        BEV-half graph, beside the camera graph, and hands it to `forward` (`precomputed_dpg_lidar`) instead of running its ~14
-        small launches on the serial tail after the join."""
-        w = self._channel_sum(self._stair(self.dpg_dw_convs_lidar, point_feats[:self.lidar_feat_lvls]))
-        return linear_graph_safe(self.dpg_fc2_lidar, self.dpg_act_lidar(linear_graph_safe(self.dpg_fc1_lidar, w)))
+        BEV-half graph, beside the camera graph, and hands it to `forward` (`precomputed_dpg_lidar`) instead of running its
+        small launches on the serial tail after the join.  Inference on channels-last GPU levels: 6 launches (three stair steps,
+        ops.nhwc_pool_sum, two GEMVs)."""
+        feats = point_feats[:self.lidar_feat_lvls]
+        if self._stair_fusable(self.dpg_dw_convs_lidar, feats):
+            w = ops.nhwc_pool_sum(self._stair_nhwc(self.dpg_dw_convs_lidar, feats, as_nhwc=True))
+        else:
+            w = self._channel_sum(self._stair(self.dpg_dw_convs_lidar, feats))
+        return linear_graph_safe(self.dpg_fc2_lidar, linear_graph_safe(self.dpg_fc1_lidar, w, relu=True, act=self.dpg_act_lidar))
+
+    def dpg_img_logits(self, img_feats, bs):
+        """The camera half (srfdet_head.py:541-552): stair over the camera levels, nearest resize to 30 x 30 (30 x 15 on KITTI), sum over
+        the cameras and the channels, fc1 -> ReLU -> fc2."""
+        flat = [f.reshape(f.shape[0] * f.shape[1], *f.shape[2:]) for f in img_feats[:self.img_feat_lvls]]
+        n_cam = img_feats[0].shape[1]
+        size = [30, 15] if self.is_kitti else [30, 30]
+        if self._stair_fusable(self.dpg_dw_convs_img, flat):
+            x = ops.nhwc_pool_sum(self._stair_nhwc(self.dpg_dw_convs_img, flat, as_nhwc=True), n_cam=n_cam, size=size)
+        else:
+            x = F.interpolate(self._stair(self.dpg_dw_convs_img, flat), size)
+            x = self._channel_sum(x.view(bs, n_cam, *x.shape[1:]).sum(dim=1))
+        return linear_graph_safe(self.dpg_fc2_img, linear_graph_safe(self.dpg_fc1_img, x, relu=True, act=self.dpg_act_img))
 
     def _get_init_proposals(self, img_feats, point_feats, lidar_logits=None):
         bs = point_feats[0].shape[0]
@@ -544,17 +565,25 @@ class SRFDetHead(BaseModule):
         E, P = self.num_dpg_exp, self.num_proposals
         w = (self.dpg_lidar_logits(point_feats) if lidar_logits is None else lidar_logits).reshape(bs, E, P)
         if self.use_img:
-            flat = [f.reshape(f.shape[0] * f.shape[1], *f.shape[2:]) for f in img_feats[:self.img_feat_lvls]]
-            n_cam = img_feats[0].shape[1]
-            x = self._stair(self.dpg_dw_convs_img, flat)
-            x = F.interpolate(x, [30, 15] if self.is_kitti else [30, 30])
-            x = self._channel_sum(x.view(bs, n_cam, *x.shape[1:]).sum(dim=1))
-            wi = linear_graph_safe(self.dpg_fc2_img, self.dpg_act_img(linear_graph_safe(self.dpg_fc1_img, x))).reshape(bs, E, P)
-            w = (w + wi) / 2
+            w = (w + self.dpg_img_logits(img_feats, bs).reshape(bs, E, P)) / 2
         w = w.softmax(1).unsqueeze(-1)
         boxes = (w * boxes_w.view(1, E, P, -1)).sum(1)
         feats = (w * feats_w.view(1, E, P, -1)).sum(1)
         return boxes, feats
+
+    def _stage_proposals(self, img_feats, point_feats, lidar_logits=None):
+        """`_get_init_proposals` + the sigmoid `forward` applies to the centres (srfdet_head.py:957).  GPU inference with the proposal
+        generator: softmax, both expert sums and the sigmoid are one launch (ops.dpg_mix)."""
+        if self.with_dpg and fusable(point_feats[0]):
+            bs = point_feats[0].shape[0]
+            wl = self.dpg_lidar_logits(point_feats) if lidar_logits is None else lidar_logits
+            wi = self.dpg_img_logits(img_feats, bs) if self.use_img else None
+            return ops.dpg_mix(wl.reshape(bs, -1), wi, self.init_proposal_boxes.weight, self.init_proposal_feats.weight,
+                               self.num_dpg_exp, self.num_proposals)
+        boxes, prop_feats = self._get_init_proposals(img_feats, point_feats, lidar_logits)
+        boxes = boxes.contiguous()
+        boxes[..., :3] = boxes[..., :3].sigmoid()
+        return boxes, prop_feats
 
     def _img_convs_only(self, img_feats):
         """`img_convs` (3x3, feat_channels_img -> hidden_dim, bias) on every camera level (srfdet_head.py:404-416)."""
@@ -584,12 +613,34 @@ class SRFDetHead(BaseModule):
     def forward(self, img_feats, point_feats, img_metas, precomputed_dpg_lidar=None):
         """-> logits (#stage, bs, n_p, #cls), boxes (#stage, bs, n_p, D) with centres in metres, log sizes.
         precomputed_dpg_lidar: `dpg_lidar_logits(point_feats)` computed earlier by the caller (graphs.GraphedFrame: in the BEV half)."""
+        logits_all, boxes_all = self._stages(img_feats, point_feats, img_metas, precomputed_dpg_lidar)
+        r = self.pc_range
+        lo = _const(r[:3], point_feats[0])
+        ext = _const([r[3] - r[0], r[4] - r[1], r[5] - r[2]], point_feats[0])
+        if self.deep_supervision:
+            logits_all, boxes_all = torch.stack(logits_all), torch.stack(boxes_all)
+        else:
+            logits_all, boxes_all = logits_all[-1][None], boxes_all[-1][None].clone()
+        boxes_all[..., :3] = boxes_all[..., :3] * ext + lo
+        return logits_all, boxes_all
+
+    def forward_decode(self, img_feats, point_feats, img_metas, precomputed_dpg_lidar=None):
+        """`decode(*forward(...))` for inference: (scores (bs, n_p, #cls), boxes (bs, n_p, 7|9)).  On the GPU without autograd only the
+        last stage's outputs are kept -- each stage rewrites the centres of its input boxes in metres in place (srfdet_head.py:1646),
+        so the per-stage copies `forward` makes for deep supervision are not needed -- and the end of `forward` + `decode` run as one
+        launch (ops.decode_boxes) instead of 13."""
+        if not (point_feats[0].is_cuda and not torch.is_grad_enabled()):
+            return self.decode(*self(img_feats, point_feats, img_metas, precomputed_dpg_lidar))
+        logits, pred = self._stages(img_feats, point_feats, img_metas, precomputed_dpg_lidar, last_only=True)
+        return ops.decode_boxes(logits[-1], pred[-1], self.pc_range)
+
+    def _stages(self, img_feats, point_feats, img_metas, precomputed_dpg_lidar=None, last_only=False):
+        """The decoder stages (srfdet_head.py:960-1000) -> per-stage lists of logits and boxes (centres normalised); with last_only
+        one entry each, and no copy of the boxes between stages."""
         point_feats = list(point_feats)
         if self.use_img and self.hidden_dim != self.feat_channels_img and not isinstance(img_feats, nhwc.ConsumedLevels):
             img_feats = self._img_convs_only(img_feats)
-        boxes, prop_feats = self._get_init_proposals(img_feats, point_feats, precomputed_dpg_lidar)
-        boxes = boxes.contiguous()
-        boxes[..., :3] = boxes[..., :3].sigmoid()
+        boxes, prop_feats = self._stage_proposals(img_feats, point_feats, precomputed_dpg_lidar)
 
         # channels-last copies of the pyramids, made once: every RoI tap then reads C contiguous floats
         if point_feats[0].is_cuda:
@@ -609,19 +660,13 @@ class SRFDetHead(BaseModule):
             else:
                 logits, pred, prop_feats = stage(img_feats_g, point_feats_g, boxes, prop_feats,
                                                  self.roi_extractor_lidar, img_metas, pooler_img=self.roi_extractor_img)
-            if self.deep_supervision:
+            if self.deep_supervision and not last_only:
                 logits_all.append(logits)
                 boxes_all.append(pred)
-            boxes = pred.detach().clone()
-
-        r = self.pc_range
-        lo = _const(r[:3], point_feats[0])
-        ext = _const([r[3] - r[0], r[4] - r[1], r[5] - r[2]], point_feats[0])
-        if self.deep_supervision:
-            logits_all, boxes_all = torch.stack(logits_all), torch.stack(boxes_all)
-        else:
-            logits_all, boxes_all = logits[None], pred[None].clone()
-        boxes_all[..., :3] = boxes_all[..., :3] * ext + lo
+            # the next stage overwrites the centres of its input in place: a copy, unless this stage's boxes are not kept
+            boxes = pred.detach() if last_only else pred.detach().clone()
+        if last_only or not self.deep_supervision:
+            logits_all, boxes_all = [logits], [pred]
         return logits_all, boxes_all
 
     # ---- training (srfdet_head.py:322-377, :1041-1201) ----------------------------------------------------------
@@ -686,8 +731,7 @@ class SRFDetHead(BaseModule):
         return torch.nan_to_num(self.loss_bbox(p[ok, :D], tn[ok, :D], w[ok, :D]) / num)
 
     def simple_test_bboxes(self, img_feats, point_feats, img_metas):
-        logits, boxes = self(img_feats, point_feats, img_metas)
-        return self.get_bboxes(logits, boxes, img_metas)
+        return self.get_bboxes(None, None, img_metas, decoded=self.forward_decode(img_feats, point_feats, img_metas))
 
     def decode(self, pred_logits, pred_bboxes):
         """last-stage outputs -> (scores (bs,n_p,#cls), boxes (bs,n_p,7|9) with bottom-centre z): the tensors the

@@ -63,7 +63,7 @@ class SparseConvTensor:
         set stays sorted.  The dense result of an encoder does not depend on the row order."""
         lvl, order, sorted_idx = ops.bitmap_build(indices if indices.dtype == torch.int32 else indices.int(), spatial_shape,
                                                   batch_size, padded=static_caps is not None)
-        t = SparseConvTensor(features[order.long()], sorted_idx, spatial_shape, batch_size)
+        t = SparseConvTensor(torch.index_select(features, 0, order), sorted_idx, spatial_shape, batch_size)  # int32 index: one launch
         t.indice_dict[("bitmap",) + t._level_key()] = lvl
         if static_caps is not None:
             # static-shape mode (whole-frame hipGraph): `indices` may carry padding rows (b < 0); every strided conv

@@ -152,7 +152,9 @@ def test_batch_of_two_frames(setup, dev):
     np.testing.assert_allclose(boxes.cpu().numpy(), ref_boxes.numpy(), rtol=0, atol=1e-4)
     # each sample of the batch equals the same frame run alone (the first stages are tight; see test_oracle_pinned)
     with torch.no_grad():
-        l1, b1 = gpu.bbox_head(None, [f[1:2].contiguous() for f in feats], metas[1:])
+        # (the lone sample in the layout the batch has: an NCHW-contiguous copy would send the proposal generator down its
+        # torch route, whose channel sum adds in another order -- 1e-6 on the proposals, 1e-4 after a random-weight stage)
+        l1, b1 = gpu.bbox_head(None, [f[1:2].contiguous(memory_format=torch.channels_last) for f in feats], metas[1:])
     np.testing.assert_allclose(boxes[0, 1].cpu().numpy(), b1[0, 0].cpu().numpy(), rtol=0, atol=1e-4)
 
 
