@@ -84,6 +84,13 @@ int srf_bitmap_strided_pairs(const int *out_indices, const int *num_out, int max
                              const int *ksize, const int *stride, const int *pad, const void *in_bitmap, const int *in_prefix,
                              int in_rows, int *nbr, int nbr_stride, int fill_tail, int *pair_counts, srf_stream_t stream);
 
+/* SparseConvTensor.dense() + the (N, C, D, H, W) -> (N, C * D, H, W) view of sparse_encoder_custom.py:144-147 as ONE pass that writes
+ * the BEV map channels-last (out: (B, H, W, C * D) floats, channel c * D + z): every pixel is written once, from the level's bitmap
+ * (active cells: the feature row of their rank; others: zeros) -- no zero fill, no scatter, no NCHW -> NHWC transpose.
+ * feats (A x C) sorted by (b, y, x, z); bitmap / prefix as built for this level; (C * D) % 4 == 0. */
+int srf_densify_bev(const float *feats, int A, int C, const void *bitmap, const int *prefix, int B, int D, int H, int W, float *out,
+                    srf_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * f-4  the step before the path: the CPU transforms of the reference's test pipeline between the decoded
  * sensor data and SRFDet.forward (configs/nus/srfdet_voxel_nusc_LC.py:253-283), on the device.

@@ -77,6 +77,7 @@ SIGNATURES = {
     "srf_bitmap_pair_count_ints": (c_size_t, []),
     "srf_bitmap_workspace_bytes": (c_size_t, [c_size_t]),
     "srf_bitmap_build": (c_int, [_P, c_int, _HI, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "srf_densify_bev": (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "srf_bitmap_build_padded": (c_int, [_P, c_int, _HI, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "srf_bitmap_rulebook_subm": (c_int, [_P, c_int, _HI, c_int, _HI, _P, _P, _P, _P, _P]),
     "srf_bitmap_strided_outputs": (c_int, [_P, c_int, _HI, c_int, _HI, _HI, _HI, _P, _P, _P, c_int, _P, _P, c_size_t, _P]),

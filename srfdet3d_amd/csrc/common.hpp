@@ -235,12 +235,13 @@ __global__ __launch_bounds__(SRF_SCAN_THREADS) void srf_scan_apply_k(int n, ValF
     }
 }
 
-// The same scan as ONE launch of one 1024-thread workgroup, for inputs of at most SRF_SCAN_SINGLE_MAX elements (the bitmaps of
-// the coarse sparse levels: 2-45 k words; the points of a sweep): the three-launch form costs ~15 us there whatever the size
-// (three dependent graph nodes), this one 5-9 us.  Element i belongs to thread (i / ITEMS) % 1024 of round i / (1024 * ITEMS),
-// as in srf_scan_apply_k: identical prefixes, identical out() calls.
+// The same scan as ONE launch of one 1024-thread workgroup, for inputs of at most SRF_SCAN_SINGLE_MAX = 8192 elements (the bitmaps
+// of the two coarsest sparse levels: 2-5 k words): the three-launch form costs ~15 us there whatever the size (three dependent
+// graph nodes), this one 7 us.  One round only: a lone workgroup pays a full memory latency per round (measured: 43 us for the
+// 44.5 k words of level 3, 124 us for the 35 k points of the voxelization flags -- against 15 and 22 us in three launches).
+// Element i belongs to thread i / ITEMS, as in srf_scan_apply_k: identical prefixes, identical out() calls.
 #define SRF_SCAN_SINGLE_THREADS 1024
-#define SRF_SCAN_SINGLE_MAX (8 * SRF_SCAN_SINGLE_THREADS * SRF_SCAN_ITEMS)
+#define SRF_SCAN_SINGLE_MAX (SRF_SCAN_SINGLE_THREADS * SRF_SCAN_ITEMS)
 
 template <class ValF, class OutF>
 __global__ __launch_bounds__(SRF_SCAN_SINGLE_THREADS) void srf_scan_single_k(int n, ValF val, OutF out, int *__restrict__ partial_total,

@@ -675,3 +675,45 @@ extern "C" int srf_bitmap_strided_pairs(const int *out_indices, const int *num_o
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// srf_densify_bev: SparseConvTensor.dense() + the (N, C, D, H, W) -> (N, C * D, H, W) view of sparse_encoder_custom.py:144-147,
+// written CHANNELS-LAST for the dense backbone that follows (pixel-major, channel c * D + z), from the level's bitmap: every
+// pixel of the map is written exactly once -- its active cells' feature rows (row = bitmap rank), zeros elsewhere -- so the
+// zero fill of the dense tensor (33 MB on nuScenes), the scatter and the NCHW -> NHWC transpose are one pass.
+// One thread per (pixel, four channels); feats (A, C) rows sorted by (b, y, x, z) as everywhere in this file.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void srf_densify_bev_k(const float *__restrict__ feats, int A, int C, const uint32_t *__restrict__ bitmap,
+                                                       const int *__restrict__ prefix, long long pixels, int D, int Q,
+                                                       float *__restrict__ out)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= pixels * Q) return;
+    const long long pix = t / Q;
+    const int q = (int)(t - pix * Q);
+    f32x4n v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ch = q * 4 + j, c = ch / D, z = ch - c * D;
+        const int r = srf_bm_rank(bitmap, prefix, (uint32_t)(pix * D + z));
+        if (r >= 0 && r < A) v[j] = feats[(size_t)r * C + c];
+    }
+    *reinterpret_cast<f32x4n *>(out + (size_t)pix * (4 * Q) + q * 4) = v;
+}
+
+extern "C" int srf_densify_bev(const float *feats, int A, int C, const void *bitmap, const int *prefix, int B, int D, int H, int W,
+                               float *out, srf_stream_t stream)
+{
+    if (A < 0 || C <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || !out || !bitmap || !prefix) return SRF_EINVAL;
+    if (((long long)C * D) & 3 || ((uintptr_t)out & 15)) return SRF_EUNSUPPORTED;
+    if ((unsigned long long)B * H * W * D >= 0xFFFFFFFFull) return SRF_EUNSUPPORTED;
+    if (A > 0 && !feats) return SRF_EINVAL;
+    const long long pixels = (long long)B * H * W;
+    const int Q = C * D / 4;
+    hipLaunchKernelGGL(srf_densify_bev_k, dim3(srf_ceil_div(pixels * Q, 256)), dim3(256), 0, (hipStream_t)stream, feats, A, C,
+                       (const uint32_t *)bitmap, prefix, pixels, D, Q, out);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}

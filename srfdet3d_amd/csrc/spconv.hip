@@ -1081,12 +1081,8 @@ __global__ __launch_bounds__(256) void srf_gs_rowpairs_k(const int *__restrict__
     if (threadIdx.x == 0) blocksum[blockIdx.x] = carry;
 }
 
-// exclusive scan of the block totals (one workgroup; nb <= a few hundred), total pair count at [nb]; then, by the same
-// workgroup (one launch instead of two: each is ~5 us of launch latency around microseconds of work),
-// tiles[t] = first row whose exclusive pair prefix reaches t*P/T (binary search over blocks, then inside the block)
-__global__ __launch_bounds__(256) void srf_gs_scan_cut_k(const int *__restrict__ blocksum, int nb, int *__restrict__ blockoff,
-                                                       const int *__restrict__ local, int A, const int *__restrict__ rows_dev, int T,
-                                                       int *__restrict__ tiles)
+// exclusive scan of the block totals (one workgroup; nb <= a few hundred), total pair count at [nb]
+__global__ __launch_bounds__(256) void srf_gs_blockscan_k(const int *__restrict__ blocksum, int nb, int *__restrict__ blockoff)
 {
     __shared__ int s_scan[4];
     int carry = 0;
@@ -1098,41 +1094,44 @@ __global__ __launch_bounds__(256) void srf_gs_scan_cut_k(const int *__restrict__
         if (b < nb) blockoff[b] = carry + ex;
         carry += total;
     }
-    if (nb > 0 && threadIdx.x == 0) blockoff[nb] = carry;  // (nb == 0: A == 0, there is no workspace)
-    __threadfence_block();
-    __syncthreads();  // blockoff[] of this workgroup's own stores is visible to all its threads from here
+    if (threadIdx.x == 0) blockoff[nb] = carry;
+}
+
+// tiles[t] = first row whose exclusive pair prefix reaches t*P/T (binary search over blocks, then inside the block)
+__global__ __launch_bounds__(256) void srf_gs_cut_k(const int *__restrict__ local, const int *__restrict__ blockoff, int nb, int A,
+                                                  const int *__restrict__ rows_dev, int T, int *__restrict__ tiles)
+{
     if (rows_dev) {
         const int live = *rows_dev;
         A = A < live ? A : live;
     }
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t > T) return;
     const int nbl = (A + SRF_TB_ROWS - 1) / SRF_TB_ROWS;  // live blocks (<= nb)
-    const volatile int *boff_v = blockoff;
-    for (int t = threadIdx.x; t <= T; t += 256) {
-        if (t == T || A == 0) {
-            tiles[t] = A;
-            continue;
-        }
-        const long long P = boff_v[nbl];
-        const long long target = (P * t + T - 1) / T;
-        // last block whose offset is <= target
-        int lo = 0, hi = nbl - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (boff_v[mid] <= target) lo = mid;
-            else hi = mid - 1;
-        }
-        const long long boff = boff_v[lo];
-        const int r0 = lo * SRF_TB_ROWS;
-        const int r1 = r0 + SRF_TB_ROWS < A ? r0 + SRF_TB_ROWS : A;
-        // first row in [r0, r1) with boff + local[r] >= target, else r1
-        int a = r0, b = r1;
-        while (a < b) {
-            const int mid = (a + b) >> 1;
-            if (boff + local[mid] >= target) b = mid;
-            else a = mid + 1;
-        }
-        tiles[t] = a;
+    if (t == T || A == 0) {
+        tiles[t] = A;
+        return;
     }
+    const long long P = blockoff[nbl];
+    const long long target = (P * t + T - 1) / T;
+    // last block whose offset is <= target
+    int lo = 0, hi = nbl - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (blockoff[mid] <= target) lo = mid;
+        else hi = mid - 1;
+    }
+    const long long boff = blockoff[lo];
+    const int r0 = lo * SRF_TB_ROWS;
+    const int r1 = r0 + SRF_TB_ROWS < A ? r0 + SRF_TB_ROWS : A;
+    // first row in [r0, r1) with boff + local[r] >= target, else r1
+    int a = r0, b = r1;
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (boff + local[mid] >= target) b = mid;
+        else a = mid + 1;
+    }
+    tiles[t] = a;
 }
 
 extern "C" int srf_spconv_tiles_count(int A_out) { return A_out <= 0 ? 1 : srf_gs_ranges(A_out); }
@@ -1153,9 +1152,11 @@ extern "C" int srf_spconv_tiles_build(const int *nbr, int nbr_stride, int K, int
     const int T = srf_spconv_tiles_count(A_out);
     const int nb = (A_out + SRF_TB_ROWS - 1) / SRF_TB_ROWS;
     int *local = (int *)workspace, *blocksum = local + A_out, *blockoff = blocksum + nb + 1;
-    if (nb > 0)
+    if (nb > 0) {
         hipLaunchKernelGGL(srf_gs_rowpairs_k, dim3(nb), dim3(256), 0, st, nbr, nbr_stride, K, A_out, rows_dev, local, blocksum);
-    hipLaunchKernelGGL(srf_gs_scan_cut_k, dim3(1), dim3(256), 0, st, blocksum, nb, blockoff, local, A_out, rows_dev, T, tiles);
+        hipLaunchKernelGGL(srf_gs_blockscan_k, dim3(1), dim3(256), 0, st, blocksum, nb, blockoff);
+    }
+    hipLaunchKernelGGL(srf_gs_cut_k, dim3(srf_ceil_div(T + 1, 256)), dim3(256), 0, st, local, blockoff, nb, A_out, rows_dev, T, tiles);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

@@ -449,6 +449,20 @@ def densify(feats, indices, batch, spatial_shape):
     return _densify(feats, indices, batch, spatial_shape)
 
 
+def densify_bev(feats, level, batch, spatial_shape):
+    """sorted rows (A, C) + their BitmapLevel -> the BEV map (batch, C * D, H, W) with CHANNELS-LAST strides: dense() + the
+    (N, C, D, H, W) -> (N, C * D, H, W) view in one pass (no zero fill, no transpose; srf_densify_bev).  Inference only."""
+    feats = _dev(feats, "feats", torch.float32)
+    A, C = feats.shape
+    D, H, W = [int(v) for v in spatial_shape]
+    if [int(v) for v in level.shape] != [D, H, W] or level.batch != batch:
+        raise ValueError("densify_bev: the bitmap level belongs to another grid")
+    out = torch.empty((batch, C * D, H, W), dtype=torch.float32, device=feats.device, memory_format=torch.channels_last)
+    check(_lib.lib().srf_densify_bev(_ptr(feats), A, C, _ptr(level.bitmap), _ptr(level.prefix), batch, D, H, W, _ptr(out), _stream()),
+          "densify_bev")
+    return out
+
+
 def _densify(feats, indices, batch, spatial_shape):
     feats = _dev(feats, "feats", torch.float32)
     indices = _dev(indices, "indices", torch.int32)
@@ -1138,7 +1152,7 @@ def gemm_split_enabled():
     return os.environ.get("SRF_GEMM_SPLIT", "1") != "0"
 
 
-GEMM_SPLIT_MIN_TILES = 384   # 128 x 128 tiles of a launch from which the split kernel is taken: half a round at three workgroups per CU
+GEMM_SPLIT_MIN_TILES = 128   # 128 x 128 tiles of a launch from which the split kernel is taken (tools/small_gemm_ab.py)
 
 
 def gemm_split_wanted(M, Cout):

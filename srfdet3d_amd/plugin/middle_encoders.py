@@ -76,9 +76,7 @@ class SparseEncoderCustom(BaseModule):
             x = self.conv_input(x)
             for stage in self.encoder_layers._modules.values():
                 x = stage(x)
-            dense = self.conv_out(x).dense()
-            N, C, D, H, W = dense.shape
-            return dense.view(N, C * D, H, W), static["counts"]
+            return self.conv_out(x).dense_bev(), static["counts"]
         if self.spatial_sort and coors.is_cuda and coors.shape[0] > 0:
             # rows into (b, y, x, z) order + the level's occupancy bitmap: all rulebooks below are built by bitmap rank
             x = SparseConvTensor.sorted_by_bitmap(voxel_features, coors, self.sparse_shape, int(batch_size))
@@ -87,7 +85,4 @@ class SparseEncoderCustom(BaseModule):
         x = self.conv_input(x)
         for stage in self.encoder_layers._modules.values():
             x = stage(x)
-        out = self.conv_out(x)
-        dense = out.dense()
-        N, C, D, H, W = dense.shape
-        return dense.view(N, C * D, H, W)
+        return self.conv_out(x).dense_bev()

@@ -88,6 +88,18 @@ class SparseConvTensor:
         out = ops.densify(self.features, self.indices, self.batch_size, self.spatial_shape)
         return out if channels_first else out.permute(0, 2, 3, 4, 1)
 
+    def dense_bev(self):
+        """dense() viewed as (N, C * D, H, W) (sparse_encoder_custom.py:144-147).  GPU inference on a bitmap-ranked level: one pass that
+        writes the map channels-last for the dense backbone (ops.densify_bev); same values, other strides."""
+        lvl = self.bitmap_level()
+        C = self.features.shape[1]
+        if (lvl is not None and self.features.is_cuda and not (torch.is_grad_enabled() and self.features.requires_grad)
+                and (C * self.spatial_shape[0]) % 4 == 0 and self.features.dtype == torch.float32):
+            return ops.densify_bev(self.features, lvl, self.batch_size, self.spatial_shape)
+        dense = self.dense()
+        N, C, D, H, W = dense.shape
+        return dense.view(N, C * D, H, W)
+
     @property
     def spatial_size(self):
         return int(torch.tensor(self.spatial_shape).prod())

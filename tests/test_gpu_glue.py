@@ -185,3 +185,26 @@ def test_host_pack(dev):
     out = ops.host_pack(a, b, c)
     ref = torch.cat([a.reshape(-1), b.reshape(-1).float(), c.float()])
     assert torch.equal(out, ref)
+
+
+def test_densify_bev_is_dense_view_channels_last(dev):
+    """ops.densify_bev (one pass from the bitmap, channels-last) against dense() + the (N, C*D, H, W) view"""
+    from srfdet3d_amd import ops
+    g = torch.Generator().manual_seed(19)
+    for (B, D, H, W, C, A) in ((1, 2, 180, 180, 128, 9000), (2, 2, 45, 51, 64, 3000), (1, 3, 20, 24, 16, 700)):
+        cells = torch.randperm(B * D * H * W, generator=g)[:A]
+        b = cells // (D * H * W)
+        r = cells % (D * H * W)
+        z, y, x = r // (H * W), (r // W) % H, r % W
+        idx = torch.stack([b, z, y, x], 1).int().to(dev)
+        feats = torch.randn(A, C, generator=g).to(dev)
+        lvl, order, sidx = ops.bitmap_build(idx, [D, H, W], B)
+        sf = feats[order.long()]
+        ref = ops.densify(sf, sidx, B, [D, H, W]).view(B, C * D, H, W)
+        torch.full((B * C * D * H * W,), float("nan"), device=dev)   # dirty the pool: every element must be written
+        got = ops.densify_bev(sf, lvl, B, [D, H, W])
+        assert got.shape == ref.shape and got.stride(1) == 1 and torch.equal(got, ref)
+    # a capacity-sized set with padding rows behind the live ones (static frames)
+    pad = torch.cat([sidx, torch.full((100, 4), -1, dtype=torch.int32, device=dev)])
+    padf = torch.cat([sf, torch.full((100, C), float("nan"), device=dev)])
+    assert torch.equal(ops.densify_bev(padf, lvl, B, [D, H, W]), ref)
