@@ -534,6 +534,14 @@ int srf_nhwc_dwconv3x3s2(const float *x, long long x_ld, int N, int H, int W, in
 int srf_nhwc_dwconv3x3s2_cat(const float *x, long long x_ld, int N, int H, int W, int C, const float *w, const float *scale,
                              const float *shift, int relu, float *y, long long y_ld, const float *side, long long side_ld, int Cs,
                              float *side_out, srf_stream_t stream);
+/* Training (config 4, tools/train.py:220-234): the backward pass of y = relu(z * s[c] + t[c]) -- a convolution's eval-mode BatchNorm
+ * (norm_eval=True, vovnet.py:371) + ReLU, which the forward pass runs as the convolution's epilogue -- over channels-last (M x C)
+ * tensors in one pass: gz = (relu ? gy * [y > 0] : gy) * s, sums[0..C) = sum_p gu, sums[C..2C) = sum_p gu * y (gu = the masked gy);
+ * deterministic (per-block partials added in block order).  C % 4 == 0, C <= 1024. */
+size_t srf_nhwc_affine_relu_bwd_workspace_bytes(long long M, int C);
+int srf_nhwc_affine_relu_bwd(const float *gy, long long gy_ld, const float *y, long long y_ld, long long M, int C, const float *scale /*or NULL*/,
+                             int relu, float *gz, long long gz_ld, float *sums /*2 C*/, void *workspace, size_t workspace_bytes,
+                             srf_stream_t stream);
 int srf_nhwc_pool_sum(const float *x, long long x_ld, int B, int n_cam, int H, int W, int C, int Ho, int Wo, float *out, int out_ld,
                       srf_stream_t stream);
 int srf_dpg_mix(const float *wl, const float *wi /*or NULL*/, int B, int E, int P, const float *boxes_w, int D, const float *feats_w,

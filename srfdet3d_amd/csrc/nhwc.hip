@@ -354,3 +354,112 @@ extern "C" int srf_nhwc_pool_sum(const float *x, long long x_ld, int B, int n_ca
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// srf_nhwc_affine_relu_bwd: the backward pass of  y = relu(z * s[c] + t[c])  (a convolution's eval-mode BatchNorm + ReLU, run as the
+// convolution kernel's epilogue in the forward pass) in ONE streaming pass over channels-last tensors:
+//     gu = relu ? (y > 0 ? gy : 0) : gy          gz = gu * s[c]          sum_gu[c] = sum_p gu          sum_guy[c] = sum_p gu * y
+// from which the caller forms  d beta = sum_gu  and  d s = sum_p gu * z = (sum_guy - t * sum_gu) / s  (z = (y - t) / s wherever
+// gu != 0) without ever having stored z.  As torch ops this is threshold_backward, a multiply and two strided column sums
+// (four passes over the tensor).  Column sums are deterministic: per-block partials (256 rows each), added in block order.
+// ---------------------------------------------------------------------------------------------------------------------
+#define SRF_ARB_ROWS 256
+
+__global__ __launch_bounds__(256) void srf_affine_relu_bwd_k(const float *__restrict__ gy, long long gy_ld, const float *__restrict__ y,
+                                                           long long y_ld, long long M, int Cq, const float *__restrict__ scale, int relu,
+                                                           float *__restrict__ gz, long long gz_ld, float *__restrict__ partial)
+{
+    __shared__ float s_red[256 * 8];
+    const int rpp = 256 / Cq;  // rows per pass (Cq <= 256)
+    const int r_local = threadIdx.x / Cq, cq = threadIdx.x - r_local * Cq;
+    const long long row0 = (long long)blockIdx.x * SRF_ARB_ROWS;
+    const long long row1 = row0 + SRF_ARB_ROWS < M ? row0 + SRF_ARB_ROWS : M;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r_local < rpp) {
+        f32x4n s = {1.f, 1.f, 1.f, 1.f};
+        if (scale) s = *reinterpret_cast<const f32x4n *>(scale + cq * 4);
+        for (long long row = row0 + r_local; row < row1; row += rpp) {
+            const f32x4n g = *reinterpret_cast<const f32x4n *>(gy + row * gy_ld + cq * 4);
+            const f32x4n v = *reinterpret_cast<const f32x4n *>(y + row * y_ld + cq * 4);
+            f32x4n o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gu = (relu && !(v[j] > 0.f)) ? 0.f : g[j];
+                o[j] = __fmul_rn(gu, s[j]);
+                acc[j] = __fadd_rn(acc[j], gu);
+                acc[4 + j] = __fmaf_rn(gu, v[j], acc[4 + j]);
+            }
+            *reinterpret_cast<f32x4n *>(gz + row * gz_ld + cq * 4) = o;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_red[threadIdx.x * 8 + j] = acc[j];
+    __syncthreads();
+    if (r_local == 0) {
+        const int C = Cq * 4;
+        float tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < rpp; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tot[j] = __fadd_rn(tot[j], s_red[(r * Cq + cq) * 8 + j]);
+        float *p = partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            p[cq * 4 + j] = tot[j];
+            p[C + cq * 4 + j] = tot[4 + j];
+        }
+    }
+}
+
+// 16 columns x 16 segments per workgroup: segment g adds the partials of blocks [g nb / 16, (g + 1) nb / 16) in order, then the
+// 16 segment sums are added in order -- a fixed tree (one thread walking all ~270 blocks of a stage-4 layer took 50 us)
+__global__ __launch_bounds__(256) void srf_affine_relu_bwd_finish_k(const float *__restrict__ partial, int nblocks, int C2,
+                                                                  float *__restrict__ sums)
+{
+    __shared__ float s_seg[16][17];
+    const int col = threadIdx.x & 15, seg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + col;
+    const int b0 = (int)((long long)nblocks * seg / 16), b1 = (int)((long long)nblocks * (seg + 1) / 16);
+    float acc = 0.f;
+    if (c < C2)
+        for (int b = b0; b < b1; ++b) acc = __fadd_rn(acc, partial[(size_t)b * C2 + c]);
+    s_seg[seg][col] = acc;
+    __syncthreads();
+    if (seg == 0 && c < C2) {
+        float tot = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) tot = __fadd_rn(tot, s_seg[g][col]);
+        sums[c] = tot;
+    }
+}
+
+extern "C" size_t srf_nhwc_affine_relu_bwd_workspace_bytes(long long M, int C)
+{
+    if (M <= 0 || C <= 0) return 0;
+    return (size_t)((M + SRF_ARB_ROWS - 1) / SRF_ARB_ROWS) * 2 * C * sizeof(float);
+}
+
+extern "C" int srf_nhwc_affine_relu_bwd(const float *gy, long long gy_ld, const float *y, long long y_ld, long long M, int C,
+                                        const float *scale, int relu, float *gz, long long gz_ld, float *sums, void *workspace,
+                                        size_t workspace_bytes, srf_stream_t stream)
+{
+    if (M < 0 || C <= 0 || gy_ld < C || y_ld < C || gz_ld < C) return SRF_EINVAL;
+    if ((C & 3) || C > 1024 || (gy_ld & 3) || (y_ld & 3) || (gz_ld & 3) || ((uintptr_t)gy & 15) || ((uintptr_t)y & 15) || ((uintptr_t)gz & 15) ||
+        (scale && ((uintptr_t)scale & 15)))
+        return SRF_EUNSUPPORTED;
+    if (!sums) return SRF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (M == 0) {
+        SRF_HIP_TRY(srf_fill_bytes(sums, 0, sizeof(float) * 2 * C, st));
+        return SRF_OK;
+    }
+    if (!gy || !y || !gz || !workspace) return SRF_EINVAL;
+    if (workspace_bytes < srf_nhwc_affine_relu_bwd_workspace_bytes(M, C)) return SRF_EWORKSPACE;
+    const long long nb = (M + SRF_ARB_ROWS - 1) / SRF_ARB_ROWS;
+    if (nb > 0x7FFFFFFF) return SRF_EUNSUPPORTED;
+    hipLaunchKernelGGL(srf_affine_relu_bwd_k, dim3((unsigned)nb), dim3(256), 0, st, gy, gy_ld, y, y_ld, M, C / 4, scale, relu, gz, gz_ld,
+                       (float *)workspace);
+    hipLaunchKernelGGL(srf_affine_relu_bwd_finish_k, dim3(srf_ceil_div(2 * C, 16)), dim3(256), 0, st, (const float *)workspace, (int)nb, 2 * C,
+                       sums);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}

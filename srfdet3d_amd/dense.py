@@ -5,6 +5,8 @@ The convolutions stay on MIOpen; the eval-mode BatchNorm2d and the ReLU behind e
 autograd / autocast behaviour are untouched: the fused route is taken only for fp32 CUDA tensors with grad disabled and
 BatchNorm in eval mode, everything else goes through the modules as written.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -51,6 +53,10 @@ def conv_bn_act(conv, bn, relu, x):
         scale, shift = _fold_bn2d(bn)
         return ops.dwconv3x3s2(x, conv.weight, scale, shift, relu)
     from . import train_conv
+    if _train_fusable(x):
+        y = train_conv.conv_bn_act(conv, bn, relu, x)   # training: conv + eval BatchNorm + ReLU as one autograd node
+        if y is not None:
+            return y
     y = train_conv.conv2d(conv, x)   # training: the 3x3 layers on srf_wino43 (forward and data gradient), else conv(x)
     if _foldable(bn) and fusable(y) and y.is_contiguous() and y.shape[0] * y.shape[1] <= 65535:  # grid.y of the kernel
         return bn_act_(y, bn, relu)
@@ -92,13 +98,19 @@ def conv1x1_cat_bn_act(conv, bn, relu, xs):
     return conv_bn_act(conv, bn, relu, x)
 
 
+def _train_fusable(x):
+    """under autograd: conv -> eval-mode BatchNorm -> ReLU may run as train_conv._ConvAffineRelu (conv_bn_act decides per layer)"""
+    return (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and os.environ.get("SRF_TRAIN_FUSED", "1") != "0")
+
+
 def run_sequential(seq, x):
     """nn.Sequential forward with every [Conv2d, BatchNorm2d(eval), (ReLU)] run through `conv_bn_act`."""
     mods = list(seq.children())
     i = 0
     while i < len(mods):
         m = mods[i]
-        if (isinstance(m, nn.Conv2d) and i + 1 < len(mods) and _foldable(mods[i + 1]) and fusable(x)):
+        if (isinstance(m, nn.Conv2d) and i + 1 < len(mods) and _foldable(mods[i + 1]) and (fusable(x) or _train_fusable(x))):
             relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
             x = conv_bn_act(m, mods[i + 1], relu, x)
             i += 3 if relu else 2

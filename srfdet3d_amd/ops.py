@@ -1337,6 +1337,23 @@ def nhwc_dwconv3x3s2_cat(x, weight, scale, shift, relu, side, out):
     return out
 
 
+def nhwc_affine_relu_bwd(gy, y, scale, relu):
+    """Backward of y = relu(z * scale + shift) on NHWC tensors (N, H, W, C): -> gz (N, H, W, C) = masked gy * scale, and the column
+    sums (2, C) [sum gu, sum gu * y] (gu = gy where y > 0); one streaming pass + a finish launch (srf_nhwc_affine_relu_bwd)."""
+    N, H, W, C = gy.shape
+    gy_ld, y_ld = nhwc_ld(gy), nhwc_ld(y)
+    M = N * H * W
+    L = _lib.lib()
+    gz = _empty((N, H, W, C), torch.float32, gy.device)
+    sums = _empty((2, C), torch.float32, gy.device)
+    nbytes = L.srf_nhwc_affine_relu_bwd_workspace_bytes(M, C)
+    ws = _empty((max(nbytes, 4) // 4,), torch.float32, gy.device)
+    sc = None if scale is None else _aligned16(_dev(scale, "scale", torch.float32))
+    check(L.srf_nhwc_affine_relu_bwd(_ptr(gy), gy_ld, _ptr(y), y_ld, M, C, _ptr(sc), int(bool(relu)), _ptr(gz), C, _ptr(sums), _ptr(ws),
+                                     nbytes, _stream()), "nhwc_affine_relu_bwd")
+    return gz, sums
+
+
 def nhwc_pool_sum(x, n_cam=1, size=None, pad_to=4):
     """x (B * n_cam, H, W, C) channels-last -> (B, pad(Ho * Wo)): per output pixel the sum over cameras and channels at its `nearest`
     source pixel (size = (Ho, Wo); None: the map itself); columns past Ho * Wo are zeros (row length rounded up to pad_to)."""

@@ -99,6 +99,85 @@ class _Wino43Conv(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _ConvAffineRelu(torch.autograd.Function):
+    """conv (3x3 / stride 1 on `srf_wino43`, or 1x1 on the library's GEMM) -> BatchNorm2d in EVAL mode (`norm_eval=True`: an affine
+    map with trainable gamma / beta) -> ReLU as ONE forward launch -- the inference kernel with the folded BatchNorm and the ReLU in
+    its epilogue -- and a backward pass that starts with ONE streaming kernel (`srf_nhwc_affine_relu_bwd`: ReLU mask, scale, and
+    the two column sums gamma / beta need).  As torch ops the same chain is conv, multiply, add, relu_ forward and
+    threshold_backward, multiply and two strided column sums backward: eight passes over each layer's output instead of two.
+    Only y is saved (not the convolution's own output z): sum gu z = (sum gu y - t sum gu) / s since z = (y - t) / s wherever the mask
+    lets a gradient through.  (A channel whose gamma is exactly 0 has s = 0: that term of its d gamma is taken as 0.)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, mean, var, eps, relu):
+        xn = _nhwc(x)
+        Cout, Cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+        inv = torch.rsqrt(var + eps)
+        s = gamma.detach() * inv
+        t0 = beta.detach() - mean * s
+        t = t0 if bias is None else t0 + bias.detach() * s
+        w = weight.detach()
+        if k == 3:
+            yn = ops.wino43(xn, ops.pack_wino43_weights(w), Cout, s, t, relu)
+        else:
+            w2 = w.reshape(Cout, Cin)
+            yn = ops.conv1x1_nhwc(xn, lambda: ops.pack_conv1x1_nhwc_weights(w2), Cout, s, t, relu,
+                                  packed_split=lambda: ops.pack_conv1x1_nhwc_split_weights(w2))
+        ctx.save_for_backward(x, weight, yn, s, t0, inv, mean)
+        ctx.relu, ctx.has_bias, ctx.k = bool(relu), bias is not None, k
+        return yn.permute(0, 3, 1, 2)          # logical NCHW, channels-last strides
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, yn, s, t0, inv, mean = ctx.saved_tensors
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        gz, sums = ops.nhwc_affine_relu_bwd(_nhwc(gy), yn, s, ctx.relu)
+        need = ctx.needs_input_grad
+        gx = gw = gb = ggamma = gbeta = None
+        if need[4]:
+            gbeta = sums[0]
+        if need[3]:
+            # u = (z - mean) inv gamma + beta:  d gamma = inv (sum gu z - mean sum gu),  sum gu z = (sum gu y - t0 sum gu) / s
+            ggamma = (torch.where(s != 0, (sums[1] - t0 * sums[0]) / s, torch.zeros_like(s)) - mean * sums[0]) * inv
+        if ctx.has_bias and need[2]:
+            gb = sums[0] * s
+        w = weight.detach()
+        if need[0]:
+            if ctx.k == 3:
+                w_t = w.flip(2, 3).transpose(0, 1).contiguous()           # (Cin, Cout, 3, 3), rotated by 180 degrees
+                gx = ops.wino43(gz, ops.pack_wino43_weights(w_t), Cin).permute(0, 3, 1, 2)
+            else:
+                w_t = w.reshape(Cout, Cin).t().contiguous()              # (Cin, Cout): dx = gz W
+                gx = ops.conv1x1_nhwc(gz, lambda: ops.pack_conv1x1_nhwc_weights(w_t), Cin,
+                                      packed_split=lambda: ops.pack_conv1x1_nhwc_split_weights(w_t)).permute(0, 3, 1, 2)
+        if need[1]:
+            if ctx.k == 3:
+                gw = torch.ops.aten.convolution_backward(gz.permute(0, 3, 1, 2), x.contiguous(memory_format=torch.channels_last), weight, None,
+                                                         (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+            else:
+                xn = _nhwc(x)
+                gw = (gz.reshape(-1, Cout).t() @ xn.reshape(-1, Cin)).view(Cout, Cin, 1, 1)
+        return gx, gw, gb, ggamma, gbeta, None, None, None, None
+
+
+def fused_eligible(conv, bn, x):
+    """conv -> eval-mode BatchNorm2d (-> ReLU) under autograd on a channels-last tensor, in the shapes `_ConvAffineRelu` covers."""
+    if not (isinstance(bn, nn.BatchNorm2d) and not bn.training and bn.track_running_stats and bn.affine and x.dim() == 4 and x.is_cuda
+            and x.stride(1) == 1 and conv.out_channels % 4 == 0 and conv.out_channels <= 1024):
+        return False
+    if eligible(conv, x):
+        return ops.wino43_supported(x.permute(0, 2, 3, 1), conv.out_channels)
+    return (eligible_1x1(conv, x) and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0
+            and x.shape[0] * x.shape[2] * x.shape[3] * max(conv.in_channels, conv.out_channels) * 512 < (1 << 31) * 128)
+
+
+def conv_bn_act(conv, bn, relu, x):
+    """The fused training route when it applies, else None (the caller then runs conv2d / bn_eval / relu)."""
+    if fused_eligible(conv, bn, x):
+        return _ConvAffineRelu.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bool(relu))
+    return None
+
+
 class _DepthwiseNative(torch.autograd.Function):
     """Depthwise convolutions (the stride-2 stair of the proposal generator, srfdet_head.py:520-537) on torch's own depthwise
     kernels in BOTH directions.  The forward already kept MIOpen away (its choice is a naive reference kernel: 34 ms on the

@@ -306,3 +306,70 @@ def test_train_mode_batchnorm_never_sees_a_channels_last_tensor(dev):
     t = torch.randn(1, 128, 23, 23, device=dev).contiguous(memory_format=torch.channels_last)
     assert train_conv.bn_train_input(bn.train(), t).is_contiguous()
     assert train_conv.bn_train_input(bn.eval(), t) is t
+
+
+@pytest.mark.parametrize("k,N,Cin,Cout,H,W,relu,bias", [(3, 2, 192, 192, 29, 50, True, False), (3, 1, 160, 224, 13, 21, False, True),
+                                                        (1, 2, 1472, 768, 29, 25, True, False), (1, 3, 64, 96, 17, 9, True, True)])
+def test_fused_conv_evalbn_relu_training_node_matches_autograd(dev, k, N, Cin, Cout, H, W, relu, bias):
+    """train_conv._ConvAffineRelu (conv + eval-mode BatchNorm + ReLU: one forward launch, `srf_nhwc_affine_relu_bwd` + dgrad + wgrad
+    backward) against torch's autograd through conv2d -> batch_norm(eval) -> relu in float64"""
+    from torch import nn
+    from srfdet3d_amd import dense, train_conv
+    g = torch.Generator().manual_seed(k * 100 + Cin)
+    conv = nn.Conv2d(Cin, Cout, k, padding=k // 2, bias=bias).to(dev)
+    bn = nn.BatchNorm2d(Cout, eps=1e-3).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(Cout, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(Cout, generator=g) * 0.2)
+        bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+    bn.eval()
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gy = torch.randn(N, Cout, H, W, generator=g).to(dev)
+    assert train_conv.fused_eligible(conv, bn, x)
+    y = dense.conv_bn_act(conv, bn, relu, x)
+    assert type(y.grad_fn).__name__ == "_ConvAffineReluBackward" and y.stride(1) == 1
+    y.backward(gy)
+    got = [y.detach(), x.grad, conv.weight.grad, bn.weight.grad, bn.bias.grad] + ([conv.bias.grad] if bias else [])
+    # float64 reference through torch's own operators
+    xd = x.detach().double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    bd = conv.bias.detach().double().requires_grad_(True) if bias else None
+    gam, bet = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+    z = F.conv2d(xd, wd, bd, padding=k // 2)
+    u = F.batch_norm(z, bn.running_mean.double(), bn.running_var.double(), gam, bet, False, 0.0, bn.eps)
+    yr = torch.relu(u) if relu else u
+    yr.backward(gy.double())
+    ref = [yr.detach(), xd.grad, wd.grad, gam.grad, bet.grad] + ([bd.grad] if bias else [])
+    names = ["y", "dx", "dW", "dgamma", "dbeta", "dbias"]
+    for name, a, b in zip(names, got, ref):
+        scale = float(b.abs().max())
+        err = float((a.double() - b).abs().max()) / max(scale, 1e-30)
+        # the ReLU mask of an element within rounding of zero may differ between the f32 kernel and float64: a handful of elements
+        tol = 2e-3 if name in ("dx",) else 5e-4
+        assert err < tol, (name, err)
+    # the switch: SRF_TRAIN_FUSED=0 runs the same layer as separate autograd nodes
+    os.environ["SRF_TRAIN_FUSED"] = "0"
+    try:
+        y2 = dense.conv_bn_act(conv, bn, relu, x)
+        assert type(y2.grad_fn).__name__ != "_ConvAffineReluBackward"
+        assert float((y2 - got[0]).abs().max()) / float(got[0].abs().max()) < 1e-4
+    finally:
+        del os.environ["SRF_TRAIN_FUSED"]
+
+
+def test_affine_relu_bwd_kernel(dev):
+    g = torch.Generator().manual_seed(23)
+    for (N, H, W, C, relu) in ((2, 29, 50, 224, True), (1, 7, 5, 1024, True), (3, 11, 13, 40, False), (1, 1, 3, 4, True)):
+        gy = torch.randn(N, H, W, C, generator=g).to(dev)
+        y = torch.randn(N, H, W, C, generator=g).to(dev)
+        if relu:
+            y = torch.relu(y)
+        s = (torch.rand(C, generator=g) + 0.5).to(dev)
+        gz, sums = ops.nhwc_affine_relu_bwd(gy, y, s, relu)
+        gu = gy * (y > 0) if relu else gy
+        assert torch.equal(gz, gu * s)
+        np.testing.assert_allclose(sums[0].cpu().numpy(), gu.double().sum(dim=(0, 1, 2)).cpu().numpy(), rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(sums[1].cpu().numpy(), (gu.double() * y.double()).sum(dim=(0, 1, 2)).cpu().numpy(), rtol=1e-5, atol=1e-4)
+        gz2, sums2 = ops.nhwc_affine_relu_bwd(gy, y, s, relu)
+        assert torch.equal(sums, sums2)      # fixed summation order
