@@ -43,8 +43,9 @@ TARGETS = {
                  "hard voxelization + per-voxel mean (K1 + a3): insert, first-seen numbering scan, gather; per frame", 3),
     "rulebook": (["tools/prof_lidar_frame.py", "3"], ("srf_bm_", "srf_scan_reduce_k<BmPop", "srf_scan_apply_k<BmPop"),
                  "bitmap-rank rulebooks of the whole encoder (K4): mark / rank scans / place / subm / strided mark, emit, pairs; per frame", 3),
-    "densify": (["tools/prof_lidar_frame.py", "3"], ("srf_densify_k",),
-                "densify (K6) without its zero fill (srf_fill_words_k is shared with other clears); per frame", 3),
+    "densify": (["tools/prof_lidar_frame.py", "3"], ("srf_densify_bev_k",),
+                "dense BEV map (K6: dense() + the (N, C D, H, W) view) written channels-last in one pass from the last level's bitmap, zero cells "
+                "included (srf_densify_bev); per frame", 3),
     "roi": (["tools/prof_lidar_frame.py", "3"], ("srf_roi_extract_k",),
             "multi-level RoIAlign gather (K7), 5 stages x 200 RoIs on the channels-last BEV pyramid; per frame", 3),
     "spconv128": (["tools/bench_spconv.py", "--levels", "4", "--reps", "8"], "srf_spconv_gs_k<4, 128>",
