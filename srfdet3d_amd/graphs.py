@@ -281,6 +281,10 @@ class GraphedFrame:
     def _capture(self, pts, img_metas, sizes, n_cap, img_feats=None, safe=False):
         m = self.model
         caps = {k: self._round(v * self.HEADROOM) for k, v in sizes.items()}
+        if hasattr(m, "pts_middle_encoder") and m.pts_middle_encoder is not None:
+            # the sparse encoder's index-only pass on a second stream pays when the frame is the BEV branch alone; beside the
+            # camera graph the forked graph costs more than it hides (middle_encoders.SparseEncoderCustom._layers)
+            m.pts_middle_encoder.index_stream = img_feats is None
         far = torch.full((n_cap, pts.shape[1]), 1.0e6, dtype=pts.dtype, device=pts.device)  # out of every range: dropped
         static_pts = far.clone()
         static_pts[:pts.shape[0]] = pts

@@ -183,8 +183,21 @@ class _SparseConv(SparseModule):
         return nbr, counts, out_idx, oshape, x.indice_dict.get(("rows", out_idx.data_ptr()))
 
     def forward(self, x, bn=None, relu=False, residual=None):
-        """conv, optionally with an eval-mode BatchNorm1d, residual rows and ReLU fused into the same kernel."""
+        """conv, optionally with an eval-mode BatchNorm1d, residual rows and ReLU fused into the same kernel.
+        An index-only tensor (`x.features is None`) gets the layer's rulebook (and row ranges) built and cached and comes back
+        index-only: the encoder runs that dry pass on a second stream, ahead of the convolutions (middle_encoders.py)."""
         nbr, counts, out_idx, oshape, rows_dev = self._rulebook(x)
+        use_packed = not self.training and self.out_channels >= 32 and self.in_channels % 4 == 0
+        tiles = None
+        if self.subm and use_packed and ops.spconv_tiles_wanted(self.in_channels, self.out_channels) and nbr.shape[1] > 0:
+            # balanced row ranges, one set per rulebook: worth their ~20 us only where several layers share the rulebook
+            # (the SubM layers of a level); a strided conv or conv_out runs on equal-height tiles
+            tkey = ("tiles", nbr.data_ptr(), nbr.shape[1])
+            tiles = x.indice_dict.get(tkey)
+            if tiles is None:
+                tiles = x.indice_dict[tkey] = ops.spconv_tiles(nbr, rows_dev)
+        if x.features is None:
+            return SparseConvTensor(None, out_idx, oshape, x.batch_size, x.indice_dict, rows_dev)
         K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
         w = self.weight.view(K, self.in_channels, self.out_channels)
         alpha = beta = None
@@ -195,7 +208,7 @@ class _SparseConv(SparseModule):
         elif self.bias is not None:
             alpha, beta = torch.ones_like(self.bias), self.bias
         packed = None
-        if not self.training and self.out_channels >= 32 and self.in_channels % 4 == 0:
+        if use_packed:
             vers = (self.weight._version, self.weight.data_ptr())
             cache = getattr(self, "_srf_packed", None)
             if cache is None or cache[0] != vers:
@@ -203,15 +216,6 @@ class _SparseConv(SparseModule):
                     cache = (vers, ops.pack_spconv_weights(w.detach()))
                 self._srf_packed = cache
             packed = cache[1]
-        tiles = None
-        if self.subm and packed is not None and ops.spconv_tiles_wanted(self.in_channels, self.out_channels) and \
-                nbr.shape[1] > 0:
-            # balanced row ranges, one set per rulebook: worth their ~20 us only where several layers share the rulebook
-            # (the SubM layers of a level); a strided conv or conv_out runs on equal-height tiles
-            tkey = ("tiles", nbr.data_ptr(), nbr.shape[1])
-            tiles = x.indice_dict.get(tkey)
-            if tiles is None:
-                tiles = x.indice_dict[tkey] = ops.spconv_tiles(nbr, rows_dev)
         feats = ops.spconv_fwd(x.features, w, nbr, alpha, beta, residual, relu, pair_counts=counts, packed=packed,
                                rows_dev=rows_dev, tiles=tiles, subm=self.subm)
         return SparseConvTensor(feats, out_idx, oshape, x.batch_size, x.indice_dict, rows_dev)
@@ -267,7 +271,8 @@ class SparseSequential(SparseModule):
                 x = m(x)
                 i += 1
             else:
-                x = x.replace_feature(m(x.features)) if isinstance(x, SparseConvTensor) else m(x)
+                if not (isinstance(x, SparseConvTensor) and x.features is None):   # (an index-only dry pass has nothing for it)
+                    x = x.replace_feature(m(x.features)) if isinstance(x, SparseConvTensor) else m(x)
                 i += 1
         return x
 
@@ -289,6 +294,8 @@ class SparseBasicBlock(SparseModule):
 
     def forward(self, x):
         identity = x.features
+        if identity is None:   # index-only dry pass: both layers share the level's rulebook
+            return self.conv2(self.conv1(x))
         if _bn_foldable(self.bn1) and _bn_foldable(self.bn2):
             out = self.conv1(x, bn=self.bn1, relu=True)
             return self.conv2(out, bn=self.bn2, relu=True, residual=identity)

@@ -280,6 +280,15 @@ def test_whole_frame_graph_equals_eager(setup, dev):
         bev_s, counts = gpu.extract_bev_static(torch.cat([p, far]), caps)
         assert torch.equal(bev, bev_s)
         assert all(int(c[1].item()) <= c[2] for c in counts)
+        # ... and does not depend on whether the rulebooks were built by the index-only pass on a second stream (the default
+        # of the static path) or in line with the convolutions
+        import os
+        os.environ["SRF_SPARSE_INDEX_STREAM"] = "0"
+        try:
+            bev_1, _ = gpu.extract_bev_static(torch.cat([p, far]), caps)
+        finally:
+            del os.environ["SRF_SPARSE_INDEX_STREAM"]
+        assert torch.equal(bev_1, bev_s)
     # overflow: capacities sized for a sparse sweep, then a dense one
     old = GraphedFrame.HEADROOM
     GraphedFrame.HEADROOM = 1.0
