@@ -272,7 +272,7 @@ class BitmapLevel:
 
 def bitmap_build(indices, spatial_shape, batch, want_order=True, padded=False):
     """Distinct active sites (A,4) (b,z,y,x) -> (BitmapLevel, order, sorted_indices): row r of the sorted set is
-    original row order[r].  One memset + mark + 3-launch scan + place; no host sync.  padded=True: rows with b < 0 are
+    original row order[r].  One clear + mark + rank scan (three launches; one workgroup for <= 8192 bitmap words) + place; no host sync.  padded=True: rows with b < 0 are
     padding of a capacity-sized set; the valid rows come first in the sorted result, padding stays (-1,...)."""
     indices = _dev(indices, "indices", torch.int32)
     lvl = BitmapLevel(spatial_shape, batch, indices.device)
@@ -689,7 +689,8 @@ def nms_rotated_counted(sorted_boxes_xywhr, n_live, iou_threshold, classes=None)
 def nms_select(boxes, scores, score_thr, capacity):
     """(n, D) boxes, (n, C) scores -> the L = min(n*C, capacity) best (box, class) pairs above score_thr in descending score:
     cand (L, D), top_s (L,), cls (L,) int64, bev (L, 5) for the rotated NMS, m (1,) int32 = pairs above the threshold.
-    One single-workgroup launch (LDS bitonic sort), nothing read back: graph-capturable.  n*C <= 16384."""
+    One single-workgroup launch (pairs above the threshold compacted, rank-sorted in LDS when <= 1024 of them, else a bitonic sort of
+    all pairs), nothing read back: graph-capturable.  n*C <= 16384."""
     boxes = _dev(boxes, "boxes", torch.float32).contiguous()
     scores = _dev(scores, "scores", torch.float32).contiguous()
     n, D = boxes.shape

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _always_split(monkeypatch):
-    """ops.conv1x1_nhwc takes the split kernel only for launches of >= 384 tiles; these tests exercise it on small shapes too"""
+    """ops.conv1x1_nhwc takes the split kernel only for launches of >= ops.GEMM_SPLIT_MIN_TILES (128) tiles; these tests exercise it on small shapes too"""
     monkeypatch.setenv("SRF_GEMM_SPLIT_MIN", "0")
 
 
