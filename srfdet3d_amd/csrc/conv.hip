@@ -1385,22 +1385,26 @@ extern "C" int srf_conv_gemm_nhwc(const float *x, int N, int H, int W, int Cin, 
 #define ST_R 4
 #define ST_C 64
 #define ST_ROWP 130
-__global__ __launch_bounds__(256) void srf_stem_conv_nchw_k(const float *__restrict__ x, int N, int Cin, int H, int W, int Ho, int Wo,
+template <int CIN>   // the input channel count at compile time: the k loop unrolls and its LDS reads batch (a run-time K kept the chain
+                     // offset table -> operand -> MFMA serial per step)
+__global__ __launch_bounds__(256) void srf_stem_conv_nchw_k(const float *__restrict__ x, int N, int Cin_rt, int H, int W, int Ho, int Wo,
                                                            const float *__restrict__ wt, const float *__restrict__ scale,
                                                            const float *__restrict__ shift, int relu, float *__restrict__ y, long long y_ld,
                                                            int tilesX, int tilesY)
 {
     __shared__ float s_p[4 * 9 * ST_ROWP];  // [ci][patch row 0 .. 8][column parity][65]
-    __shared__ float s_w[36][64];           // [k][channel]
+    __shared__ float s_w[36][65];           // [k][channel] (rows padded: the transposing copy below writes a column per lane group)
     __shared__ int s_off[36];               // patch offset of tap k
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int K = Cin * 9, KP = (K + 1) & ~1;
+    constexpr int Cin = CIN, K = CIN * 9, KP = (K + 1) & ~1;
     const int bx = blockIdx.x % tilesX, rest = blockIdx.x / tilesX;
     const int by = rest % tilesY, n = rest / tilesY;
     const int ox0 = bx * ST_C, oy0 = by * ST_R;
+    // weights (Cout, K) -> s_w[k][co]: consecutive lanes read consecutive k of one output channel (runs of K floats; with consecutive
+    // co per lane every load instruction touched 64 lines K floats apart, ~1500 line lookups per workgroup for 7 KB)
     for (int e = tid; e < KP * 64; e += 256) {
-        const int k = e >> 6, co = e & 63;
+        const int co = e / KP, k = e - co * KP;
         s_w[k][co] = k < K ? wt[(size_t)co * K + k] : 0.f;
     }
     if (tid < KP) {
@@ -1409,15 +1413,27 @@ __global__ __launch_bounds__(256) void srf_stem_conv_nchw_k(const float *__restr
         s_off[tid] = (ci * 9 + ky) * ST_ROWP + (kx & 1) * 65 + (kx >> 1);
     }
     {
+        // the patch: all of a thread's loads first (a constant trip count, fully unrolled), then its LDS stores.  Written as
+        // `for (e = tid; e < total; e += 256) s_p[...] = xn[...]` the loop kept its run-time trip count and every iteration waited
+        // for its own 4-byte load: 14 memory latencies in a row per workgroup, 290 us for the layer at 2.3 TB/s.
         const int cols = 2 * ST_C + 1, total = Cin * 9 * cols;
         const float *xn = x + (size_t)n * Cin * H * W;
-        for (int e = tid; e < total; e += 256) {
+        constexpr int NL = (CIN * 9 * (2 * ST_C + 1) + 255) / 256;
+        float v[NL];
+        int dst[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * 256;
             const int r = e / cols, c = e - r * cols;
             const int ci = r / 9, iyl = r - ci * 9;
             const int iy = 2 * oy0 - 1 + iyl, ix = 2 * ox0 - 1 + c;
-            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-            s_p[r * ST_ROWP + (c & 1) * 65 + (c >> 1)] = ok ? xn[((size_t)ci * H + iy) * W + ix] : 0.f;
+            const bool ok = e < total && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            v[i] = ok ? xn[((size_t)ci * H + iy) * W + ix] : 0.f;
+            dst[i] = e < total ? r * ST_ROWP + (c & 1) * 65 + (c >> 1) : -1;
         }
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+            if (dst[i] >= 0) s_p[dst[i]] = v[i];
     }
     __syncthreads();
     f32x16 acc[2][2];
@@ -1427,8 +1443,9 @@ __global__ __launch_bounds__(256) void srf_stem_conv_nchw_k(const float *__restr
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int ksteps = KP >> 1;
+    constexpr int ksteps = KP >> 1;
     const int a_base = 2 * wave * ST_ROWP + li;   // output row `wave` of the tile: patch rows 2 wave + ky
+#pragma unroll
     for (int s2 = 0; s2 < ksteps; ++s2) {
         const int k = 2 * s2 + lh;
         const int off = s_off[k] + a_base;
@@ -1481,8 +1498,16 @@ extern "C" int srf_stem_conv_nchw(const float *x, int N, int Cin, int H, int W, 
     const int tilesX = srf_ceil_div(Wo, ST_C), tilesY = srf_ceil_div(Ho, ST_R);
     const long long blocks = (long long)N * tilesX * tilesY;
     if (blocks >= (1ll << 31)) return SRF_EUNSUPPORTED;
-    hipLaunchKernelGGL(srf_stem_conv_nchw_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, N, Cin, H, W, Ho, Wo, Wt, scale, shift,
-                       relu, y, y_ld, tilesX, tilesY);
+#define SRF_STEM(C)                                                                                                             \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_stem_conv_nchw_k<C>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, N, Cin, H, W, Ho, Wo, \
+                       Wt, scale, shift, relu, y, y_ld, tilesX, tilesY)
+    switch (Cin) {
+    case 1: SRF_STEM(1); break;
+    case 2: SRF_STEM(2); break;
+    case 3: SRF_STEM(3); break;
+    default: SRF_STEM(4); break;
+    }
+#undef SRF_STEM
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

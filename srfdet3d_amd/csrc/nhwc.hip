@@ -120,36 +120,55 @@ extern "C" int srf_nhwc_colmean(const float *x, long long x_ld, int N, long long
 // ---------------------------------------------------------------------------------------------------------------------
 // MaxPool2d(kernel 3, stride 2, ceil_mode=True, no padding): windows that reach past the bottom / right edge are clipped.
 // ---------------------------------------------------------------------------------------------------------------------
+// One thread = a 2 x 2 block of outputs x 4 channels: its 5 x 5 input pixels are loaded once (25 float4 instead of the 36 that
+// four independent windows read: the kernel is bound by the loads it issues, not by HBM) and reduced as three-tap maxima
+// along x, then along y -- max is exact, the result is the same whatever the order.
 __global__ __launch_bounds__(256) void srf_nhwc_maxpool3s2_k(const float *__restrict__ x, long long x_ld, int N, int H, int W, int Cq, int Ho,
                                                              int Wo, float *__restrict__ y, long long y_ld)
 {
+    const int Ho2 = (Ho + 1) >> 1, Wo2 = (Wo + 1) >> 1;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)N * Ho * Wo * Cq;
+    const long long total = (long long)N * Ho2 * Wo2 * Cq;
     if (t >= total) return;
     const int cq = (int)(t % Cq);
     long long r = t / Cq;
-    const int xo = (int)(r % Wo);
-    r /= Wo;
-    const int yo = (int)(r % Ho), n = (int)(r / Ho);
+    const int xb = (int)(r % Wo2);
+    r /= Wo2;
+    const int yb = (int)(r % Ho2), n = (int)(r / Ho2);
     const float NEG = -__builtin_inff();
-    f32x4n m = {NEG, NEG, NEG, NEG};
+    const f32x4n neg = {NEG, NEG, NEG, NEG};
+    const int yi0 = 4 * yb, xi0 = 4 * xb;
+    const float *base = x + ((long long)n * H * W) * x_ld + cq * 4;
+    f32x4n h[5][2];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-        const int yi = 2 * yo + dy;
-        if (yi >= H) break;
+    for (int dy = 0; dy < 5; ++dy) {
+        const int yi = yi0 + dy;
+        f32x4n v[5];
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int xi = 2 * xo + dx;
-            if (xi < W) {
-                const f32x4n v = *reinterpret_cast<const f32x4n *>(x + (((long long)n * H + yi) * W + xi) * x_ld + cq * 4);
-                m[0] = fmaxf(m[0], v[0]);
-                m[1] = fmaxf(m[1], v[1]);
-                m[2] = fmaxf(m[2], v[2]);
-                m[3] = fmaxf(m[3], v[3]);
-            }
+        for (int dx = 0; dx < 5; ++dx) {
+            const int xi = xi0 + dx;
+            v[dx] = (yi < H && xi < W) ? *reinterpret_cast<const f32x4n *>(base + ((long long)yi * W + xi) * x_ld) : neg;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            h[dy][0][c] = fmaxf(fmaxf(v[0][c], v[1][c]), v[2][c]);
+            h[dy][1][c] = fmaxf(fmaxf(v[2][c], v[3][c]), v[4][c]);
         }
     }
-    *reinterpret_cast<f32x4n *>(y + (((long long)n * Ho + yo) * Wo + xo) * y_ld + cq * 4) = m;
+#pragma unroll
+    for (int oy = 0; oy < 2; ++oy) {
+        const int yo = 2 * yb + oy;
+        if (yo >= Ho) break;
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox) {
+            const int xo = 2 * xb + ox;
+            if (xo >= Wo) continue;
+            f32x4n m;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) m[c] = fmaxf(fmaxf(h[2 * oy][ox][c], h[2 * oy + 1][ox][c]), h[2 * oy + 2][ox][c]);
+            *reinterpret_cast<f32x4n *>(y + (((long long)n * Ho + yo) * Wo + xo) * y_ld + cq * 4) = m;
+        }
+    }
 }
 
 static inline int srf_pool_out(int H)
@@ -168,7 +187,7 @@ extern "C" int srf_nhwc_maxpool3s2_ceil(const float *x, long long x_ld, int N, i
     if (!x || !y) return SRF_EINVAL;
     if ((C & 3) || (x_ld & 3) || (y_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return SRF_EUNSUPPORTED;
     const int Ho = srf_pool_out(H), Wo = srf_pool_out(W);
-    const long long total = (long long)N * Ho * Wo * (C / 4);
+    const long long total = (long long)N * ((Ho + 1) / 2) * ((Wo + 1) / 2) * (C / 4);
     hipLaunchKernelGGL(srf_nhwc_maxpool3s2_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld, N, H, W, C / 4, Ho, Wo,
                        y, y_ld);
     SRF_LAUNCH_CHECK();
