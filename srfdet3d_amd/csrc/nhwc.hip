@@ -239,54 +239,76 @@ extern "C" int srf_nhwc_upsample_add(const float *lat, long long l_ld, const flo
 // generator on the camera levels.  Taps summed in (ky, kx) order like srf_dwconv3x3s2_k; weights w (C, 3, 3).
 // ---------------------------------------------------------------------------------------------------------------------
 // `side` (N, Ho, Wo, Csq * 4) is copied next to the result (srf_nhwc_dwconv3x3s2_cat): the threads past the convolution's own
-// channel quads move one float4 each.
+// work items move one float4 each.  A convolution thread owns a 2 x 2 block of outputs x 4 channels: its 5 x 5 input pixels
+// are loaded once (25 float4 instead of the 36 four independent windows read -- on the finest camera level the kernel is
+// bound by the loads it issues); every output still adds its nine taps in (ky, kx) order.
 __global__ __launch_bounds__(256) void srf_nhwc_dwconv3x3s2_k(const float *__restrict__ x, long long x_ld, int N, int H, int W, int Cq, int Ho,
                                                               int Wo, const float *__restrict__ w, const float *__restrict__ scale,
                                                               const float *__restrict__ shift, int relu, float *__restrict__ y, long long y_ld,
                                                               const float *__restrict__ side, long long side_ld, int Csq,
                                                               float *__restrict__ side_out)
 {
+    const int Ho2 = (Ho + 1) >> 1, Wo2 = (Wo + 1) >> 1;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int Ct = Cq + Csq;
-    const long long total = (long long)N * Ho * Wo * Ct;
-    if (t >= total) return;
-    const int cq = (int)(t % Ct);
-    long long r = t / Ct;
-    if (cq >= Cq) {  // r = (n, yo, xo) linearised = the pixel row of both `side` and the output buffer
-        *reinterpret_cast<f32x4n *>(side_out + r * y_ld + (cq - Cq) * 4) = *reinterpret_cast<const f32x4n *>(side + r * side_ld + (cq - Cq) * 4);
+    const long long conv_total = (long long)N * Ho2 * Wo2 * Cq;
+    if (t >= conv_total) {
+        const long long u = t - conv_total;
+        if (u >= (long long)N * Ho * Wo * Csq) return;
+        const long long pix = u / Csq;   // (n, yo, xo) linearised = the pixel row of both `side` and the output buffer
+        const int sq = (int)(u - pix * Csq);
+        *reinterpret_cast<f32x4n *>(side_out + pix * y_ld + sq * 4) = *reinterpret_cast<const f32x4n *>(side + pix * side_ld + sq * 4);
         return;
     }
-    const int xo = (int)(r % Wo);
-    r /= Wo;
-    const int yo = (int)(r % Ho), n = (int)(r / Ho);
+    const int cq = (int)(t % Cq);
+    long long r = t / Cq;
+    const int xb = (int)(r % Wo2);
+    r /= Wo2;
+    const int yb = (int)(r % Ho2), n = (int)(r / Ho2);
     float k[4][9];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int j = 0; j < 9; ++j) k[c][j] = w[(cq * 4 + c) * 9 + j];
-    f32x4n acc = {0.f, 0.f, 0.f, 0.f};
+    const float *base = x + ((long long)n * H * W) * x_ld + cq * 4;
+    const int yi0 = 4 * yb - 1, xi0 = 4 * xb - 1;
+    f32x4n v[5][5];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int yi = 2 * yo - 1 + ky;
+    for (int dy = 0; dy < 5; ++dy) {
+        const int yi = yi0 + dy;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int xi = 2 * xo - 1 + kx;
-            f32x4n v = {0.f, 0.f, 0.f, 0.f};
-            if (yi >= 0 && yi < H && xi >= 0 && xi < W)
-                v = *reinterpret_cast<const f32x4n *>(x + (((long long)n * H + yi) * W + xi) * x_ld + cq * 4);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = __fmaf_rn(v[c], k[c][ky * 3 + kx], acc[c]);
+        for (int dx = 0; dx < 5; ++dx) {
+            const int xi = xi0 + dx;
+            f32x4n z = {0.f, 0.f, 0.f, 0.f};
+            if (yi >= 0 && yi < H && xi >= 0 && xi < W) z = *reinterpret_cast<const f32x4n *>(base + ((long long)yi * W + xi) * x_ld);
+            v[dy][dx] = z;
         }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        float o = acc[c];
-        if (scale) o = __fmaf_rn(o, scale[cq * 4 + c], shift ? shift[cq * 4 + c] : 0.f);
-        else if (shift) o = __fadd_rn(o, shift[cq * 4 + c]);
-        if (relu) o = fmaxf(o, 0.f);
-        acc[c] = o;
+    for (int oy = 0; oy < 2; ++oy) {
+        const int yo = 2 * yb + oy;
+        if (yo >= Ho) break;
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox) {
+            const int xo = 2 * xb + ox;
+            if (xo >= Wo) continue;
+            f32x4n acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = __fmaf_rn(v[2 * oy + ky][2 * ox + kx][c], k[c][ky * 3 + kx], acc[c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float o = acc[c];
+                if (scale) o = __fmaf_rn(o, scale[cq * 4 + c], shift ? shift[cq * 4 + c] : 0.f);
+                else if (shift) o = __fadd_rn(o, shift[cq * 4 + c]);
+                if (relu) o = fmaxf(o, 0.f);
+                acc[c] = o;
+            }
+            *reinterpret_cast<f32x4n *>(y + (((long long)n * Ho + yo) * Wo + xo) * y_ld + cq * 4) = acc;
+        }
     }
-    *reinterpret_cast<f32x4n *>(y + (((long long)n * Ho + yo) * Wo + xo) * y_ld + cq * 4) = acc;
 }
 
 extern "C" int srf_nhwc_dwconv3x3s2(const float *x, long long x_ld, int N, int H, int W, int C, const float *w, const float *scale,
@@ -297,7 +319,7 @@ extern "C" int srf_nhwc_dwconv3x3s2(const float *x, long long x_ld, int N, int H
     if (!x || !w || !y) return SRF_EINVAL;
     if ((C & 3) || (x_ld & 3) || (y_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return SRF_EUNSUPPORTED;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long long total = (long long)N * Ho * Wo * (C / 4);
+    const long long total = (long long)N * ((Ho + 1) / 2) * ((Wo + 1) / 2) * (C / 4);
     hipLaunchKernelGGL(srf_nhwc_dwconv3x3s2_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld, N, H, W, C / 4, Ho, Wo,
                        w, scale, shift, relu, y, y_ld, (const float *)nullptr, 0LL, 0, (float *)nullptr);
     SRF_LAUNCH_CHECK();
@@ -318,7 +340,7 @@ extern "C" int srf_nhwc_dwconv3x3s2_cat(const float *x, long long x_ld, int N, i
         ((uintptr_t)side & 15) || ((uintptr_t)side_out & 15))
         return SRF_EUNSUPPORTED;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long long total = (long long)N * Ho * Wo * ((C + Cs) / 4);
+    const long long total = (long long)N * ((Ho + 1) / 2) * ((Wo + 1) / 2) * (C / 4) + (long long)N * Ho * Wo * (Cs / 4);
     hipLaunchKernelGGL(srf_nhwc_dwconv3x3s2_k, dim3(srf_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, x_ld, N, H, W, C / 4, Ho, Wo,
                        w, scale, shift, relu, y, y_ld, side, side_ld, Cs / 4, side_out);
     SRF_LAUNCH_CHECK();
