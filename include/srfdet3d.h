@@ -542,6 +542,13 @@ size_t srf_nhwc_affine_relu_bwd_workspace_bytes(long long M, int C);
 int srf_nhwc_affine_relu_bwd(const float *gy, long long gy_ld, const float *y, long long y_ld, long long M, int C, const float *scale /*or NULL*/,
                              int relu, float *gz, long long gz_ld, float *sums /*2 C*/, void *workspace, size_t workspace_bytes,
                              srf_stream_t stream);
+/* srf_ese_apply: the end of VoVNet's eSEModule (vovnet.py:165-177) applied to an OSA block's concat output (:225-228) in one launch:
+ * gate[n][c] = hsigmoid(fc(mean[n])) (the bits of srf_ese_gate) and y = x * gate (+ residual = the block's identity input), the bits of
+ * srf_nhwc_affine with a per-sample scale.  x / residual / y: (N * HW) pixel rows of x_ld / r_ld / y_ld floats; W (C x C), bias (C) the
+ * fc = 1x1 conv; gate_out (N x C) optional.  C % 64 == 0, C <= 1024. */
+int srf_ese_apply(const float *x, long long x_ld, int N, long long HW, int C, const float *mean, const float *W, const float *bias,
+                  const float *residual /*or NULL*/, long long r_ld, float *y, long long y_ld, float *gate_out /*or NULL*/,
+                  srf_stream_t stream);
 int srf_nhwc_pool_sum(const float *x, long long x_ld, int B, int n_cam, int H, int W, int C, int Ho, int Wo, float *out, int out_ld,
                       srf_stream_t stream);
 int srf_dpg_mix(const float *wl, const float *wi /*or NULL*/, int B, int E, int P, const float *boxes_w, int D, const float *feats_w,

@@ -58,6 +58,99 @@ extern "C" int srf_nhwc_affine(const float *x, long long x_ld, int N, long long 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// srf_ese_apply: the end of VoVNet's eSE module (vovnet.py:165-177, :225-228) as ONE launch: gate = hsigmoid(fc(mean)) and
+// y = x * gate (+ identity).  The gate GEMV used to be its own launch between the pooled convolution and this pass -- 14
+// microsecond-sized launches per frame on the camera graph's critical path, each costing its launch latency.  Here a workgroup
+// owns (64 channels, a range of pixel rows, an image): its four waves first compute their 64 gates exactly as
+// srf_linear_gemv_k does (one wave per output: float4 fma chains over k = 4 lane + 256 j, xor-shuffle sum, + bias, relu6(v + 3) / 6
+// -- the same bits), ~3 us hidden behind the other workgroups' streaming, then stream their rows (multiply, then add: the
+// two roundings of srf_nhwc_affine_k).  C % 64 == 0, C <= 1024.  Measured on the LC frame: slower than the two launches it replaces
+// (29.27 -> 28.93 frames/s): the 64-channel slices stream worse than the linear pass; kept as an opt-in (SRF_ESE_FUSED=1), tested.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void srf_ese_apply_k(const float *__restrict__ x, long long x_ld, long long HW, int C,
+                                                       const float *__restrict__ mean, const float *__restrict__ W,
+                                                       const float *__restrict__ bias, const float *__restrict__ res, long long r_ld,
+                                                       float *__restrict__ y, long long y_ld, float *__restrict__ gate_out,
+                                                       long long rows_per_part)
+{
+    __shared__ float s_gate[64];
+    const int slice = blockIdx.x, n = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const float *mv = mean + (size_t)n * C;
+        f32x4n xv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = lane * 4 + 256 * i;
+            xv[i] = k < C ? *reinterpret_cast<const f32x4n *>(mv + k) : f32x4n{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int j = 0; j < 16; ++j) {
+            const int co = slice * 64 + wave * 16 + j;
+            const float *w = W + (size_t)co * C;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = lane * 4 + 256 * i;
+                if (k < C) {
+                    const f32x4n wv = *reinterpret_cast<const f32x4n *>(w + k);
+                    acc = __fmaf_rn(xv[i][3], wv[3], __fmaf_rn(xv[i][2], wv[2], __fmaf_rn(xv[i][1], wv[1], __fmaf_rn(xv[i][0], wv[0], acc))));
+                }
+            }
+            float v = acc;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane == 0) {
+                v += bias ? bias[co] : 0.f;
+                v = __fadd_rn(v, 3.0f);
+                v = v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
+                v = __fdiv_rn(v, 6.0f);
+                s_gate[wave * 16 + j] = v;
+                if (gate_out && blockIdx.y == 0) gate_out[(size_t)n * C + co] = v;
+            }
+        }
+    }
+    __syncthreads();
+    const int q = tid & 15, rl = tid >> 4;
+    const f32x4n g = *reinterpret_cast<const f32x4n *>(s_gate + q * 4);
+    const long long r0 = (long long)blockIdx.y * rows_per_part;
+    const long long r1 = r0 + rows_per_part < HW ? r0 + rows_per_part : HW;
+    const int ch = slice * 64 + q * 4;
+    for (long long r = r0 + rl; r < r1; r += 16) {
+        const long long p = (long long)n * HW + r;
+        f32x4n v = *reinterpret_cast<const f32x4n *>(x + p * x_ld + ch);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = __fmul_rn(v[c], g[c]);
+        if (res) {
+            const f32x4n rv = *reinterpret_cast<const f32x4n *>(res + p * r_ld + ch);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = __fadd_rn(v[c], rv[c]);
+        }
+        *reinterpret_cast<f32x4n *>(y + p * y_ld + ch) = v;
+    }
+}
+
+extern "C" int srf_ese_apply(const float *x, long long x_ld, int N, long long HW, int C, const float *mean, const float *W, const float *bias,
+                             const float *residual, long long r_ld, float *y, long long y_ld, float *gate_out, srf_stream_t stream)
+{
+    if (N < 0 || HW < 0 || C <= 0 || x_ld < C || y_ld < C || (residual && r_ld < C)) return SRF_EINVAL;
+    if (N == 0 || HW == 0) return SRF_OK;
+    if (!x || !y || !mean || !W) return SRF_EINVAL;
+    if ((C & 63) || C > 1024 || N > 65535 || (x_ld & 3) || (y_ld & 3) || (r_ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) ||
+        ((uintptr_t)residual & 15) || ((uintptr_t)mean & 15) || ((uintptr_t)W & 15))
+        return SRF_EUNSUPPORTED;
+    // row ranges: enough workgroups to fill the chip a few times over, at least 256 rows each (the gate prologue is ~3 us)
+    long long parts = (HW + 255) / 256;
+    const long long want = 4096 / ((long long)(C / 64) * N) + 1;
+    parts = parts > want ? want : parts;
+    parts = parts < 1 ? 1 : (parts > 65535 ? 65535 : parts);
+    const long long rows_per_part = (HW + parts - 1) / parts;
+    hipLaunchKernelGGL(srf_ese_apply_k, dim3(C / 64, (unsigned)parts, N), dim3(256), 0, (hipStream_t)stream, x, x_ld, HW, C, mean, W, bias,
+                       residual, r_ld, y, y_ld, gate_out, rows_per_part);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // mean over the pixels of every (sample, channel): AdaptiveAvgPool2d(1) of the eSE module.  Deterministic two-level sum:
 // level 1: grid (P chunks of pixels, N); a workgroup = 256 threads = (C / 4 channel quads) x (256 / (C / 4) pixel lanes)
 // when C <= 1024; each thread sums its pixels in order, the pixel lanes are combined through LDS in a fixed order;

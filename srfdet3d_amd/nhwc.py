@@ -225,8 +225,12 @@ def _osa_forward(m, buf, cin, dst):
         src, off = out, off + w
     conv, bn = _cbr(m.concat)
     t, mean = conv1x1(buf, conv, bn, True, pool=True)     # eSE average pool from the convolution's own epilogue
-    gate = ops.ese_gate(mean, m.ese.fc.weight, m.ese.fc.bias)
-    ops.nhwc_affine(t, scale=gate, residual=buf[..., :cin] if m.identity else None, out=dst)
+    res = buf[..., :cin] if m.identity else None
+    if ops.ese_apply_supported(t, t.shape[3]):
+        ops.ese_apply(t, mean, m.ese.fc.weight, m.ese.fc.bias, residual=res, out=dst)   # gate GEMV + multiply (+ identity): one launch
+    else:
+        gate = ops.ese_gate(mean, m.ese.fc.weight, m.ese.fc.bias)
+        ops.nhwc_affine(t, scale=gate, residual=res, out=dst)
     return dst
 
 

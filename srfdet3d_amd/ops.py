@@ -4,6 +4,7 @@ torch is used here only to own device memory and to name the current HIP stream;
 kernel of libsrfdet3d_hip.so.  All functions raise on CPU tensors (there is no CPU fallback).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -868,6 +869,29 @@ def ese_gate(mean, weight, bias):
         n1 = min(N, n0 + 8)
         check(_lib.lib().srf_ese_gate(_ptr(mean[n0:n1]), n1 - n0, C, _ptr(w), _ptr(bias), _ptr(gate[n0:n1]), _stream()), "ese_gate")
     return gate
+
+
+def ese_apply_supported(x, C):
+    """Opt-in (SRF_ESE_FUSED=1): measured on the LC frame the fused launch LOSES 0.34 frames/s (29.27 -> 28.93, same box, three alternating
+    runs) -- a workgroup's 64-channel slices stream worse than srf_nhwc_affine's linear pass and every workgroup starts with ~3 us of
+    gate arithmetic; the separate gate GEMV (14 launches of ~14 us on the camera graph) stays the default."""
+    return C % 64 == 0 and C <= 1024 and x.shape[0] <= 65535 and os.environ.get("SRF_ESE_FUSED", "0") == "1"
+
+
+def ese_apply(x, mean, weight, bias, residual=None, out=None, want_gate=False):
+    """VoVNet's eSE gate + its application in one launch: out = x * hsigmoid(fc(mean)) (+ residual) on NHWC slices (N, H, W, C);
+    the same bits as `ese_gate` followed by `nhwc_affine(x, scale=gate, residual=...)`.  -> out (, gate (N, C))."""
+    x_ld = nhwc_ld(x)
+    N, H, W, C = x.shape
+    mean = _dev(mean, "mean", torch.float32).contiguous()
+    w = _dev(weight, "weight", torch.float32).reshape(C, C).contiguous()
+    if out is None:
+        out = _empty((N, H, W, C), torch.float32, x.device)
+    gate = _empty((N, C), torch.float32, x.device) if want_gate else None
+    check(_lib.lib().srf_ese_apply(_ptr(x), x_ld, N, H * W, C, _ptr(mean), _ptr(w), _ptr(bias), _ptr(residual),
+                                   nhwc_ld(residual) if residual is not None else 0, _ptr(out), nhwc_ld(out), _ptr(gate), _stream()),
+          "ese_apply")
+    return (out, gate) if want_gate else out
 
 
 def maxpool3s2_ceil(x):

@@ -208,3 +208,25 @@ def test_densify_bev_is_dense_view_channels_last(dev):
     pad = torch.cat([sidx, torch.full((100, 4), -1, dtype=torch.int32, device=dev)])
     padf = torch.cat([sf, torch.full((100, C), float("nan"), device=dev)])
     assert torch.equal(ops.densify_bev(padf, lvl, B, [D, H, W]), ref)
+
+
+def test_ese_apply_equals_gate_then_affine(dev):
+    """srf_ese_apply (gate GEMV + multiply + identity add in one launch) against srf_ese_gate followed by srf_nhwc_affine: same bits"""
+    from srfdet3d_amd import ops
+    g = torch.Generator().manual_seed(29)
+    for (N, H, W, C, ident) in ((6, 29, 50, 1024, True), (2, 58, 100, 768, True), (3, 17, 23, 256, False), (1, 5, 3, 512, True), (1, 300, 9, 64, False)):
+        wide = torch.randn(N, H, W, C + 64, generator=g).to(dev)
+        x = wide[..., 32:32 + C] if C % 4 == 0 else wide[..., :C]        # a channel slice of a wider pixel-major buffer
+        mean = torch.randn(N, C, generator=g).to(dev)
+        w = (torch.randn(C, C, 1, 1, generator=g) * 0.05).to(dev)
+        b = torch.randn(C, generator=g).to(dev)
+        res = torch.randn(N, H, W, C, generator=g).to(dev) if ident else None
+        gate = ops.ese_gate(mean, w, b)
+        ref = ops.nhwc_affine(x, scale=gate, residual=res)
+        out = torch.full((N, H, W, C), float("nan"), device=dev)
+        got, gate2 = ops.ese_apply(x, mean, w, b, residual=res, out=out, want_gate=True)
+        assert got.data_ptr() == out.data_ptr() and torch.equal(gate2, gate) and torch.equal(out, ref)
+        # the definition in torch: hsigmoid(fc(mean)) gate, multiply, identity add
+        tg = torch.nn.functional.hardsigmoid(mean @ w.view(C, C).t() + b)
+        tref = x * tg.view(N, 1, 1, C) + (res if ident else 0)
+        np.testing.assert_allclose(out.cpu().numpy(), tref.cpu().numpy(), rtol=1e-5, atol=1e-5)
