@@ -16,6 +16,8 @@
 #define SRF_MAX_POOLED 8
 #define SRF_MAX_SR 4
 
+#define SRF_ROI_NC 4   /* channels per thread whose running sums srf_roi_extract_k keeps in registers (C <= 4 x 128) */
+
 struct RoiLevels {
     srf_featmap lv[SRF_MAX_LEVELS];
     int num;
@@ -42,6 +44,18 @@ __global__ __launch_bounds__(128) void srf_roi_extract_k(RoiLevels L, int C, con
     __shared__ float s_w[SRF_MAX_POOLED * SRF_MAX_SR * SRF_MAX_SR][4];
     __shared__ int s_lvl;
     const int r_out = blockIdx.x, ph = blockIdx.y;
+    // The running sums over the n_sum RoIs live in registers (up to SRF_ROI_NC channels per thread) and are written once; a RoI
+    // with no sample inside its map -- a proposal is seen by one or two of the six cameras -- is skipped as a whole (it adds +0).
+    // Before: every camera added its result into the output element in global memory, 7 read-modify-writes per thread and camera,
+    // and walked all 28 samples of the invisible ones too: 61 -> 42 us per stage for 200 proposals x 6 cameras.  (Tried on top and
+    // dropped: the pooled size and sampling ratio as template parameters with the bin / sample loops unrolled and every tap loaded
+    // unconditionally -- 73 us: the 112 64-bit offsets of a thread no longer fit in registers.)
+    float run[SRF_ROI_NC][SRF_MAX_POOLED];
+#pragma unroll
+    for (int i = 0; i < SRF_ROI_NC; ++i)
+#pragma unroll
+        for (int j = 0; j < SRF_MAX_POOLED; ++j) run[i][j] = 0.0f;
+    const bool in_regs = C <= SRF_ROI_NC * (int)blockDim.x && pooled <= SRF_MAX_POOLED;
     for (int sidx = 0; sidx < n_sum; ++sidx) {
     const int r = sidx * R + r_out;
     if (sidx > 0) __syncthreads();   // the previous RoI's sample table is no longer read
@@ -56,6 +70,7 @@ __global__ __launch_bounds__(128) void srf_roi_extract_k(RoiLevels L, int C, con
     const int n = (int)b[0];
     const int nsamp = pooled * sr * sr;
     const bool valid_n = n >= 0 && n < f.N;
+    bool any_w = false;
     if (threadIdx.x < nsamp) {
         const int pw = threadIdx.x / (sr * sr), iy = (threadIdx.x / sr) % sr, ix = threadIdx.x % sr;
         const float x1 = __fsub_rn(__fmul_rn(b[1], f.spatial_scale), 0.5f), y1 = __fsub_rn(__fmul_rn(b[2], f.spatial_scale), 0.5f);
@@ -102,10 +117,13 @@ __global__ __launch_bounds__(128) void srf_roi_extract_k(RoiLevels L, int C, con
         s_w[threadIdx.x][1] = w2;
         s_w[threadIdx.x][2] = w3;
         s_w[threadIdx.x][3] = w4;
+        any_w = w1 != 0.f || w2 != 0.f || w3 != 0.f || w4 != 0.f;
     }
-    __syncthreads();
+    const int live = __syncthreads_or(any_w ? 1 : 0);
+    if (in_regs && !live) continue;   // block-uniform: nothing of this RoI lies inside its map
     const float count = (float)(sr * sr);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    int ci = 0;
+    for (int c = threadIdx.x; c < C; c += blockDim.x, ++ci) {
         const float *plane = f.data + (long long)c * f.stride_c;
         for (int pw = 0; pw < pooled; ++pw) {
             float acc = 0.0f;
@@ -121,11 +139,32 @@ __global__ __launch_bounds__(128) void srf_roi_extract_k(RoiLevels L, int C, con
                 acc = __fadd_rn(acc, v);
             }
             const float res = __fdiv_rn(acc, count);
-            float *dst = out + (long long)r_out * so_r + (long long)c * so_c + (long long)(ph * pooled + pw) * so_b;
-            // the running sum over the n_sum RoIs lives in the output element itself: written by this thread only, in order
-            *dst = (accumulate || sidx > 0) ? __fadd_rn(*dst, res) : res;
+            if (in_regs) {
+#pragma unroll
+                for (int i = 0; i < SRF_ROI_NC; ++i)
+#pragma unroll
+                    for (int j = 0; j < SRF_MAX_POOLED; ++j)
+                        if (i == ci && j == pw) run[i][j] = __fadd_rn(run[i][j], res);   // (constant indices: the array stays in registers)
+            } else {
+                float *dst = out + (long long)r_out * so_r + (long long)c * so_c + (long long)(ph * pooled + pw) * so_b;
+                // the running sum over the n_sum RoIs lives in the output element itself: written by this thread only, in order
+                *dst = (accumulate || sidx > 0) ? __fadd_rn(*dst, res) : res;
+            }
         }
     }
+    }
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < SRF_ROI_NC; ++i) {
+            const int c = threadIdx.x + i * (int)blockDim.x;
+            if (c >= C) break;
+#pragma unroll
+            for (int j = 0; j < SRF_MAX_POOLED; ++j) {
+                if (j >= pooled) break;
+                float *dst = out + (long long)r_out * so_r + (long long)c * so_c + (long long)(ph * pooled + j) * so_b;
+                *dst = accumulate ? __fadd_rn(*dst, run[i][j]) : run[i][j];
+            }
+        }
     }
 }
 
