@@ -155,7 +155,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ops.KERNEL_TIMING = {"spconv": [], "wino": [], "gemm": [], "gsplit": [], "w43x": [], "w43m": []}  # HIP-event pairs around every launch of the timed region
+    ops.KERNEL_TIMING = {"spconv": [], "wino": [], "gemm": [], "gsplit": [], "cgemm": [], "w43x": [], "w43m": []}  # HIP-event pairs around every launch of the timed region
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -172,7 +172,8 @@ def main():
                            "replay as one hipGraph; per-launch times inside it: profiles/)")
         with torch.no_grad():
             for i in range(5):
-                model.extract_bev([frames[(rank + i) % n_pool]])
+                # + SECOND and the BEV FPN: their GEMM-shaped layers report which arithmetic route they take (config.gemm_route)
+                model.extract_point_features([frames[(rank + i) % n_pool]])
         torch.cuda.synchronize()
         records = ops.KERNEL_TIMING["spconv"]
     dense_source = roofline_source
@@ -190,6 +191,7 @@ def main():
         model._graphed_img = gi
     wino_rec, gemm_rec, gsplit_rec = ops.KERNEL_TIMING["wino"], ops.KERNEL_TIMING["gemm"], ops.KERNEL_TIMING["gsplit"]
     w43x_rec, w43m_rec = ops.KERNEL_TIMING["w43x"], ops.KERNEL_TIMING["w43m"]
+    cgemm_rec = ops.KERNEL_TIMING["cgemm"]
     ops.KERNEL_TIMING = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -345,6 +347,20 @@ def main():
             roofline = spconv128
         if roofline is not None:
             roofline["stage"] = stage
+        # which GEMM-shaped layers of THIS workload run on which arithmetic (the LiDAR-only lines route SECOND's
+        # stride-2 layer and the finest BEV FPN lateral to the split kernel too): the labels of the launches seen by the event records
+        def _labels(recs, want_split):
+            seen = []
+            for r in recs:
+                if r[2].endswith(" split") == want_split and r[2] not in seen:
+                    seen.append(r[2])
+            return seen
+        gemm_route = dict(rule=f"a 1x1 / strided-3x3 layer runs on srf_gemm_split_k (f32 GEMM on the bf16 MFMA, exact three-way split) when its "
+                               f"launch has >= {os.environ.get('SRF_GEMM_SPLIT_MIN', ops.GEMM_SPLIT_MIN_TILES)} tiles of 128 x 128 and SRF_GEMM_SPLIT != 0, "
+                               "else on the f32 MFMA (k-ordered fma chain)",
+                          split_kernel=[l[:-6] for l in _labels(gsplit_rec + cgemm_rec, True)],
+                          f32_mfma=_labels(gemm_rec + cgemm_rec, False),
+                          source=dense_source)
         # the same frames with the 1x1 convolutions on the f32-MFMA kernels (SRF_GEMM_SPLIT=0): a second model instance with its own
         # graphs, timed like the headline right after it -- so that the line carries both arithmetic routes measured in one run
         f32_mfma_only = None
@@ -410,9 +426,12 @@ def main():
                                img_branch=("channels-last on srf_wino43 / srf_wino3x3 / srf_conv1x1_nhwc" if nhwc.wino43_enabled() else "channels-last on srf_wino3x3 / srf_conv1x1_nhwc") if (model.use_img and nhwc_on) else ("MIOpen" if model.use_img else None),
                                gemm_1x1=(("f32 GEMM on the bf16 MFMA (srf_gemm_split_k): every f32 operand split EXACTLY into three bf16 values, six of "
                                           "the nine exact partial products accumulated in f32, dropped terms < 2^-23 of a product = one f32 "
-                                          "rounding; error vs float64 equal to the f32 fma chain's (tests/test_gpu_gemm_split.py); "
-                                          "SRF_GEMM_SPLIT=0 -> f32_mfma_only") if split_on else "f32 MFMA (k-ordered fma chain)")
+                                          "rounding; error vs float64 equal to the f32 fma chain's (tests/test_gpu_gemm_split.py); exact for "
+                                          "finite operands with 2^-110 <= |x| <= 3.3895e38 (the bf16 maximum) and zero: smaller ones add an "
+                                          "absolute error <= 2^-126 each, larger activations / inf give NaN rows (weights of that size keep the "
+                                          "layer on the f32 MFMA); SRF_GEMM_SPLIT=0 -> f32_mfma_only") if split_on else "f32 MFMA (k-ordered fma chain)")
                                if (model.use_img and nhwc_on) else None,
+                               gemm_route=gemm_route,
                                graph_validation_failures=len(graphs.VALIDATION_LOG),
                                weights="seeded random init, randomised BN statistics",
                                parallelism=f"replica per GPU x{world}, frames sharded, no data-path collective"),

@@ -16,6 +16,23 @@
 // the instruction), deterministic, and within the same bound; tests/test_gpu_gemm_split.py holds it to the f32 chain's own
 // error against float64.  SRF_GEMM_SPLIT=0 (ops.conv1x1_nhwc) keeps these layers on the f32-MFMA kernels.
 //
+// Domain (what "exact split" covers, and what happens outside; tests/test_gpu_gemm_split.py holds every line of this):
+//   * x = xh + xm + xl EXACTLY for every finite x with |x| <= 0x1.FEp127 (the largest bf16, 3.3895e38) whose lowest set bit is
+//     worth >= 2^-133 (the smallest bf16 subnormal): zero, and every |x| >= 2^-110.  Rows that mix magnitudes (2^-60 ... 2^+60 in
+//     one dot product) and sums that cancel to 1e-6 of sum |a b| are inside the domain: the bound is relative to sum |a b|, as the
+//     f32 chain's own.
+//   * tiny operands, |x| < 2^-110 (f32 subnormals included): the low planes fall under the bf16 range and are rounded to the bf16
+//     subnormal grid or flushed, an ABSOLUTE error of at most 2^-126 per operand (times its partner): the result carries an extra
+//     <= 4 x 2^-126 (sum |a| + sum |b|) over the terms in question -- a flush-to-zero-sized effect, below anything a network's
+//     activations can resolve.
+//   * |x| in (3.3895e38, FLT_MAX]: bf16(x) rounds to infinity, the remainders become inf - inf: every output of that row (activation)
+//     or column (weight) is NaN where the f32 chain stays finite.  OUTSIDE the domain.  Weights are checked when they are packed
+//     (ops.gemm_split_weight_in_domain: such a layer stays on the f32-MFMA kernels); activations are not checked -- a value of
+//     3.4e38 behind a BatchNorm means the network has already diverged.
+//   * +-inf / NaN inputs: every output that the f32 chain makes non-finite (inf or NaN) is non-finite here too and vice versa, but
+//     an infinity arrives as NaN (inf - bf16(inf) = NaN in the low planes; inf x 0 in a zero plane) -- same finiteness pattern,
+//     NaN in place of +-inf.
+//
 // Structure (the LDS-staged form of srf_conv1x1_nhwc_k; the bf16 MFMA, unlike the f32 one, leaves the vector ALU to its wave:
 // "an MFMA holds the SIMD's vector issue for 8 of its 32 cycles", MI355X_MICROARCH.md):
 //   * workgroup tile 128 pixels x 128 channels, 4 waves = 2 x 2 wave tiles of 64 x 64 (2 x 2 accumulator tiles), K in chunks of

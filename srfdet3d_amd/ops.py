@@ -1164,9 +1164,25 @@ def pack_conv1x1_nhwc_split_weights(weight):
     nbytes = L.srf_conv1x1_nhwc_split_packed_weight_bytes(Cout, K)
     if nbytes == 0:
         raise ValueError("conv1x1_nhwc: K must be a multiple of 32")
+    if not gemm_split_weight_in_domain(weight):
+        return None     # callers keep such a layer on the f32-MFMA kernels
     packed = _empty((nbytes // 2,), torch.int16, weight.device)
     check(L.srf_conv1x1_nhwc_split_pack_weights(_ptr(weight), Cout, K, _ptr(packed), _stream()), "conv1x1_nhwc_split_pack_weights")
     return packed
+
+
+GEMM_SPLIT_MAX = float.fromhex("0x1.FEp127")   # the largest bf16 (3.3895e38): above it the first plane rounds to infinity
+
+
+def gemm_split_weight_in_domain(weight):
+    """The three-way bf16 split is exact for finite values of magnitude <= GEMM_SPLIT_MAX (csrc/gemm_split.hip, "Domain"); a weight
+    outside that range (larger, infinite or NaN) would turn whole output columns into NaN where the f32 fma chain stays finite or
+    propagates an infinity, so such a layer is kept on the f32-MFMA kernels.  Checked once per packed weight (one reduction and one
+    device -> host read; skipped -- the weight taken as in range -- while a stream capture is running, where a read-back is illegal:
+    the graphs are captured after an eager warm-up that has packed, and checked, every layer)."""
+    if weight.is_cuda and torch.cuda.is_current_stream_capturing():
+        return True
+    return bool((weight.abs().max() <= GEMM_SPLIT_MAX).item()) if weight.numel() else True   # NaN compares False
 
 
 def gemm_split_enabled():
@@ -1225,10 +1241,11 @@ def conv1x1_nhwc(x, packed_weight, Cout, scale=None, shift=None, relu=False, out
     y_ld = nhwc_ld(out)
     L = _lib.lib()
     split = packed_split is not None and gemm_split_wanted(N * H * W, Cout) and max(x_ld, y_ld) * 512 < (1 << 31)
+    if split and callable(packed_split):
+        packed_split = packed_split()
+        split = packed_split is not None     # None: a weight outside the split's exact domain (gemm_split_weight_in_domain)
     direct = not split and packed_direct is not None and conv1x1_direct_wanted(N * H * W, Cout) and max(x_ld, y_ld) * 512 < (1 << 31)
     if split:
-        if callable(packed_split):
-            packed_split = packed_split()
         if packed_split.numel() * 2 != L.srf_conv1x1_nhwc_split_packed_weight_bytes(Cout, K):
             raise ValueError("conv1x1_nhwc: split-packed weight does not match (Cout, K)")
         wp = _ptr(packed_split)
@@ -1434,9 +1451,10 @@ def conv_gemm_nhwc(x, packed_weight, Cout, ksize, stride, pad, scale=None, shift
         raise ValueError("conv_gemm_nhwc: out has the wrong shape")
     L = _lib.lib()
     split = packed_split is not None and gemm_split_wanted(N * Ho * Wo, Cout)
+    if split and callable(packed_split):
+        packed_split = packed_split()
+        split = packed_split is not None     # None: a weight outside the split's exact domain stays on the f32 MFMA
     if split:
-        if callable(packed_split):
-            packed_split = packed_split()
         if packed_split.numel() * 2 != L.srf_conv1x1_nhwc_split_packed_weight_bytes(Cout, kh * kw * Cin):
             raise ValueError("conv_gemm_nhwc: split-packed weight does not match the layer")
         packed_weight, fn = packed_split, L.srf_conv_gemm_nhwc_split
@@ -1452,10 +1470,17 @@ def conv_gemm_nhwc(x, packed_weight, Cout, ksize, stride, pad, scale=None, shift
     per_img = 4 * H * W * x_ld
     group = N if N * per_img < (1 << 31) else max(1, ((1 << 31) - 1) // per_img)
     sc, sh = _opt(scale, "scale"), _opt(shift, "shift")
+    timing = _dense_timing("cgemm")
     for n0 in range(0, max(N, 1), max(group, 1)):
         xs, os_ = x[n0:n0 + group], out[n0:n0 + group]
         check(fn(_ptr(xs), xs.shape[0], H, W, Cin, x_ld, _ptr(packed_weight), Cout, kh, kw, stride, pad, sc, sh,
                  int(bool(relu)), _ptr(os_), nhwc_ld(out), _stream()), "conv_gemm_nhwc")
+    if timing is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        fl = 2.0 * kh * kw * Cin * Cout * N * Ho * Wo
+        timing[1].append((timing[0], ev1, f"{Cin}->{Cout} {kh}x{kw}/s{stride} @{N}x{H}x{W}" + (" split" if split else ""), fl,
+                          6.0 * fl if split else fl, 4.0 * N * (H * W * Cin + Ho * Wo * Cout) + (6.0 if split else 4.0) * kh * kw * Cin * Cout))
     return out
 
 

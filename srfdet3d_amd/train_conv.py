@@ -18,6 +18,7 @@ mode -- `norm_eval=True` -- ReLU, cat, max_pool2d, nearest interpolate), so noth
 SRF_TRAIN_CONV=0 switches back to torch's convolution (A/B switch for tests and benchmarks).
 """
 import os
+import weakref
 
 import torch
 from torch import nn
@@ -106,7 +107,8 @@ class _ConvAffineRelu(torch.autograd.Function):
     the two column sums gamma / beta need).  As torch ops the same chain is conv, multiply, add, relu_ forward and
     threshold_backward, multiply and two strided column sums backward: eight passes over each layer's output instead of two.
     Only y is saved (not the convolution's own output z): sum gu z = (sum gu y - t sum gu) / s since z = (y - t) / s wherever the mask
-    lets a gradient through.  (A channel whose gamma is exactly 0 has s = 0: that term of its d gamma is taken as 0.)"""
+    lets a gradient through -- which needs s away from 0: `conv_bn_act` takes this node only for layers whose min |s| >= 1e-3 max |s|
+    (`gamma_well_conditioned`; anything else runs under plain autograd), and a frozen gamma needs no d gamma at all."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, mean, var, eps, relu):
@@ -171,9 +173,44 @@ def fused_eligible(conv, bn, x):
             and x.shape[0] * x.shape[2] * x.shape[3] * max(conv.in_channels, conv.out_channels) * 512 < (1 << 31) * 128)
 
 
+GAMMA_GUARD_RATIO = 1e-3   # min |s| / max |s| of a layer below which `_ConvAffineRelu` is not used (s = gamma / sqrt(var + eps))
+_GUARD = weakref.WeakKeyDictionary()   # BatchNorm2d -> ((gamma version, gamma pointer, var version), well conditioned?)
+
+
+def _guard_key(bn):
+    return (bn.weight._version, bn.weight.data_ptr(), bn.running_var._version)
+
+
+def gamma_well_conditioned(bn):
+    """`_ConvAffineRelu` rebuilds sum gu z from the saved OUTPUT, (sum gu y - t sum gu) / s: a channel with s = 0 has no such
+    term at all (its true d gamma is not zero, so a zero-initialised or pruned channel could never recover) and a small |s|
+    amplifies the rounding of two column sums by 1 / s.  The node is therefore used only for layers whose
+    min |s| >= GAMMA_GUARD_RATIO max |s|; any other layer runs conv2d / bn_eval / relu under plain autograd, which is exact.
+    The verdict is cached per (gamma version, pointer); when one is stale, the verdicts of ALL layers seen so far are refreshed
+    in one batch -- two concatenations, two segment reductions and ONE device -> host copy per optimiser step, not one per layer."""
+    ent = _GUARD.get(bn)
+    if ent is not None and ent[0] == _guard_key(bn):
+        return ent[1]
+    dev = bn.weight.device
+    mods = [m for m, e in list(_GUARD.items()) if m is not bn and m.weight.device == dev and e[0] != _guard_key(m)] + [bn]
+    with torch.no_grad():
+        lengths = [m.weight.numel() for m in mods]
+        g = torch.cat([m.weight.detach().reshape(-1) for m in mods]).abs()
+        v = torch.cat([m.running_var.reshape(-1) for m in mods])
+        eps = torch.repeat_interleave(torch.tensor([float(m.eps) for m in mods], dtype=v.dtype), torch.tensor(lengths)).to(dev)
+        s = g * torch.rsqrt(v + eps)
+        lt = torch.tensor(lengths, device=dev)
+        lo = torch.segment_reduce(s, "min", lengths=lt)
+        hi = torch.segment_reduce(s, "max", lengths=lt)
+        ok = ((hi > 0) & (lo >= GAMMA_GUARD_RATIO * hi) & torch.isfinite(hi)).tolist()     # the one synchronisation
+    for m, o in zip(mods, ok):
+        _GUARD[m] = (_guard_key(m), bool(o))
+    return _GUARD[bn][1]
+
+
 def conv_bn_act(conv, bn, relu, x):
     """The fused training route when it applies, else None (the caller then runs conv2d / bn_eval / relu)."""
-    if fused_eligible(conv, bn, x):
+    if fused_eligible(conv, bn, x) and (not bn.weight.requires_grad or gamma_well_conditioned(bn)):
         return _ConvAffineRelu.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bool(relu))
     return None
 

@@ -358,6 +358,52 @@ def test_fused_conv_evalbn_relu_training_node_matches_autograd(dev, k, N, Cin, C
         del os.environ["SRF_TRAIN_FUSED"]
 
 
+@pytest.mark.parametrize("k,gammas", [(3, (0.0,)), (1, (1e-6, -1e-7)), (3, (0.0, 1e-6))])
+def test_zero_and_tiny_gamma_channels_get_the_true_gradient(dev, k, gammas):
+    """`_ConvAffineRelu` divides two column sums by s = gamma / sqrt(var + eps); a layer with a zero-initialised / pruned
+    (gamma == 0) or nearly dead channel must not lose or blow up that channel's d gamma.  `conv_bn_act` sends such a layer through
+    plain autograd (`train_conv.gamma_well_conditioned`); every gradient is compared with float64 autograd, the small channels too."""
+    from torch import nn
+    from srfdet3d_amd import dense, train_conv
+    g = torch.Generator().manual_seed(77 + k)
+    Cin, Cout, N, H, W = 64, 96, 2, 17, 23
+    conv = nn.Conv2d(Cin, Cout, k, padding=k // 2, bias=False).to(dev)
+    bn = nn.BatchNorm2d(Cout, eps=1e-3).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(Cout, generator=g) * 0.3 + 0.2)
+        bn.running_mean.copy_(torch.randn(Cout, generator=g) * 0.2)
+        bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+    bn.eval()
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gy = torch.randn(N, Cout, H, W, generator=g).to(dev)
+    assert train_conv.fused_eligible(conv, bn, x) and train_conv.gamma_well_conditioned(bn)
+    assert type(dense.conv_bn_act(conv, bn, True, x).grad_fn).__name__ == "_ConvAffineReluBackward"
+    small = [5 + 7 * i for i in range(len(gammas))]
+    with torch.no_grad():                                   # an in-place update, as an optimiser step: the cached verdict goes stale
+        for c, v in zip(small, gammas):
+            bn.weight[c] = v
+    assert not train_conv.gamma_well_conditioned(bn)
+    y = dense.conv_bn_act(conv, bn, True, x)
+    assert type(y.grad_fn).__name__ != "_ConvAffineReluBackward"
+    y.backward(gy)
+    xd = x.detach().double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    gam, bet = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+    u = F.batch_norm(F.conv2d(xd, wd, None, padding=k // 2), bn.running_mean.double(), bn.running_var.double(), gam, bet, False, 0.0, bn.eps)
+    torch.relu(u).backward(gy.double())
+    for name, a, b in (("dx", x.grad, xd.grad), ("dW", conv.weight.grad, wd.grad), ("dgamma", bn.weight.grad, gam.grad), ("dbeta", bn.bias.grad, bet.grad)):
+        err = float((a.double() - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+        assert err < (2e-3 if name == "dx" else 5e-4), (name, err)
+    # the channels in question carry a real gradient (beta > 0 for most pixels' mask), and it is the true one
+    for c in small:
+        want = float(gam.grad[c])
+        assert abs(want) > 1e-3 and abs(float(bn.weight.grad[c]) - want) <= 1e-3 * abs(want) + 1e-4
+    # a frozen gamma needs no d gamma: the fused node stays
+    bn.weight.requires_grad_(False)
+    assert type(dense.conv_bn_act(conv, bn, True, x).grad_fn).__name__ == "_ConvAffineReluBackward"
+
+
 def test_affine_relu_bwd_kernel(dev):
     g = torch.Generator().manual_seed(23)
     for (N, H, W, C, relu) in ((2, 29, 50, 224, True), (1, 7, 5, 1024, True), (3, 11, 13, 40, False), (1, 1, 3, 4, True)):
