@@ -33,7 +33,7 @@ import torch.distributed as dist  # noqa: E402
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA": ~2.5 PF dense (the 5 PF headline includes 2:1 sparsity)
 HBM_PEAK_GBS = 8000.0         # same guide, "HBM3E peak BW" (spec)
-ROUND = "r04"                 # prefix of the profiles/ files this build's counter numbers live in
+ROUND = "r05"                 # prefix of the profiles/ files this build's counter numbers live in
 
 WORKLOADS = {
     "nusc_L": dict(cfg="srfdet_voxel_nusc_L", desc="srfdet_voxel_nusc_L inference (LiDAR-only), synthetic 30k-pt sweep, "
@@ -336,7 +336,7 @@ def main():
             gemm = gsplit
         elif gsplit is not None:
             gemm["split"] = gsplit
-        if w43m is not None or wino is not None:   # LC: the camera branch dominates the frame
+        if model.use_img and (w43m is not None or wino is not None):   # LC: the camera branch dominates the frame
             roofline = w43m if w43m is not None else wino
             if w43m is not None:
                 roofline["xform"] = xform

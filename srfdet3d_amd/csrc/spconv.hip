@@ -1327,6 +1327,378 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
 }
 
 // =====================================================================================================================
+// srf_spconv_gsp_k: the compacted-offset kernel above with its step SOFTWARE-PIPELINED (round 5).
+// In srf_spconv_gs_k a step (one group of 16 compacted rows) is a serial chain in every wave: read the A fragments and the
+// group's accumulators from LDS (0.71 us of exposed LDS latency and address arithmetic in the in-kernel stamps), 64 MFMAs
+// (0.92 us), accumulators back (0.18), wait for the gather + store it (0.22), barrier: the MFMA pipe sees 45 % of a wave's time
+// and the two workgroups of a CU interleave only partly (62 % busy).  Same arithmetic here -- the same (offset, channel)-
+// ascending chain per output, bit-identical results -- but every wave's MFMA block is the only thing it waits for:
+//   * the rows of ALL offsets of a sub-tile form ONE flat list of steps (per offset padded to whole groups of 16; s_pin holds
+//     the byte offset of the input row, s_pslot the output slot): step i's rows are entries 16 i .. 16 i + 15 whatever its
+//     offset, so looking two steps ahead is plain address arithmetic (the per-offset lists of the kernel above needed the
+//     offset after next for that);
+//   * step i issues, in this order: the chunk-0 fragments of A[i]; the LDS stores of A[i + 1] (gathered during step i - 1:
+//     landed long ago, no wait); the gather of step i + 2; then per 32-channel chunk the fragment reads of the NEXT chunk
+//     followed by the chunk's MFMAs (fragments double-buffered per chunk: 16 registers instead of 32), the output slots of
+//     step i + 1 inside the first chunk; accumulators of step i back to the tile and those of step i + 1 out of it (the
+//     same wave's LDS operations execute in order, so rows shared by the two steps are read after they were written);
+//     barrier.  LDS instructions issued between the MFMAs of the own wave cost ~1 cycle per MFMA; what stays exposed per
+//     step is one LDS latency behind the barrier and the accumulator round trip;
+//   * address arithmetic per step: rows are gathered through a buffer descriptor (32-bit offset row + quad: one add per
+//     load, padding entries are out-of-range offsets that read zeros without touching memory), the store addresses of the A
+//     image are precomputed per thread: ~20 vector instructions per step (they take MFMA issue time on this chip);
+//   * the last step of an offset is a separate instantiation (LAST) that also fetches the next offset's B operands into the
+//     other register set right behind the gather: no branch inside a step, the compiler's vmcnt bookkeeping stays exact.
+// The flat lists carry two dummy steps behind the real ones (zeros into the spare row), so nothing in a step is conditional.
+// =====================================================================================================================
+#define SRF_GSP_FL(TMAX) ((((TMAX) * SRF_KMAX + SRF_KMAX * 15 + 15) & ~15) + 32)
+
+static bool srf_gsp_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("SRF_SPCONV_GSP");  // developer switch: 0 keeps srf_spconv_gs_k (A/B timing, parity of the two forms)
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+typedef __attribute__((address_space(3))) float srf_lds_float;
+typedef __attribute__((address_space(3))) f32x4 srf_lds_f32x4;
+__device__ __forceinline__ unsigned srf_lds_addr(const void *p) { return (unsigned)(uintptr_t)p; }   // LDS byte address of a __shared__ object
+
+// per-thread constants of a step (LDS byte addresses for buffer 0 of the A image; the other buffer is `abuf_bytes` further)
+struct SrfGspLane {
+    unsigned fo0, fo1;     // the lane's two fragment quads inside chunk 0
+    unsigned sto[4];       // where the four floats of the lane's first gathered quad go (its second quad: two chunks further)
+    unsigned goff;         // byte offset of that quad inside the input row
+    unsigned colbase;      // LDS byte address of (slot 0, the lane's first column) of the output tile
+    unsigned boff;         // byte offset of the lane's B fragment inside a (offset, chunk) image
+};
+
+// ABL: timing ablations of the developer build (-DSRF_DEV; wrong outputs by design): 1 = no MFMAs, 2 = no gathers / A stores,
+// 3 = no accumulator round trip through the tile, 4 = no barrier
+template <int NCH, int COUT, bool LAST, int ABL = 0>
+__device__ __forceinline__ void srf_gsp_step(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t wrs, int kn, int i, const unsigned *s_pin,
+                                             const unsigned char *s_pslot, int &buf, const SrfGspLane &L,
+                                             f32x4 (&bc)[NCH][COUT / 32], f32x4 (&bn)[NCH][COUT / 32],
+                                             f32x4 (&ra)[16 * 8 * NCH / 256], f32x4 (&acc)[COUT / 64], unsigned (&oaddr)[4])
+{
+    constexpr int NT = COUT / 64, NB = COUT / 32, NA = 16 * 8 * NCH / 256, CHS = SRF_GS_CHS, OS = COUT + 4;
+    constexpr unsigned ABUF = NCH * CHS * 4;   // bytes of one A buffer
+    const int lane = threadIdx.x & 63;
+    const int aj = lane >> 4;
+    const unsigned cur = buf ? ABUF : 0u, nxt = buf ? 0u : ABUF;
+    // one address register per fragment quad / store target and immediate offsets for the chunks (opaque to the compiler, which
+    // otherwise folds the chunk offset into the scalar buffer offset and spends one vector add per LDS instruction)
+    unsigned f0 = L.fo0 + cur, f1 = L.fo1 + cur, st[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) st[jj] = L.sto[jj] + nxt;
+    asm volatile("" : "+v"(f0), "+v"(f1), "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]));
+    f32x4 af[2][2];
+    af[0][0] = *reinterpret_cast<const srf_lds_f32x4 *>(f0);
+    af[0][1] = *reinterpret_cast<const srf_lds_f32x4 *>(f1);
+    const unsigned ro = s_pin[(i + 2) * 16 + (threadIdx.x >> 4)];   // the row this thread gathers for step i + 2
+    // A[i + 1]: rows gathered during step i - 1, into the buffer the previous step read
+    if (ABL != 2) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<srf_lds_float *>(st[jj] + j * (2 * CHS * 4)) = ra[j][jj];
+        // rows of step i + 2 (dummy steps behind the last one: out-of-range offsets, zeros)
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro + L.goff + j * 256), 0, 0);
+            ra[j] = *reinterpret_cast<f32x4 *>(&v);
+        }
+    }
+    if (LAST) {   // B of the next offset into the other register set, a whole step ahead (through a descriptor: not an invariant
+                  // load the compiler may sink to its first use behind the barrier)
+        const int so = kn * (NCH * NB * 4096);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int g = 0; g < NB; ++g) {
+                auto v = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(L.boff + g * 1024), so + c * (NB * 4096), 0);
+                bn[c][g] = *reinterpret_cast<f32x4 *>(&v);
+            }
+    }
+    unsigned sl4 = 0;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) {
+            af[(c + 1) & 1][0] = *reinterpret_cast<const srf_lds_f32x4 *>(f0 + (c + 1) * (CHS * 4));
+            af[(c + 1) & 1][1] = *reinterpret_cast<const srf_lds_f32x4 *>(f1 + (c + 1) * (CHS * 4));
+        }
+        if (c == 0) sl4 = *reinterpret_cast<const unsigned *>(s_pslot + (i + 1) * 16 + aj * 4);
+        __builtin_amdgcn_sched_barrier(0);   // the next chunk's fragments are requested BEFORE this chunk's MFMAs (a whole chunk = 512 cycles ahead)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float a = af[c & 1][s >> 2][s & 3];
+            if (ABL == 1) {   // keep the operands alive, issue nothing
+                asm volatile("" ::"v"(a), "v"(bc[c][s >> 2][s & 3]), "v"(bc[c][NB - 2 + (s >> 2)][s & 3]));
+                continue;
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[c][s >> 2][s & 3], acc[0], 0, 0, 0);
+            if (NT == 2) acc[NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[c][NB - 2 + (s >> 2)][s & 3], acc[NT - 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ABL == 3) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) oaddr[jj] = ((sl4 >> (8 * jj)) & 255u) * (unsigned)(OS * 4) + L.colbase;
+        __syncthreads();
+        buf ^= 1;
+        return;
+    }
+    // accumulators of step i back into the tile, those of step i + 1 out of it (in-order LDS: shared rows are read after they were
+    // written); the reads are plain ds_read_b32 into the accumulator registers themselves (the compiler pairs them as ds_read2 and
+    // then shuffles registers behind a wait), awaited before the barrier together with the stores
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int cb = 0; cb < NT; ++cb) *reinterpret_cast<srf_lds_float *>(oaddr[jj] + cb * 64) = acc[cb][jj];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) oaddr[jj] = ((sl4 >> (8 * jj)) & 255u) * (unsigned)(OS * 4) + L.colbase;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int cb = 0; cb < NT; ++cb)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            float t;
+            if (cb == 0) asm volatile("ds_read_b32 %0, %1" : "=v"(t) : "v"(oaddr[jj]) : "memory");
+            else asm volatile("ds_read_b32 %0, %1 offset:64" : "=v"(t) : "v"(oaddr[jj]) : "memory");
+            acc[cb][jj] = t;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (ABL != 4) __syncthreads();
+    buf ^= 1;
+}
+
+template <int NCH, int COUT, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restrict__ in, int A_in, const float *__restrict__ Wg, int K,
+                                                         const int *__restrict__ nbr, int nbr_stride, int A_out,
+                                                         const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                         const float *__restrict__ residual, int relu,
+                                                         float *__restrict__ out, const int *__restrict__ rows_dev,
+                                                         const int *__restrict__ tiles)
+{
+    constexpr int NT = COUT / 64, NB = COUT / 32;
+    constexpr int NA = 16 * 8 * NCH / 256, NKW = (SRF_KMAX + 3) / 4, CHS = SRF_GS_CHS;
+    constexpr int TMAX = COUT == 128 ? SRF_GS_TMAX : 120, OS = COUT + 4;
+    constexpr int FL = SRF_GSP_FL(TMAX);
+    static_assert(COUT == 128 || COUT == 64, "column tiling of the waves");
+    static_assert(TMAX <= 128 && TMAX < 255, "two ballot segments of 64 rows; slots are bytes");
+    static_assert(NA >= 1 && (NCH & 1) == 0, "fragment double buffer assumes an even chunk count");
+    __shared__ unsigned s_pin[FL];                          // flat step list: byte offset of the input row (padding: out of range)
+    __shared__ __attribute__((aligned(4))) unsigned char s_pslot[FL];  // ... and the row's slot in the output tile
+    __shared__ int s_cnt[SRF_KMAX];
+    __shared__ int s_gstart[SRF_KMAX + 1];                  // first step of an offset; [KMAX] = steps of the sub-tile
+    __shared__ int s_klist[SRF_KMAX + 1];
+    __shared__ __attribute__((aligned(16))) float s_out[(TMAX + 1) * OS];
+    __shared__ __attribute__((aligned(16))) float s_a[2 * NCH * CHS];
+
+    const int A_cap = A_out;
+    if (rows_dev) {
+        const int live = *rows_dev;
+        A_out = A_out < live ? A_out : live;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int range0, range1;
+    if (tiles) {
+        const int T = srf_gs_ranges(A_cap);
+        if ((int)blockIdx.x >= T) return;
+        const int t = srf_xcd_tile(blockIdx.x, T);
+        range0 = tiles[t];
+        range1 = tiles[t + 1];
+        range1 = range1 < A_out ? range1 : A_out;
+    } else {
+        const int tm = srf_gs_tile_rows(A_out);
+        const int n_tiles = (A_out + tm - 1) / tm;
+        if ((int)blockIdx.x >= n_tiles) return;
+        range0 = srf_xcd_tile(blockIdx.x, n_tiles) * tm;
+        range1 = range0 + tm < A_out ? range0 + tm : A_out;
+    }
+    if (range1 <= range0) return;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)((long long)A_in * (32 * NCH) * 4), 0x00020000);
+    const int nsub = (range1 - range0 + TMAX - 1) / TMAX;
+    const int TM = (((range1 - range0 + nsub - 1) / nsub) + 7) & ~7;
+    for (int row0 = range0; row0 < range1; row0 += TM) {
+    const int row_end = row0 + TM < range1 ? row0 + TM : range1;
+    int zero = 0;   // opaque: keeps the prologue's address arithmetic from being hoisted above the sub-tile loop and spilled (see srf_spconv_gs_k)
+    asm volatile("" : "+s"(zero));
+    for (int e = tid; e < TM * OS / 4; e += 256) reinterpret_cast<f32x4 *>(s_out)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int nv[NKW][2];
+#pragma unroll
+    for (int i = 0; i < NKW; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = wave + 4 * i, r = h * 64 + lane;
+            nv[i][h] = (k < K && row0 + r < row_end) ? nbr[(size_t)(k + zero) * nbr_stride + row0 + r] : -1;
+        }
+    // pass 1: pairs per offset
+#pragma unroll
+    for (int i = 0; i < NKW; ++i) {
+        const int k = wave + 4 * i;
+        if (k >= SRF_KMAX) break;
+        const int c = __popcll(__ballot(nv[i][0] >= 0)) + __popcll(__ballot(nv[i][1] >= 0));
+        if (lane == 0) s_cnt[k] = c;
+    }
+    __syncthreads();
+    if (tid < 64) {   // first step of every offset (exclusive prefix of the group counts), the used offsets in ascending order
+        const int c = tid < SRF_KMAX ? s_cnt[tid] : 0;
+        const int ng = (c + 15) >> 4;
+        int x = ng;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const int y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (tid < SRF_KMAX) s_gstart[tid] = x - ng;
+        if (tid == SRF_KMAX - 1) s_gstart[SRF_KMAX] = x;
+        const unsigned long long m = __ballot(c > 0);
+        if (c > 0) s_klist[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+        if (tid == 0) s_klist[SRF_KMAX] = __popcll(m);
+    }
+    __syncthreads();
+    const int S = __builtin_amdgcn_readfirstlane(s_gstart[SRF_KMAX]);
+    // pass 2: compaction into the flat list
+#pragma unroll
+    for (int i = 0; i < NKW; ++i) {
+        const int k = wave + 4 * i;
+        if (k >= SRF_KMAX) break;
+        const int g0 = s_gstart[k + zero] * 16;
+        int base = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int v = nv[i][h];
+            const unsigned long long m = __ballot(v >= 0);
+            if (v >= 0) {
+                const int pos = g0 + base + __popcll(m & ((1ull << lane) - 1ull));
+                s_pin[pos] = (unsigned)v * (unsigned)(32 * NCH * 4);
+                s_pslot[pos] = (unsigned char)(h * 64 + lane);
+            }
+            base += __popcll(m);
+        }
+        const int pad = ((base + 15) & ~15) - base;   // padding of the offset's last group: zeros into the spare row
+        if (lane < pad) {
+            s_pin[g0 + base + lane] = 0x80000000u;
+            s_pslot[g0 + base + lane] = (unsigned char)TMAX;
+        }
+    }
+    if (tid < 32) {   // two dummy steps behind the last one
+        s_pin[S * 16 + tid] = 0x80000000u;
+        s_pslot[S * 16 + tid] = (unsigned char)TMAX;
+    }
+    __syncthreads();
+    const int ntap = __builtin_amdgcn_readfirstlane(s_klist[SRF_KMAX]);
+
+    // per-thread constants of a step
+    SrfGspLane L;
+    {
+        const int ar = lane & 15, aj = lane >> 4, a_swz = (ar >> 1) & 7;
+        const unsigned a0 = srf_lds_addr(s_a) + (unsigned)zero;
+        L.fo0 = a0 + (unsigned)(ar * 32 + (((aj << 1) ^ a_swz) << 2)) * 4u;
+        L.fo1 = a0 + (unsigned)(ar * 32 + ((((aj << 1) + 1) ^ a_swz) << 2)) * 4u;
+        L.colbase = srf_lds_addr(s_out) + (unsigned)((COUT == 128 ? wave * 32 : wave * 16) + ar + zero) * 4u;
+        // gather: thread = (row tid / 16, quad tid % 16 of the row, and for Cin = 128 the quad 16 further = two chunks further)
+        const int r = tid >> 4, qq = tid & 15, ch = qq >> 3, q = qq & 7, swz = (r >> 1) & 7;
+        L.goff = (unsigned)(qq * 16 + zero);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) L.sto[jj] = a0 + (unsigned)(ch * CHS + r * 32 + (q & 3) + (((jj * 2 + (q >> 2)) ^ swz) << 2)) * 4u;
+        const int wc = COUT == 128 ? wave : (wave >> 1), g0 = COUT == 128 ? 0 : 2 * (wave & 1);
+        L.boff = (unsigned)(lane * 16 + wc * 4096 + g0 * 1024 + zero);
+    }
+    __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wg), 0, K * NCH * NB * 4096, 0x00020000);
+    f32x4 b0[NCH][NB], b1[NCH][NB], ra[NA], acc[NT];
+    unsigned oaddr[4];
+    int buf = 0;
+    if (ntap > 0) {
+        const int k0 = s_klist[0];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int g = 0; g < NB; ++g) {
+                auto v = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(L.boff + g * 1024), (k0 * NCH + c) * (NB * 4096), 0);
+                b0[c][g] = *reinterpret_cast<f32x4 *>(&v);
+            }
+        {
+            const unsigned ro = s_pin[tid >> 4];
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro + L.goff + j * 256), 0, 0);
+                ra[j] = *reinterpret_cast<f32x4 *>(&v);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<srf_lds_float *>(L.sto[jj] + j * (2 * CHS * 4)) = ra[j][jj];
+        {
+            const unsigned ro = s_pin[16 + (tid >> 4)];
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro + L.goff + j * 256), 0, 0);
+                ra[j] = *reinterpret_cast<f32x4 *>(&v);
+            }
+        }
+        const unsigned sl4 = *reinterpret_cast<const unsigned *>(s_pslot + (lane >> 4) * 4);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            oaddr[jj] = ((sl4 >> (8 * jj)) & 255u) * (unsigned)(OS * 4) + L.colbase;
+#pragma unroll
+            for (int cb = 0; cb < NT; ++cb) acc[cb][jj] = 0.0f;   // the tile was just zeroed
+        }
+    }
+    __syncthreads();
+    for (int tk = 0; tk < ntap; tk += 2) {   // two offsets per trip: the B register sets swap roles without moves
+        {
+            const bool more = tk + 1 < ntap;
+            const int kc = __builtin_amdgcn_readfirstlane(s_klist[tk]), kn = more ? __builtin_amdgcn_readfirstlane(s_klist[tk + 1]) : kc;
+            const int i0 = __builtin_amdgcn_readfirstlane(s_gstart[kc]), i1 = __builtin_amdgcn_readfirstlane(s_gstart[kc + 1]);
+            for (int i = i0; i + 1 < i1; ++i) srf_gsp_step<NCH, COUT, false, ABL>(rs, wrs, kn, i, s_pin, s_pslot, buf, L, b0, b1, ra, acc, oaddr);
+            srf_gsp_step<NCH, COUT, true, ABL>(rs, wrs, kn, i1 - 1, s_pin, s_pslot, buf, L, b0, b1, ra, acc, oaddr);
+        }
+        if (tk + 1 < ntap) {
+            const bool more = tk + 2 < ntap;
+            const int kc = __builtin_amdgcn_readfirstlane(s_klist[tk + 1]), kn = more ? __builtin_amdgcn_readfirstlane(s_klist[tk + 2]) : kc;
+            const int i0 = __builtin_amdgcn_readfirstlane(s_gstart[kc]), i1 = __builtin_amdgcn_readfirstlane(s_gstart[kc + 1]);
+            for (int i = i0; i + 1 < i1; ++i) srf_gsp_step<NCH, COUT, false, ABL>(rs, wrs, kn, i, s_pin, s_pslot, buf, L, b1, b0, ra, acc, oaddr);
+            srf_gsp_step<NCH, COUT, true, ABL>(rs, wrs, kn, i1 - 1, s_pin, s_pslot, buf, L, b1, b0, ra, acc, oaddr);
+        }
+    }
+    // the last step's write-back went through raw LDS addresses: make the whole tile visible to the epilogue's plain reads
+    __syncthreads();
+
+    // epilogue: every output row once, BN / residual / ReLU in registers, 512 B per row and store
+    constexpr int CQ = COUT / 4;
+    const int c4 = ((tid & (CQ - 1)) + zero) * 4;
+    f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+    if (alpha) {
+        al = *reinterpret_cast<const f32x4 *>(alpha + c4);
+        be = *reinterpret_cast<const f32x4 *>(beta + c4);
+    }
+    for (int r = tid / CQ; r < TM; r += 256 / CQ) {
+        const int row = row0 + r;
+        if (row >= row_end) break;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(s_out + r * OS + c4);
+        f32x4 rsd = {0.f, 0.f, 0.f, 0.f};
+        if (residual) rsd = *reinterpret_cast<const f32x4 *>(residual + (size_t)row * COUT + c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = v[j];
+            if (alpha) x = __fmaf_rn(x, al[j], be[j]);
+            if (residual) x = __fadd_rn(x, rsd[j]);
+            if (relu) x = x > 0.0f ? x : 0.0f;
+            v[j] = x;
+        }
+        *reinterpret_cast<f32x4 *>(out + (size_t)row * COUT + c4) = v;
+    }
+    __syncthreads();
+    }
+}
+
+// =====================================================================================================================
 // srf_spconv_w32_k: the 32-output-channel layers (SubM 32 -> 32 x 4 and the strided 16 -> 32 of the nuScenes encoder,
 // sparse_encoder_custom.py:109-140 through spconv's SubMConv3d / SparseConv3d) -- 2 GFLOP per frame that took 0.33 ms: the
 // tile kernel above walks its 27 offsets as gather -> LDS -> barrier -> 16 MFMAs with one step of lookahead, i.e. at the
@@ -1474,8 +1846,12 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
     case 64:
         if (srf_gs_layout(Cin, Cout)) {
             const dim3 grid(tiles ? srf_gs_ranges(A_out) : SRF_GS_SLOTS * srf_gs_rounds(A_out));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gs_k<2, 64>), grid, dim3(256), 0, st, in, W_packed, K, nbr, nbr_stride, A_out,
-                               alpha, beta, residual, relu, out, rows_dev, tiles);
+            if (srf_gsp_enabled() && (long long)A_in * Cin * 4 < (1ll << 31))
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gsp_k<2, 64>), grid, dim3(256), 0, st, in, A_in, W_packed, K, nbr, nbr_stride, A_out,
+                                   alpha, beta, residual, relu, out, rows_dev, tiles);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gs_k<2, 64>), grid, dim3(256), 0, st, in, W_packed, K, nbr, nbr_stride, A_out,
+                                   alpha, beta, residual, relu, out, rows_dev, tiles);
             break;
         }
         if (srf_direct_layout(Cin, Cout)) {
@@ -1490,6 +1866,30 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
         if (srf_gs_layout(Cin, Cout)) {
             // >= the tiles of any live row count <= A_out / the ranges srf_spconv_tiles_build cut for this capacity
             const dim3 grid(tiles ? srf_gs_ranges(A_out) : SRF_GS_SLOTS * srf_gs_rounds(A_out));
+            if (srf_gsp_enabled() && (long long)A_in * Cin * 4 < (1ll << 31)) {
+#ifdef SRF_DEV
+                if (Cin == 128) {   // SRF_GSP_ABL = ablation (wrong outputs), SRF_GSP_PADLDS = extra LDS bytes (one workgroup per CU from 4000 on)
+                    const char *e = getenv("SRF_GSP_ABL"), *pl = getenv("SRF_GSP_PADLDS");
+                    const int abl = e ? atoi(e) : 0, pad = pl ? atoi(pl) : 0;
+#define SRF_GSP_DEV(A) hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gsp_k<4, 128, A>), grid, dim3(256), pad, st, in, A_in, W_packed, K, nbr, nbr_stride, \
+                                          A_out, alpha, beta, residual, relu, out, rows_dev, tiles)
+                    if (abl == 1) SRF_GSP_DEV(1);
+                    else if (abl == 2) SRF_GSP_DEV(2);
+                    else if (abl == 3) SRF_GSP_DEV(3);
+                    else if (abl == 4) SRF_GSP_DEV(4);
+                    else SRF_GSP_DEV(0);
+#undef SRF_GSP_DEV
+                    break;
+                }
+#endif
+                if (Cin == 128)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gsp_k<4, 128>), grid, dim3(256), 0, st, in, A_in, W_packed, K, nbr, nbr_stride,
+                                       A_out, alpha, beta, residual, relu, out, rows_dev, tiles);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gsp_k<2, 128>), grid, dim3(256), 0, st, in, A_in, W_packed, K, nbr, nbr_stride,
+                                       A_out, alpha, beta, residual, relu, out, rows_dev, tiles);
+                break;
+            }
             if (Cin == 128)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gs_k<4, 128>), grid, dim3(256), 0, st, in, W_packed, K, nbr, nbr_stride,
                                    A_out, alpha, beta, residual, relu, out, rows_dev, tiles);

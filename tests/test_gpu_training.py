@@ -383,6 +383,7 @@ def test_zero_and_tiny_gamma_channels_get_the_true_gradient(dev, k, gammas):
     with torch.no_grad():                                   # an in-place update, as an optimiser step: the cached verdict goes stale
         for c, v in zip(small, gammas):
             bn.weight[c] = v
+            bn.bias[c] = 0.4                                # u = beta > 0 on these channels: the ReLU lets their gradient through
     assert not train_conv.gamma_well_conditioned(bn)
     y = dense.conv_bn_act(conv, bn, True, x)
     assert type(y.grad_fn).__name__ != "_ConvAffineReluBackward"

@@ -4,9 +4,9 @@
 `--pmc` passes (each with --kernel-trace only), read bytes = 2 x FETCH_SIZE x 1024 on gfx950 (128-B requests are tallied
 as 64 B), WRITE_SIZE x 1024 exact.  Run on the GPU box from the repo root:
 
-    python tools/measure_traffic.py            # writes gpurun_out/traffic/r04_pmc_<name>_traffic.json
+    python tools/measure_traffic.py            # writes gpurun_out/traffic/r05_pmc_<name>_traffic.json
 
-and copy the files into profiles/ (bench.py reads profiles/r04_pmc_<name>_traffic.json -> roofline.traffic).
+and copy the files into profiles/ (bench.py reads profiles/r05_pmc_<name>_traffic.json -> roofline.traffic).
 This process never touches the GPU itself: every pass is `rocprofv3 ... -- python3 <tool>` started as a child.
 """
 import csv
@@ -20,10 +20,10 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "traffic")
 SQ = ("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS "
-      "SQ_LDS_BANK_CONFLICT").split()
+      "SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY").split()
 
 # name -> (program after `--`, kernel-name substring, description, algorithmic bytes note)
-ROUND = "r04"
+ROUND = "r05"
 TARGETS = {
     "wino43mm": (["tools/prof_img_branch.py", "3"], ("srf_wino43_mm_k<",),
                  "every srf_wino43_mm_k launch of 3 eager passes of the LC camera branch (88 per frame: VoVNet-99 from stage 2 on, image FPN, img_convs)"),
@@ -39,18 +39,36 @@ TARGETS = {
                   "every srf_gemm_split_k launch of the same passes (21 per frame: the OSA concat convolutions, the FPN laterals and stem_3 as "
                   "f32 GEMMs on the bf16 MFMA) -- the launch set bench.py's roofline.gemm aggregates"),
     # the scatter / gather stages north_star asks HBM GB/s for: 3 eager LiDAR frames (30k points, np = 200), traffic PER FRAME
-    "voxelize": (["tools/prof_lidar_frame.py", "3"], ("srf_hv_insert_k", "srf_hv_gather_k", "srf_scan_reduce_k<HvFlag", "srf_scan_apply_k<HvFlag"),
+    # (the single-workgroup scans of the coarse levels, the middle pass of the three-launch scans and the region fills --
+    # table / bitmap clears -- belong to these families too; srf_fill_regions_k is shared by both and is counted with the rulebooks,
+    # whose bitmap clears are its large launches)
+    "voxelize": (["tools/prof_lidar_frame.py", "3"], ("srf_hv_insert_k", "srf_hv_gather_k", "srf_scan_reduce_k<HvFlag", "srf_scan_apply_k<HvFlag",
+                                                       "srf_scan_single_k<HvFlag"),
                  "hard voxelization + per-voxel mean (K1 + a3): insert, first-seen numbering scan, gather; per frame", 3),
-    "rulebook": (["tools/prof_lidar_frame.py", "3"], ("srf_bm_", "srf_scan_reduce_k<BmPop", "srf_scan_apply_k<BmPop"),
-                 "bitmap-rank rulebooks of the whole encoder (K4): mark / rank scans / place / subm / strided mark, emit, pairs; per frame", 3),
+    "rulebook": (["tools/prof_lidar_frame.py", "3"], ("srf_bm_", "srf_scan_reduce_k<BmPop", "srf_scan_apply_k<BmPop", "srf_scan_single_k<BmPop",
+                                                       "srf_scan_partials_k", "srf_fill_regions_k"),
+                 "bitmap-rank rulebooks of the whole encoder (K4): clears, mark / rank scans / place / subm / strided mark, emit, pairs; per frame "
+                 "(srf_scan_partials_k and srf_fill_regions_k of the voxelization included here: ~3 small launches)", 3),
+    # the same stages on the 180k-point Waymo frame (C5, configs/waymo/srfdet_dvoxel_waymo_L.py:6-35: dynamic voxelization + DynamicScatter)
+    "voxelize_waymo": (["tools/prof_lidar_frame.py", "3", "waymo_L"], ("srf_dynamic_voxelize_k",),
+                       "dynamic voxelization (K2) of the 180k-point Waymo frame; per frame", 3),
+    "scatter_waymo": (["tools/prof_lidar_frame.py", "3", "waymo_L"], ("srf_vu_", "srf_scatter_reduce_k"),
+                      "DynamicScatter (K3): occupancy bitmap, rank, per-voxel point lists, mean / max reductions of DynamicVFECustom on the Waymo frame; per frame", 3),
+    "rulebook_waymo": (["tools/prof_lidar_frame.py", "3", "waymo_L"], ("srf_bm_", "srf_scan_reduce_k<BmPop", "srf_scan_apply_k<BmPop", "srf_scan_single_k<BmPop",
+                                                                        "srf_scan_partials_k", "srf_fill_regions_k"),
+                       "bitmap-rank rulebooks of the whole encoder (K4) on the Waymo frame (input level 1536 x 1536 x 41); per frame", 3),
+    "densify_waymo": (["tools/prof_lidar_frame.py", "3", "waymo_L"], ("srf_densify_bev_k", "srf_densify_k"),
+                      "dense BEV map (K6) of the Waymo frame; per frame", 3),
+    "roi_waymo": (["tools/prof_lidar_frame.py", "3", "waymo_L"], ("srf_roi_extract_k",),
+                  "multi-level RoIAlign gather (K7) on the Waymo frame; per frame", 3),
     "densify": (["tools/prof_lidar_frame.py", "3"], ("srf_densify_bev_k",),
                 "dense BEV map (K6: dense() + the (N, C D, H, W) view) written channels-last in one pass from the last level's bitmap, zero cells "
                 "included (srf_densify_bev); per frame", 3),
     "roi": (["tools/prof_lidar_frame.py", "3"], ("srf_roi_extract_k",),
             "multi-level RoIAlign gather (K7), 5 stages x 200 RoIs on the channels-last BEV pyramid; per frame", 3),
-    "spconv128": (["tools/bench_spconv.py", "--levels", "4", "--reps", "8"], "srf_spconv_gs_k<4, 128>",
+    "spconv128": (["tools/bench_spconv.py", "--levels", "4", "--reps", "8"], ("srf_spconv_gs_k<4, 128>", "srf_spconv_gsp_k<4, 128"),
                   "SubM 128->128 on the 5x184x184 level of frame 2000 (A=34992), BN + residual + ReLU epilogue"),
-    "spconv64": (["tools/bench_spconv.py", "--levels", "3", "--reps", "8"], "srf_spconv_gs_k<2, 64>",
+    "spconv64": (["tools/bench_spconv.py", "--levels", "3", "--reps", "8"], ("srf_spconv_gs_k<2, 64>", "srf_spconv_gsp_k<2, 64"),
                  "SubM 64->64 on the 11x368x368 level of frame 2000, BN + residual + ReLU epilogue"),
 }
 
