@@ -118,8 +118,8 @@ def test_spconv_fwd_exact(dev, cin, cout, K):
 
 @pytest.mark.parametrize("n,live", [(6000, None), (6000, 4100), (40, None), (3000, 0)])
 def test_spconv_tiles_cut_rows_by_pair_count(dev, n, live):
-    """tiles[t] = first row whose exclusive cost prefix reaches ceil(t * P / T), cost of a row = its pairs + 12 (include/
-    srfdet3d.h): checked against that definition in numpy; with a device row count (static-shape levels) only the live rows
+    """tiles[t] = first row whose exclusive cost prefix reaches ceil(t * P / T), cost of a row = its pairs +
+    srf_spconv_tiles_row_cost() (include/srfdet3d.h): checked against that definition in numpy; with a device row count (static-shape levels) only the live rows
     are cut."""
     idx = _level1(n=n)
     nbr, _ = O.rulebook_subm(idx, SHAPE1, [3, 3, 3])
@@ -129,7 +129,9 @@ def test_spconv_tiles_cut_rows_by_pair_count(dev, n, live):
     tiles = ops.spconv_tiles(t_nbr, rows_dev).cpu().numpy()
     a_live = A if live is None else min(live, A)
     T = len(tiles) - 1
-    pairs = (nbr[:, :a_live] >= 0).sum(0).astype(np.int64) + 12
+    from srfdet3d_amd import _lib
+    row_cost = _lib.lib().srf_spconv_tiles_row_cost()
+    pairs = (nbr[:, :a_live] >= 0).sum(0).astype(np.int64) + row_cost
     prefix = np.concatenate([[0], np.cumsum(pairs)])  # prefix[r] = cost of rows < r
     P = int(prefix[-1])
     want = np.empty(T + 1, np.int64)
@@ -140,7 +142,7 @@ def test_spconv_tiles_cut_rows_by_pair_count(dev, n, live):
     assert tiles[0] == 0 and np.all(np.diff(tiles) >= 0)
     if a_live >= 2000:  # every range carries P/T cost to within one row's worth
         per = np.diff(prefix[tiles])
-        assert per.max() - per.min() <= 2 * (27 + 12)
+        assert per.max() - per.min() <= 2 * (27 + row_cost)
 
 
 @pytest.mark.parametrize("C", [128, 64])
