@@ -236,11 +236,10 @@ int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const float *W_pac
                           srf_stream_t stream);
 
 /* Work-balanced row ranges of a rulebook for srf_spconv_fwd_packed (optional, `tiles` may be NULL there): the output
- * rows are cut into srf_spconv_tiles_count(A_out) consecutive pieces of equal cost (a row costs its pairs +
- * srf_spconv_tiles_row_cost(); piece t = the rows whose exclusive cost prefix lies in [t*P/T, (t+1)*P/T)),
- * tiles[t]..tiles[t+1]; a workgroup of the 64- / 128-channel kernels owns four consecutive pieces, so that the
- * workgroups finish together although the neighbour count per row varies
- * over the sweep.  Built once per rulebook -- the SubM layers of a level share one (sparse_encoder_custom.py:125-134) --
+ * rows are cut into srf_spconv_tiles_count(A_out) consecutive ranges of equal cost (a row costs its pairs +
+ * srf_spconv_tiles_row_cost(); range t = the rows whose exclusive cost prefix lies in [t*P/T, (t+1)*P/T)),
+ * tiles[t]..tiles[t+1], so that the workgroups of the 64- / 128-channel kernels (one range each) finish together
+ * although the neighbour count per row varies over the sweep.  Built once per rulebook -- the SubM layers of a level share one (sparse_encoder_custom.py:125-134) --
  * from nbr alone; A_out / nbr_stride / rows_dev as in srf_spconv_fwd, and the same A_out must be passed to both calls.
  * workspace: srf_spconv_tiles_workspace_bytes(A_out) bytes; tiles: srf_spconv_tiles_count(A_out) + 1 ints. */
 int srf_spconv_tiles_count(int A_out);

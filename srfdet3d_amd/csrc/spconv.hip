@@ -844,7 +844,6 @@ __global__ __launch_bounds__(256) void srf_spconv_direct64_k(const float *__rest
 #define SRF_GS_OS 132    /* output-tile row stride in floats: rows 4 apart land 16 banks apart */
 #define SRF_GS_CHS (16 * 32 + 8) /* chunk stride of the A image: the four chunks of a row start 8 banks apart */
 #define SRF_GS_SLOTS 512 /* co-resident workgroups: 256 CUs x 2 */
-#define SRF_GSQ_PIECES 4 /* the cost cut of srf_spconv_tiles_build is this much finer than the ranges: srf_spconv_gsq_k pairs sub-tiles of equal cost */
 
 // Tile height.  A tile is ~80 groups of MFMAs (~200 us): with a fixed height the last partial round of tiles would leave
 // most of the chip idle for that long (547 tiles of 64 rows on 512 slots: 35 tiles run alone in a second round).  The
@@ -1023,11 +1022,14 @@ __device__ __forceinline__ void srf_gs_offset(const float *__restrict__ in, cons
 // [t*P/T, (t+1)*P/T) -- once per rulebook (the four SubM layers of a level share it).  A workgroup walks its range in
 // sub-tiles of at most SRF_GS_TMAX rows.
 #define SRF_TB_ROWS 256
-#define SRF_GS_ROW_COST 4 /* cost of a row = its pairs + 4: the constant carries the row's share of the per-sub-tile work (list
-                             build, epilogue: ~23 k cycles per ~68 rows against ~300 cycles per pair in the step loop of
-                             srf_spconv_gsp_k).  Round 1's kernel, whose steps were twice as long, was fitted with 12; with the
-                             pipelined kernel 12 leaves the step counts of a nuScenes level 81 +- 18, 4 leaves them 82 +- 8
-                             (in-kernel stamps), 0-2 produce ranges taller than a tile that pay the sub-tile overhead twice */
+#define SRF_GS_ROW_COST 8 /* cost of a row = its pairs + 8: the constant carries the row's share of the per-sub-tile work (list
+                             build, epilogue: ~20 k cycles per sub-tile against ~270 cycles per pair in the step loop of
+                             srf_spconv_gsp_k) and keeps sparse ranges from growing taller than a tile, which costs a second
+                             sub-tile (+35 k cycles).  Round 1's kernel, whose steps were twice as long, was fitted with 12.
+                             Measured (round 5, in-kernel stamps + bench_spconv): 128 -> 128 (35k rows, 68 rows per range)
+                             226 / 219 us with 12 / 4 on one box, 228 / 228 on another; 64 -> 64 (60k rows, 116 rows per range of
+                             at most 128) 88 / 91.5 us: the taller the ranges of a level against its tile, the larger the constant
+                             it wants */
 __host__ __device__ static inline int srf_gs_ranges(int A_cap)
 {
     const int t = A_cap / 32;
@@ -1136,7 +1138,7 @@ __global__ __launch_bounds__(256) void srf_gs_cut_k(const int *__restrict__ loca
     tiles[t] = a;
 }
 
-extern "C" int srf_spconv_tiles_count(int A_out) { return A_out <= 0 ? 1 : SRF_GSQ_PIECES * srf_gs_ranges(A_out); }
+extern "C" int srf_spconv_tiles_count(int A_out) { return A_out <= 0 ? 1 : srf_gs_ranges(A_out); }
 
 static int srf_gs_row_cost_value()
 {
@@ -1217,8 +1219,8 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
         if ((int)blockIdx.x >= T * SPLIT) return;
         const int ts = srf_xcd_tile(blockIdx.x, T * SPLIT);
         const int t = ts / SPLIT, part = ts - t * SPLIT;
-        range0 = tiles[t * SRF_GSQ_PIECES];   // a range = SRF_GSQ_PIECES pieces of the cost cut
-        range1 = tiles[(t + 1) * SRF_GSQ_PIECES];
+        range0 = tiles[t];
+        range1 = tiles[t + 1];
         range1 = range1 < A_out ? range1 : A_out;
         if (SPLIT > 1 && range1 > range0) {  // this workgroup's share of the range: whole multiples of 8 rows
             const int per = (((range1 - range0 + SPLIT - 1) / SPLIT) + 7) & ~7;
@@ -1365,10 +1367,6 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gs_k(const float *__restric
 //     other register set right behind the gather: no branch inside a step, the compiler's vmcnt bookkeeping stays exact.
 // The flat lists carry two dummy steps behind the real ones (zeros into the spare row), so nothing in a step is conditional.
 // =====================================================================================================================
-#define SRF_GSP_FL(TMAX) ((((TMAX) * SRF_KMAX + SRF_KMAX * 15 + 15) & ~15) + 32)
-#ifndef SRF_GSQ_PRIO
-#define SRF_GSQ_PRIO 1   /* wave priority 3 outside the MFMA blocks of srf_spconv_gsp_k / _gsq_k (0: A/B build) */
-#endif
 
 static bool srf_gsp_enabled()
 {
@@ -1395,56 +1393,74 @@ struct SrfGspLane {
 // ABL: timing ablations of the developer build (-DSRF_DEV; wrong outputs by design): 1 = no MFMAs, 2 = no gathers / A stores,
 // 3 = no accumulator round trip through the tile, 4 = no barrier
 #ifdef SRF_DEV
-__device__ long long srf_gsq_stamps[512 * 16];   // developer build: per (workgroup, team) the cycles spent in S, wait, M, wait and the step count
-extern "C" int srf_dev_gsq_stamps(long long *host, int n)
+__device__ long long srf_gsp_stamps[512 * 16];   // developer build: per workgroup the cycles of a step spent before / in / behind the MFMA block and at the barrier, the step count, prologue / loop / epilogue
+extern "C" int srf_dev_gsp_stamps(long long *host, int n)
 {
     SRF_HIP_TRY(hipDeviceSynchronize());
-    SRF_HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(srf_gsq_stamps), sizeof(long long) * (n < 512 * 16 ? n : 512 * 16)));
+    SRF_HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(srf_gsp_stamps), sizeof(long long) * (n < 512 * 16 ? n : 512 * 16)));
     return SRF_OK;
 }
 #endif
 // what a wave carries from step to step: every address the LDS-only parts of a step use is prepared INSIDE the MFMA block before
+template <int GP>
 struct SrfGspRegs {
-    unsigned f0, f1;        // fragment quads of the A image the step reads
-    unsigned st[4];         // where it stores the rows of the step after it
-    unsigned gaddr;         // buffer offset of the row it requests (step + 2)
-    unsigned oaddr[4];      // tile addresses of its accumulators
-    unsigned pin_addr;      // LDS address of the row-list entry it reads (step + 3: the request after next)
-    unsigned slot_addr;     // LDS address of the slots it reads (step + 1)
-    unsigned info_addr;     // LDS address of the offset flag it reads (step + 1)
+    unsigned f0, f1;          // fragment quads of the A image the step reads
+    unsigned st[4];           // where it stores the rows of the step after it
+    unsigned gaddr[GP];       // buffer offsets of the rows it requests (step + 2)
+    unsigned oaddr[GP][4];    // tile addresses of its accumulators
+    unsigned pin_addr;        // LDS address of the row-list entries it reads (step + 3: the request after next)
+    unsigned slot_addr;       // LDS address of the slots it reads (step + 1)
+    unsigned info_addr;       // LDS address of the offset flag it reads (step + 1)
 };
 
-template <int NCH, int COUT, bool LAST, int ABL = 0>
+// GP = groups of 16 rows per step.  COUT = 64 runs GP = 2: a wave owns ONE 16-column MFMA tile there, i.e. one dependent chain of 16
+// MFMAs per group (40 cycles each instead of 32) behind a fixed chain of LDS latencies (fragments -> MFMAs -> accumulators back and
+// out -> barrier); two groups per step are two independent chains and half the barriers per pair.  (The rows of an offset are padded
+// to whole steps: 27 x 16 instead of 27 x 8 padding rows per sub-tile on average.)
+template <int NCH, int COUT, int GP, bool LAST, int ABL = 0>
 __device__ __forceinline__ void srf_gsp_step(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t wrs, int kn, int &buf, const SrfGspLane &L,
-                                             SrfGspRegs &G, f32x4 (&bc)[NCH][COUT / 32], f32x4 (&bn)[NCH][COUT / 32],
-                                             f32x4 (&ra)[16 * 8 * NCH / 256], f32x4 (&acc)[COUT / 64], long long (&stamp)[8], int &info_next)
+                                             SrfGspRegs<GP> &G, f32x4 (&bc)[NCH][COUT / 32], f32x4 (&bn)[NCH][COUT / 32],
+                                             f32x4 (&ra)[GP][16 * 8 * NCH / 256], f32x4 (&acc)[GP][COUT / 64], long long (&stamp)[8], int &info_next)
 {
-    constexpr int NT = COUT / 64, NB = COUT / 32, NA = 16 * 8 * NCH / 256, CHS = SRF_GS_CHS, OS = COUT + 4;
+    constexpr int NT = COUT / 64, NB = COUT / 32, NA = 16 * 8 * NCH / 256, RS = 16 * GP, CHS = RS * 32 + 8, OS = COUT + 4;
     constexpr unsigned ABUF = NCH * CHS * 4;   // bytes of one A buffer
+    typedef const __attribute__((address_space(3))) unsigned srf_lds_u32;
     long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if (ABL == 5) t0 = __builtin_amdgcn_s_memtime();
-    // ---- LDS / memory instructions only (in-kernel stamps of the ping-pong form below: a wave issues NO vector instruction while the
-    // partner wave of its SIMD -- here: the CU's other workgroup -- streams f32 MFMAs, at any s_setprio; a step whose first instruction is
-    // an address add therefore stands still until the partner's MFMA block is over, and the two workgroups take turns instead of
-    // overlapping.  Every address below comes out of registers prepared inside this wave's own previous MFMA block) ----
-    f32x4 af[2][2];
-    af[0][0] = *reinterpret_cast<const srf_lds_f32x4 *>(G.f0);
-    af[0][1] = *reinterpret_cast<const srf_lds_f32x4 *>(G.f1);
-    const unsigned ro = *reinterpret_cast<const __attribute__((address_space(3))) unsigned *>(G.pin_addr);    // list entry of step i + 3
-    const unsigned sl4 = *reinterpret_cast<const __attribute__((address_space(3))) unsigned *>(G.slot_addr);  // slots of step i + 1
+    // ---- LDS / memory instructions only.  In-kernel stamps (the ping-pong experiment, tools/micro/spconv_gsq_experiment.patch): a wave
+    // issues NO vector instruction while the partner wave of its SIMD -- here: the CU's other workgroup -- streams f32 MFMAs, at any
+    // s_setprio; a step whose first instruction is an address add therefore stands still until the partner's MFMA block is over, and
+    // the two workgroups take turns instead of overlapping.  Every address below comes out of registers prepared inside this
+    // wave's own previous MFMA block ----
+    f32x4 af[2][GP][2];
+#pragma unroll
+    for (int gp = 0; gp < GP; ++gp) {
+        af[0][gp][0] = *reinterpret_cast<const srf_lds_f32x4 *>(G.f0 + gp * 2048);
+        af[0][gp][1] = *reinterpret_cast<const srf_lds_f32x4 *>(G.f1 + gp * 2048);
+    }
+    unsigned ro[GP], sl4[GP];
+#pragma unroll
+    for (int gp = 0; gp < GP; ++gp) {
+        ro[gp] = *reinterpret_cast<srf_lds_u32 *>(G.pin_addr + gp * 64);     // list entries of step i + 3
+        sl4[gp] = *reinterpret_cast<srf_lds_u32 *>(G.slot_addr + gp * 16);   // slots of step i + 1
+    }
     const unsigned inf = *reinterpret_cast<const __attribute__((address_space(3))) unsigned char *>(G.info_addr);  // ... and its offset flag
     if (ABL != 2) {
         // A[i + 1]: rows gathered during step i - 1, into the buffer the previous step read
 #pragma unroll
-        for (int j = 0; j < NA; ++j)
+        for (int gp = 0; gp < GP; ++gp)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<srf_lds_float *>(G.st[jj] + j * (2 * CHS * 4)) = ra[j][jj];
+            for (int j = 0; j < NA; ++j)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<srf_lds_float *>(G.st[jj] + gp * 2048 + j * (2 * CHS * 4)) = ra[gp][j][jj];
         // rows of step i + 2 (dummy steps behind the last one: out-of-range offsets, zeros)
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)G.gaddr + j * 256, 0, 0);
-            ra[j] = *reinterpret_cast<f32x4 *>(&v);
-        }
+        for (int gp = 0; gp < GP; ++gp)
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)G.gaddr[gp] + j * 256, 0, 0);
+                ra[gp][j] = *reinterpret_cast<f32x4 *>(&v);
+            }
     }
     if (LAST) {   // B of the next offset into the other register set, a whole step ahead (through a descriptor: not an invariant
                   // load the compiler may sink to its first use behind the barrier)
@@ -1457,48 +1473,58 @@ __device__ __forceinline__ void srf_gsp_step(__amdgpu_buffer_rsrc_t rs, __amdgpu
                 bn[c][g] = *reinterpret_cast<f32x4 *>(&v);
             }
     }
-    unsigned oaddr_n[4];
+    unsigned oaddr_n[GP][4];
     if (ABL == 5) t1 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_sched_barrier(0);
     // ---- the MFMA block: fragments of the next chunk requested a chunk ahead; the vector instructions of the step in its last chunk ----
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         if (c + 1 < NCH) {
-            af[(c + 1) & 1][0] = *reinterpret_cast<const srf_lds_f32x4 *>(G.f0 + (c + 1) * (CHS * 4));
-            af[(c + 1) & 1][1] = *reinterpret_cast<const srf_lds_f32x4 *>(G.f1 + (c + 1) * (CHS * 4));
+#pragma unroll
+            for (int gp = 0; gp < GP; ++gp) {
+                af[(c + 1) & 1][gp][0] = *reinterpret_cast<const srf_lds_f32x4 *>(G.f0 + gp * 2048 + (c + 1) * (CHS * 4));
+                af[(c + 1) & 1][gp][1] = *reinterpret_cast<const srf_lds_f32x4 *>(G.f1 + gp * 2048 + (c + 1) * (CHS * 4));
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const float a = af[c & 1][s >> 2][s & 3];
-            if (ABL == 1) {   // keep the operands alive, issue nothing
-                asm volatile("" ::"v"(a), "v"(bc[c][s >> 2][s & 3]), "v"(bc[c][NB - 2 + (s >> 2)][s & 3]));
-                continue;
+#pragma unroll
+            for (int gp = 0; gp < GP; ++gp) {
+                const float a = af[c & 1][gp][s >> 2][s & 3];
+                if (ABL == 1) {   // keep the operands alive, issue nothing
+                    asm volatile("" ::"v"(a), "v"(bc[c][s >> 2][s & 3]), "v"(bc[c][NB - 2 + (s >> 2)][s & 3]));
+                    continue;
+                }
+                acc[gp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[c][s >> 2][s & 3], acc[gp][0], 0, 0, 0);
+                if (NT == 2) acc[gp][NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[c][NB - 2 + (s >> 2)][s & 3], acc[gp][NT - 1], 0, 0, 0);
             }
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[c][s >> 2][s & 3], acc[0], 0, 0, 0);
-            if (NT == 2) acc[NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[c][NB - 2 + (s >> 2)][s & 3], acc[NT - 1], 0, 0, 0);
             if (c == NCH - 1 && s == 3) {
                 // (all fragment reads of the step are issued: the address registers are free to move on)
                 __builtin_amdgcn_sched_barrier(0);
                 buf ^= 1;
                 const int d = buf ? (int)ABUF : -(int)ABUF;   // the A buffers swap roles
-                unsigned ro_here = ro, sl_here = sl4, inf_here = inf;   // (opaque copies: the arithmetic on them must not be hoisted to the loads)
-                asm volatile("" : "+v"(ro_here), "+v"(sl_here), "+v"(inf_here));
+                unsigned inf_here = inf;   // (opaque copies: the arithmetic on the loaded values must not be hoisted to the loads)
+                asm volatile("" : "+v"(inf_here));
                 info_next = __builtin_amdgcn_readfirstlane((int)inf_here);
                 G.f0 += d;
                 G.f1 += d;
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    G.st[jj] -= d;
-                    oaddr_n[jj] = ((sl_here >> (8 * jj)) & 255u) * (unsigned)(OS * 4) + L.colbase;
+                for (int jj = 0; jj < 4; ++jj) G.st[jj] -= d;
+#pragma unroll
+                for (int gp = 0; gp < GP; ++gp) {
+                    unsigned ro_here = ro[gp], sl_here = sl4[gp];
+                    asm volatile("" : "+v"(ro_here), "+v"(sl_here));
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) oaddr_n[gp][jj] = ((sl_here >> (8 * jj)) & 255u) * (unsigned)(OS * 4) + L.colbase;
+                    G.gaddr[gp] = ro_here + L.goff;
+                    asm volatile("" : "+v"(G.gaddr[gp]), "+v"(oaddr_n[gp][0]), "+v"(oaddr_n[gp][1]), "+v"(oaddr_n[gp][2]), "+v"(oaddr_n[gp][3]));
                 }
-                G.gaddr = ro_here + L.goff;
-                G.pin_addr += 64;
-                G.slot_addr += 16;
+                G.pin_addr += RS * 4;
+                G.slot_addr += RS;
                 G.info_addr += 1;
-                asm volatile("" : "+v"(G.f0), "+v"(G.f1), "+v"(G.st[0]), "+v"(G.st[1]), "+v"(G.st[2]), "+v"(G.st[3]), "+v"(G.gaddr), "+v"(G.pin_addr),
+                asm volatile("" : "+v"(G.f0), "+v"(G.f1), "+v"(G.st[0]), "+v"(G.st[1]), "+v"(G.st[2]), "+v"(G.st[3]), "+v"(G.pin_addr),
                              "+v"(G.slot_addr), "+v"(G.info_addr));
-                asm volatile("" : "+v"(oaddr_n[0]), "+v"(oaddr_n[1]), "+v"(oaddr_n[2]), "+v"(oaddr_n[3]));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -1507,7 +1533,9 @@ __device__ __forceinline__ void srf_gsp_step(__amdgpu_buffer_rsrc_t rs, __amdgpu
     if (ABL == 5) t2 = __builtin_amdgcn_s_memtime();
     if (ABL == 3) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) G.oaddr[jj] = oaddr_n[jj];
+        for (int gp = 0; gp < GP; ++gp)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) G.oaddr[gp][jj] = oaddr_n[gp][jj];
         __syncthreads();
         return;
     }
@@ -1515,21 +1543,27 @@ __device__ __forceinline__ void srf_gsp_step(__amdgpu_buffer_rsrc_t rs, __amdgpu
     // read after they were written); plain ds_read_b32 into the accumulator registers themselves (the compiler pairs them as
     // ds_read2 and then shuffles registers behind a wait), awaited before the barrier together with the stores ----
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
+    for (int gp = 0; gp < GP; ++gp)
 #pragma unroll
-        for (int cb = 0; cb < NT; ++cb) *reinterpret_cast<srf_lds_float *>(G.oaddr[jj] + cb * 64) = acc[cb][jj];
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int cb = 0; cb < NT; ++cb) *reinterpret_cast<srf_lds_float *>(G.oaddr[gp][jj] + cb * 64) = acc[gp][cb][jj];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int cb = 0; cb < NT; ++cb)
+    for (int gp = 0; gp < GP; ++gp)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            float t;
-            if (cb == 0) asm volatile("ds_read_b32 %0, %1" : "=v"(t) : "v"(oaddr_n[jj]) : "memory");
-            else asm volatile("ds_read_b32 %0, %1 offset:64" : "=v"(t) : "v"(oaddr_n[jj]) : "memory");
-            acc[cb][jj] = t;
-        }
+        for (int cb = 0; cb < NT; ++cb)
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) G.oaddr[jj] = oaddr_n[jj];   // (a renaming: the copies, if any, land in the next MFMA block)
+            for (int jj = 0; jj < 4; ++jj) {
+                float t;
+                if (cb == 0) asm volatile("ds_read_b32 %0, %1" : "=v"(t) : "v"(oaddr_n[gp][jj]) : "memory");
+                else asm volatile("ds_read_b32 %0, %1 offset:64" : "=v"(t) : "v"(oaddr_n[gp][jj]) : "memory");
+                acc[gp][cb][jj] = t;
+            }
+#pragma unroll
+    for (int gp = 0; gp < GP; ++gp)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) G.oaddr[gp][jj] = oaddr_n[gp][jj];   // (a renaming: the copies, if any, land in the next MFMA block)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (ABL == 5) t3 = __builtin_amdgcn_s_memtime();
     if (ABL != 4) __syncthreads();
@@ -1545,7 +1579,7 @@ __device__ __forceinline__ void srf_gsp_step(__amdgpu_buffer_rsrc_t rs, __amdgpu
 #endif
 }
 
-template <int NCH, int COUT, int ABL = 0>
+template <int NCH, int COUT, int ABL = 0, int GP = 1>
 __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restrict__ in, int A_in, const float *__restrict__ Wg, int K,
                                                          const int *__restrict__ nbr, int nbr_stride, int A_out,
                                                          const float *__restrict__ alpha, const float *__restrict__ beta,
@@ -1554,9 +1588,10 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
                                                          const int *__restrict__ tiles)
 {
     constexpr int NT = COUT / 64, NB = COUT / 32;
-    constexpr int NA = 16 * 8 * NCH / 256, NKW = (SRF_KMAX + 3) / 4, CHS = SRF_GS_CHS;
-    constexpr int TMAX = COUT == 128 ? SRF_GS_TMAX : 120, OS = COUT + 4;
-    constexpr int FL = SRF_GSP_FL(TMAX);
+    constexpr int RS = 16 * GP;   // rows per step (srf_gsp_step)
+    constexpr int NA = 16 * 8 * NCH / 256, NKW = (SRF_KMAX + 3) / 4, CHS = RS * 32 + 8;
+    constexpr int TMAX = COUT == 128 ? SRF_GS_TMAX : 128, OS = COUT + 4;   // (64 channels: 128 rows = the two ballot segments; 63 KB of LDS)
+    constexpr int FL = ((TMAX * SRF_KMAX + SRF_KMAX * (RS - 1) + RS - 1) / RS) * RS + 2 * RS;   // every offset padded to whole steps, two dummy steps
     static_assert(COUT == 128 || COUT == 64, "column tiling of the waves");
     static_assert(TMAX <= 128 && TMAX < 255, "two ballot segments of 64 rows; slots are bytes");
     static_assert(NA >= 1 && (NCH & 1) == 0, "fragment double buffer assumes an even chunk count");
@@ -1565,7 +1600,7 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
     __shared__ int s_cnt[SRF_KMAX];
     __shared__ int s_gstart[SRF_KMAX + 1];                  // first step of an offset; [KMAX] = steps of the sub-tile
     __shared__ int s_klist[SRF_KMAX + 2];                   // used offsets ascending; [KMAX] their count, [KMAX + 1] their bit mask
-    __shared__ unsigned char s_sinfo[FL / 16 + 4];          // per step: bit 0 = last step of its offset, bits 1.. = the next used offset
+    __shared__ unsigned char s_sinfo[FL / RS + 4];          // per step: bit 0 = last step of its offset, bits 1.. = the next used offset
     __shared__ __attribute__((aligned(16))) float s_out[(TMAX + 1) * OS];
     __shared__ __attribute__((aligned(16))) float s_a[2 * NCH * CHS];
 
@@ -1575,14 +1610,13 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
         A_out = A_out < live ? A_out : live;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (SRF_GSQ_PRIO) __builtin_amdgcn_s_setprio(3);
     int range0, range1;
     if (tiles) {
         const int T = srf_gs_ranges(A_cap);
         if ((int)blockIdx.x >= T) return;
         const int t = srf_xcd_tile(blockIdx.x, T);
-        range0 = tiles[t * SRF_GSQ_PIECES];
-        range1 = tiles[(t + 1) * SRF_GSQ_PIECES];
+        range0 = tiles[t];
+        range1 = tiles[t + 1];
         range1 = range1 < A_out ? range1 : A_out;
     } else {
         const int tm = srf_gs_tile_rows(A_out);
@@ -1624,7 +1658,7 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
     __syncthreads();
     if (tid < 64) {   // first step of every offset (exclusive prefix of the group counts), the used offsets in ascending order
         const int c = tid < SRF_KMAX ? s_cnt[tid] : 0;
-        const int ng = (c + 15) >> 4;
+        const int ng = (c + RS - 1) / RS;
         int x = ng;
 #pragma unroll
         for (int d = 1; d < 32; d <<= 1) {
@@ -1648,7 +1682,7 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
     for (int i = 0; i < NKW; ++i) {
         const int k = wave + 4 * i;
         if (k >= SRF_KMAX) break;
-        const int g0 = s_gstart[k + zero] * 16;
+        const int g0 = s_gstart[k + zero] * RS;
         int base = 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -1661,21 +1695,21 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
             }
             base += __popcll(m);
         }
-        const int pad = ((base + 15) & ~15) - base;   // padding of the offset's last group: zeros into the spare row
+        const int ng = (base + RS - 1) / RS;
+        const int pad = ng * RS - base;   // padding of the offset's last step (< RS <= 32 entries): zeros into the spare row
         if (lane < pad) {
             s_pin[g0 + base + lane] = 0x80000000u;
             s_pslot[g0 + base + lane] = (unsigned char)TMAX;
         }
-        const int ng = (base + 15) >> 4;
         if (lane < ng) {
             const unsigned later = k + 1 < 32 ? (used >> (k + 1)) : 0u;
             const int kn = later ? k + 1 + __builtin_ctz(later) : k;   // the next used offset (the last one names itself)
-            s_sinfo[(g0 >> 4) + lane] = (unsigned char)(lane == ng - 1 ? ((kn << 1) | 1) : 0);
+            s_sinfo[g0 / RS + lane] = (unsigned char)(lane == ng - 1 ? ((kn << 1) | 1) : 0);
         }
     }
-    if (tid < 32) {   // two dummy steps behind the last one
-        s_pin[S * 16 + tid] = 0x80000000u;
-        s_pslot[S * 16 + tid] = (unsigned char)TMAX;
+    if (tid < 2 * RS) {   // two dummy steps behind the last one
+        s_pin[S * RS + tid] = 0x80000000u;
+        s_pslot[S * RS + tid] = (unsigned char)TMAX;
     }
     __syncthreads();
     const int ntap = __builtin_amdgcn_readfirstlane(s_klist[SRF_KMAX]);
@@ -1697,25 +1731,29 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
         L.boff = (unsigned)(lane * 16 + wc * 4096 + g0 * 1024 + zero);
     }
     __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wg), 0, K * NCH * NB * 4096, 0x00020000);
-    f32x4 b0[NCH][NB], b1[NCH][NB], ra[NA], acc[NT];
-    SrfGspRegs G;
+    f32x4 b0[NCH][NB], b1[NCH][NB], ra[GP][NA], acc[GP][NT];
+    SrfGspRegs<GP> G;
     int buf = 0;
     {
         constexpr unsigned ABUF = NCH * CHS * 4;
         const int aj = lane >> 4;
         G.f0 = L.fo0;
         G.f1 = L.fo1;
-        const unsigned sl0 = *reinterpret_cast<const unsigned *>(s_pslot + aj * 4);   // slots of step 0
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            G.st[jj] = L.sto[jj] + ABUF;
-            G.oaddr[jj] = ((sl0 >> (8 * jj)) & 255u) * (unsigned)(OS * 4) + L.colbase;
+        for (int jj = 0; jj < 4; ++jj) G.st[jj] = L.sto[jj] + ABUF;
 #pragma unroll
-            for (int cb = 0; cb < NT; ++cb) acc[cb][jj] = 0.0f;   // the tile was just zeroed
+        for (int gp = 0; gp < GP; ++gp) {
+            const unsigned sl0 = *reinterpret_cast<const unsigned *>(s_pslot + gp * 16 + aj * 4);   // slots of step 0
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                G.oaddr[gp][jj] = ((sl0 >> (8 * jj)) & 255u) * (unsigned)(OS * 4) + L.colbase;
+#pragma unroll
+                for (int cb = 0; cb < NT; ++cb) acc[gp][cb][jj] = 0.0f;   // the tile was just zeroed
+            }
+            G.gaddr[gp] = s_pin[2 * RS + gp * 16 + (tid >> 4)] + L.goff;                // step 0 requests the rows of step 2
         }
-        G.gaddr = s_pin[2 * 16 + (tid >> 4)] + L.goff;                                 // step 0 requests the rows of step 2
-        G.pin_addr = srf_lds_addr(s_pin) + (unsigned)(3 * 16 + (tid >> 4)) * 4u;       // ... and reads the list entry of step 3
-        G.slot_addr = srf_lds_addr(s_pslot) + (unsigned)(16 + aj * 4);                 // ... and the slots of step 1
+        G.pin_addr = srf_lds_addr(s_pin) + (unsigned)(3 * RS + (tid >> 4)) * 4u;        // ... and reads the list entries of step 3
+        G.slot_addr = srf_lds_addr(s_pslot) + (unsigned)(RS + aj * 4);                  // ... and the slots of step 1
         G.info_addr = srf_lds_addr(s_sinfo) + 1u + (unsigned)zero;                      // ... and its offset flag
     }
     if (ntap > 0) {
@@ -1727,24 +1765,28 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
                 auto v = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(L.boff + g * 1024), (k0 * NCH + c) * (NB * 4096), 0);
                 b0[c][g] = *reinterpret_cast<f32x4 *>(&v);
             }
-        {
-            const unsigned ro = s_pin[tid >> 4];
+#pragma unroll
+        for (int gp = 0; gp < GP; ++gp) {
+            const unsigned ro = s_pin[gp * 16 + (tid >> 4)];
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
                 auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro + L.goff + j * 256), 0, 0);
-                ra[j] = *reinterpret_cast<f32x4 *>(&v);
+                ra[gp][j] = *reinterpret_cast<f32x4 *>(&v);
             }
         }
 #pragma unroll
-        for (int j = 0; j < NA; ++j)
+        for (int gp = 0; gp < GP; ++gp)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<srf_lds_float *>(L.sto[jj] + j * (2 * CHS * 4)) = ra[j][jj];
-        {
-            const unsigned ro = s_pin[16 + (tid >> 4)];
+            for (int j = 0; j < NA; ++j)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<srf_lds_float *>(L.sto[jj] + gp * 2048 + j * (2 * CHS * 4)) = ra[gp][j][jj];
+#pragma unroll
+        for (int gp = 0; gp < GP; ++gp) {
+            const unsigned ro = s_pin[RS + gp * 16 + (tid >> 4)];
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
                 auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro + L.goff + j * 256), 0, 0);
-                ra[j] = *reinterpret_cast<f32x4 *>(&v);
+                ra[gp][j] = *reinterpret_cast<f32x4 *>(&v);
             }
         }
     }
@@ -1761,17 +1803,17 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
     for (int i = 0; i < S;) {   // two offsets per trip: the B register sets swap roles without moves
         int info_next = 0;
         for (; !(info & 1); ++i) {
-            srf_gsp_step<NCH, COUT, false, ABL>(rs, wrs, 0, buf, L, G, b0, b1, ra, acc, stamp, info_next);
+            srf_gsp_step<NCH, COUT, GP, false, ABL>(rs, wrs, 0, buf, L, G, b0, b1, ra, acc, stamp, info_next);
             info = info_next;
         }
-        srf_gsp_step<NCH, COUT, true, ABL>(rs, wrs, info >> 1, buf, L, G, b0, b1, ra, acc, stamp, info_next);
+        srf_gsp_step<NCH, COUT, GP, true, ABL>(rs, wrs, info >> 1, buf, L, G, b0, b1, ra, acc, stamp, info_next);
         info = info_next;
         if (++i >= S) break;
         for (; !(info & 1); ++i) {
-            srf_gsp_step<NCH, COUT, false, ABL>(rs, wrs, 0, buf, L, G, b1, b0, ra, acc, stamp, info_next);
+            srf_gsp_step<NCH, COUT, GP, false, ABL>(rs, wrs, 0, buf, L, G, b1, b0, ra, acc, stamp, info_next);
             info = info_next;
         }
-        srf_gsp_step<NCH, COUT, true, ABL>(rs, wrs, info >> 1, buf, L, G, b1, b0, ra, acc, stamp, info_next);
+        srf_gsp_step<NCH, COUT, GP, true, ABL>(rs, wrs, info >> 1, buf, L, G, b1, b0, ra, acc, stamp, info_next);
         info = info_next;
         ++i;
     }
@@ -1814,441 +1856,7 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
     }
 #ifdef SRF_DEV
     if (ABL == 5 && tid == 0 && blockIdx.x < 512) {
-        long long *dst = srf_gsq_stamps + (size_t)blockIdx.x * 16;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j] = stamp[j];
-        dst[8] = __builtin_amdgcn_s_memtime() - tk0;
-    }
-#endif
-}
-
-// =====================================================================================================================
-// srf_spconv_gsq_k: the pipelined kernel above as a PING-PONG of two teams (round 5).
-// Measured on srf_spconv_gsp_k (128 -> 128, 35k rows): one workgroup per CU 269 us for two rounds, two per CU 233 us for one --
-// a step pair (2 x 2048 cycles of MFMA issue per SIMD) takes ~5700 cycles: the two workgroups of a CU do not fill each other's
-// gaps, they drift and collide (a wave waits at its barrier for a sibling that the OTHER workgroup's wave is holding up on its
-// SIMD).  Here the pairing is explicit: ONE workgroup of 512 threads per CU = two teams of four waves, each SIMD holding one wave
-// of either team (waves 0-3 / 4-7: MI355X_MICROARCH.md, "Two waves per SIMD"), each team with its own rows, row lists, output
-// tile and A images (2 x 78 KB of LDS: exactly what the two independent workgroups held).  A step is split into
-//   S phase: accumulators of the previous step back into the tile, those of this step and ALL fragments of its A image out of
-//            LDS into registers, the A image of the next step stored, the gather of the step after that (and at the end of an
-//            offset the next offset's B operands) requested;
-//   M phase: the step's 64 MFMAs from registers -- nothing else;
-// and the teams run half a step apart: while team 0 multiplies, team 1 does its S phase, a workgroup barrier, roles swapped.
-// The MFMA pipe of a SIMD then always has exactly one wave that wants it, and the LDS / VMEM / address work of the other wave
-// (different issue ports; its ~20 vector instructions get the slots the f32 MFMA leaves) runs underneath.  The chain per output
-// is unchanged (offset ascending, channel ascending): results stay bit-identical to the oracle and to the kernels above.
-// Rows: the cost cut is 4x finer than the ranges (srf_gs_pieces); a workgroup owns 8 consecutive pieces and walks them as 1, 2
-// or 4 pairs of sub-tiles of EQUAL cost (one per team, <= TMAX rows each), so both teams have the same number of steps up to
-// the padding of their groups; the shorter one idles for the difference.
-// =====================================================================================================================
-template <int NCH, int COUT>
-struct SrfGsqLds {
-    static constexpr int TMAX = COUT == 128 ? SRF_GS_TMAX : 120, OS = COUT + 4, FL = SRF_GSP_FL(TMAX), CHS = SRF_GS_CHS;
-    static constexpr int OUT_B = (TMAX + 1) * OS * 4, A_B = 2 * NCH * CHS * 4, PIN_B = FL * 4, PSLOT_B = FL;
-    static constexpr int SMALL_B = (SRF_KMAX + (SRF_KMAX + 1) + (SRF_KMAX + 1) + 1) * 4;   // s_cnt, s_gstart, s_klist, the team's step count
-    static constexpr int TEAM_B = (OUT_B + A_B + PIN_B + PSLOT_B + SMALL_B + 15) & ~15;
-};
-
-static bool srf_gsq_enabled()
-{
-    static const bool on = [] {
-        const char *e = getenv("SRF_SPCONV_GSQ");  // developer switch: 1 selects the ping-pong form (slower than srf_spconv_gsp_k: see above)
-        return e && e[0] == '1';
-    }();
-    return on;
-}
-
-#ifndef SRF_GSQ_PRIO
-#define SRF_GSQ_PRIO 1
-#endif
-// addresses a team's wave carries from one phase to the next: everything the S phase needs is computed in the M phase before it
-struct SrfGsqRegs {
-    unsigned f0, f1;        // fragment quads of the A image the NEXT S phase reads
-    unsigned st[4];         // where that S phase stores the rows of the step after it
-    unsigned gaddr;         // buffer offset of the row that S phase requests (step + 2)
-    unsigned oaddr_r[4];    // tile addresses of the accumulators it reads (its own step; the M phase writes them back there)
-    unsigned pin_addr;      // LDS address of the row-list entry it reads (step + 3: the request after next)
-    unsigned slot_addr;     // LDS address of the slots it reads (step + 1)
-};
-
-template <int NCH, int COUT, bool LAST, bool STAMP = false>
-__device__ __forceinline__ void srf_gsq_step(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t wrs, int kn, int &buf, const SrfGspLane &L,
-                                             SrfGsqRegs &G, f32x4 (&bc)[NCH][COUT / 32], f32x4 (&bn)[NCH][COUT / 32],
-                                             f32x4 (&ra)[16 * 8 * NCH / 256], f32x4 (&acc)[COUT / 64], long long (&stamp)[8])
-{
-    constexpr int NT = COUT / 64, NB = COUT / 32, NA = 16 * 8 * NCH / 256, CHS = SRF_GS_CHS, OS = COUT + 4;
-    constexpr unsigned ABUF = NCH * CHS * 4;
-    long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    if (STAMP) t0 = __builtin_amdgcn_s_memtime();
-    // ---------------- S phase: LDS and memory instructions only ----------------
-    // (in-kernel stamps: a wave issues NO vector instruction while the partner wave of its SIMD streams independent f32 MFMAs, at any
-    // s_setprio -- with ~20 address instructions in this phase it started when the partner's M phase was over and the two phases ran one
-    // after the other; every address below therefore comes out of registers prepared in the wave's own M phase)
-    const unsigned ro = *reinterpret_cast<const __attribute__((address_space(3))) unsigned *>(G.pin_addr);
-    const unsigned sl4 = *reinterpret_cast<const __attribute__((address_space(3))) unsigned *>(G.slot_addr);
-    f32x4 af[NCH][2];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        af[c][0] = *reinterpret_cast<const srf_lds_f32x4 *>(G.f0 + c * (CHS * 4));
-        af[c][1] = *reinterpret_cast<const srf_lds_f32x4 *>(G.f1 + c * (CHS * 4));
-    }
-#pragma unroll
-    for (int j = 0; j < NA; ++j)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<srf_lds_float *>(G.st[jj] + j * (2 * CHS * 4)) = ra[j][jj];
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-        auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)G.gaddr + j * 256, 0, 0);
-        ra[j] = *reinterpret_cast<f32x4 *>(&v);
-    }
-    if (LAST) {
-        const int so = kn * (NCH * NB * 4096);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int g = 0; g < NB; ++g) {
-                auto v = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(L.boff + g * 1024), so + c * (NB * 4096), 0);
-                bn[c][g] = *reinterpret_cast<f32x4 *>(&v);
-            }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int cb = 0; cb < NT; ++cb)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            float t;
-            if (cb == 0) asm volatile("ds_read_b32 %0, %1" : "=v"(t) : "v"(G.oaddr_r[jj]) : "memory");
-            else asm volatile("ds_read_b32 %0, %1 offset:64" : "=v"(t) : "v"(G.oaddr_r[jj]) : "memory");
-            acc[cb][jj] = t;
-        }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (STAMP) t1 = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    if (STAMP) t2 = __builtin_amdgcn_s_memtime();
-    // ---------------- M phase: the step's MFMAs, the accumulators back into the tile, the addresses of the next S phase ----------------
-    if (NT == 2) asm volatile("" : "+v"(acc[0]), "+v"(acc[NT - 1]));
-    else asm volatile("" : "+v"(acc[0]));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const float a = af[c][s >> 2][s & 3];
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[c][s >> 2][s & 3], acc[0], 0, 0, 0);
-            if (NT == 2) acc[NT - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[c][NB - 2 + (s >> 2)][s & 3], acc[NT - 1], 0, 0, 0);
-        }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int cb = 0; cb < NT; ++cb) *reinterpret_cast<srf_lds_float *>(G.oaddr_r[jj] + cb * 64) = acc[cb][jj];
-    __builtin_amdgcn_sched_barrier(0);
-    buf ^= 1;
-    {
-        // the A buffers swap roles: fragments of the next step from the one just stored into, its stores into the one just read
-        const int d = buf ? (int)ABUF : -(int)ABUF;
-        unsigned ro_here = ro, sl_here = sl4;
-        asm volatile("" : "+v"(ro_here), "+v"(sl_here));
-        G.f0 += d;
-        G.f1 += d;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            G.st[jj] -= d;
-            G.oaddr_r[jj] = ((sl_here >> (8 * jj)) & 255u) * (unsigned)(OS * 4) + L.colbase;
-        }
-        G.gaddr = ro_here + L.goff;
-        G.pin_addr += 64;
-        G.slot_addr += 16;
-        // pinned here: none of this may drift behind the second barrier into the next S phase
-        asm volatile("" : "+v"(G.f0), "+v"(G.f1), "+v"(G.st[0]), "+v"(G.st[1]), "+v"(G.st[2]), "+v"(G.st[3]), "+v"(G.gaddr), "+v"(G.pin_addr),
-                     "+v"(G.slot_addr));
-        asm volatile("" : "+v"(G.oaddr_r[0]), "+v"(G.oaddr_r[1]), "+v"(G.oaddr_r[2]), "+v"(G.oaddr_r[3]));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (STAMP) t3 = __builtin_amdgcn_s_memtime();
-    // a bare s_barrier, no wait for the LDS queue: the only LDS instructions of this phase are the accumulator stores above, into
-    // columns that no other wave touches (this wave reads them back in order; the epilogue reads them behind later barriers)
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (STAMP) {
-        const long long t4 = __builtin_amdgcn_s_memtime();
-        stamp[0] += t1 - t0;
-        stamp[1] += t2 - t1;
-        stamp[2] += t3 - t2;
-        stamp[3] += t4 - t3;
-        stamp[4] += 1;
-    }
-}
-
-template <int NCH, int COUT, bool STAMP = false>
-__global__ __launch_bounds__(512, 1) void srf_spconv_gsq_k(const float *__restrict__ in, int A_in, const float *__restrict__ Wg, int K,
-                                                         const int *__restrict__ nbr, int nbr_stride, int A_out,
-                                                         const float *__restrict__ alpha, const float *__restrict__ beta,
-                                                         const float *__restrict__ residual, int relu,
-                                                         float *__restrict__ out, const int *__restrict__ rows_dev,
-                                                         const int *__restrict__ tiles)
-{
-    using LD = SrfGsqLds<NCH, COUT>;
-    constexpr int NT = COUT / 64, NB = COUT / 32;
-    constexpr int NA = 16 * 8 * NCH / 256, NKW = (SRF_KMAX + 3) / 4, CHS = SRF_GS_CHS;
-    constexpr int TMAX = LD::TMAX, OS = LD::OS;
-    static_assert(COUT == 128 || COUT == 64, "column tiling of the waves");
-    static_assert(TMAX <= 128 && TMAX < 255, "two ballot segments of 64 rows; slots are bytes");
-    extern __shared__ __attribute__((aligned(16))) unsigned char srf_gsq_smem[];
-    const int tid = threadIdx.x, team = __builtin_amdgcn_readfirstlane(tid >> 8), tl = tid & 255, lane = tl & 63, wave = tl >> 6;
-    if (SRF_GSQ_PRIO) __builtin_amdgcn_s_setprio(3);
-    unsigned char *tb = srf_gsq_smem + team * LD::TEAM_B;
-    float *s_out = reinterpret_cast<float *>(tb);
-    float *s_a = reinterpret_cast<float *>(tb + LD::OUT_B);
-    unsigned *s_pin = reinterpret_cast<unsigned *>(tb + LD::OUT_B + LD::A_B);
-    unsigned char *s_pslot = tb + LD::OUT_B + LD::A_B + LD::PIN_B;
-    int *s_cnt = reinterpret_cast<int *>(tb + LD::OUT_B + LD::A_B + LD::PIN_B + LD::PSLOT_B);
-    int *s_gstart = s_cnt + SRF_KMAX, *s_klist = s_gstart + SRF_KMAX + 1, *s_steps = s_klist + SRF_KMAX + 1;
-    const int *s_steps_other = reinterpret_cast<const int *>(srf_gsq_smem + (team ^ 1) * LD::TEAM_B + LD::OUT_B + LD::A_B + LD::PIN_B + LD::PSLOT_B)
-                               + SRF_KMAX + 2 * (SRF_KMAX + 1);
-
-    const int A_cap = A_out;
-    if (rows_dev) {
-        const int live = *rows_dev;
-        A_out = A_out < live ? A_out : live;
-    }
-    const int R = srf_gs_ranges(A_cap), nwg = (R + 1) >> 1, T4 = SRF_GSQ_PIECES * R;
-    if ((int)blockIdx.x >= nwg) return;
-    const int p8 = srf_xcd_tile(blockIdx.x, nwg) * (2 * SRF_GSQ_PIECES);   // first of the workgroup's 8 pieces
-    const int ph = (A_out + T4 - 1) / T4;   // piece height without a cost cut
-    auto piece = [&](int p) -> int {
-        p = p < T4 ? p : T4;
-        int r = tiles ? tiles[p] : p * ph;
-        return r < A_out ? r : A_out;
-    };
-    // sub-tile pairs of the 8 pieces: 1 x (4 + 4), 2 x (2 + 2) or 4 x (1 + 1), the coarsest whose sub-tiles all fit
-    int npair = 1;
-    if (piece(p8 + 4) - piece(p8) > TMAX || piece(p8 + 8) - piece(p8 + 4) > TMAX) {
-        npair = 2;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (piece(p8 + 2 * q + 2) - piece(p8 + 2 * q) > TMAX) npair = 4;
-    }
-    const int pp = 4 / npair;   // pieces per sub-tile
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)((long long)A_in * (32 * NCH) * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wg), 0, K * NCH * NB * 4096, 0x00020000);
-    long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tk0 = 0, tp0 = 0, tl0 = 0, te0 = 0;
-    if (STAMP) tk0 = __builtin_amdgcn_s_memtime();
-    for (int u = 0; u < npair; ++u) {
-    const int ra0 = piece(p8 + (2 * u) * pp), ra1 = piece(p8 + (2 * u + 1) * pp), rb1 = piece(p8 + (2 * u + 2) * pp);   // team 0: [ra0, ra1), team 1: [ra1, rb1)
-    const int rows_a = ra1 - ra0, rows_b = rb1 - ra1;
-    const int msplit_a = (rows_a + TMAX - 1) / TMAX, msplit_b = (rows_b + TMAX - 1) / TMAX;
-    int msplit = msplit_a > msplit_b ? msplit_a : msplit_b;   // a piece taller than a tile (very sparse rows) is walked in slabs, by both teams
-    msplit = msplit < 1 ? 1 : msplit;
-    const int my0 = team ? ra1 : ra0, my1 = team ? rb1 : ra1;
-    const int TM = ((((my1 - my0) + msplit - 1) / msplit) + 7) & ~7;   // <= TMAX
-    for (int v = 0; v < msplit; ++v) {
-    const int row0 = my0 + v * TM;
-    const int row_end = row0 + TM < my1 ? row0 + TM : my1;   // may be empty (row_end <= row0): the team then only keeps the barriers
-    int zero = 0;
-    asm volatile("" : "+s"(zero));
-    if (STAMP) tp0 = __builtin_amdgcn_s_memtime();
-    for (int e = tl; e < TM * OS / 4; e += 256) reinterpret_cast<f32x4 *>(s_out)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int nv[NKW][2];
-#pragma unroll
-    for (int i = 0; i < NKW; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = wave + 4 * i, r = h * 64 + lane;
-            nv[i][h] = (k < K && row0 + r < row_end) ? nbr[(size_t)(k + zero) * nbr_stride + row0 + r] : -1;
-        }
-#pragma unroll
-    for (int i = 0; i < NKW; ++i) {
-        const int k = wave + 4 * i;
-        if (k >= SRF_KMAX) break;
-        const int c = __popcll(__ballot(nv[i][0] >= 0)) + __popcll(__ballot(nv[i][1] >= 0));
-        if (lane == 0) s_cnt[k] = c;
-    }
-    __syncthreads();
-    if (tl < 64) {
-        const int c = tl < SRF_KMAX ? s_cnt[tl] : 0;
-        const int ng = (c + 15) >> 4;
-        int x = ng;
-#pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
-            const int y = __shfl_up(x, d);
-            if (lane >= d) x += y;
-        }
-        if (tl < SRF_KMAX) s_gstart[tl] = x - ng;
-        if (tl == SRF_KMAX - 1) {
-            s_gstart[SRF_KMAX] = x;
-            s_steps[0] = x;
-        }
-        const unsigned long long m = __ballot(c > 0);
-        if (c > 0) s_klist[__popcll(m & ((1ull << tl) - 1ull))] = tl;
-        if (tl == 0) s_klist[SRF_KMAX] = __popcll(m);
-    }
-    __syncthreads();
-    const int S = __builtin_amdgcn_readfirstlane(s_gstart[SRF_KMAX]);
-    const int S_other = __builtin_amdgcn_readfirstlane(s_steps_other[0]);
-    const int N = S > S_other ? S : S_other;
-#pragma unroll
-    for (int i = 0; i < NKW; ++i) {
-        const int k = wave + 4 * i;
-        if (k >= SRF_KMAX) break;
-        const int g0 = s_gstart[k + zero] * 16;
-        int base = 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int vv = nv[i][h];
-            const unsigned long long m = __ballot(vv >= 0);
-            if (vv >= 0) {
-                const int pos = g0 + base + __popcll(m & ((1ull << lane) - 1ull));
-                s_pin[pos] = (unsigned)vv * (unsigned)(32 * NCH * 4);
-                s_pslot[pos] = (unsigned char)(h * 64 + lane);
-            }
-            base += __popcll(m);
-        }
-        const int pad = ((base + 15) & ~15) - base;
-        if (lane < pad) {
-            s_pin[g0 + base + lane] = 0x80000000u;
-            s_pslot[g0 + base + lane] = (unsigned char)TMAX;
-        }
-    }
-    if (tl < 32) {
-        s_pin[S * 16 + tl] = 0x80000000u;
-        s_pslot[S * 16 + tl] = (unsigned char)TMAX;
-    }
-    __syncthreads();
-    const int ntap = __builtin_amdgcn_readfirstlane(s_klist[SRF_KMAX]);
-
-    SrfGspLane L;
-    {
-        const int ar = lane & 15, aj = lane >> 4, a_swz = (ar >> 1) & 7;
-        const unsigned a0 = srf_lds_addr(s_a) + (unsigned)zero;
-        L.fo0 = a0 + (unsigned)(ar * 32 + (((aj << 1) ^ a_swz) << 2)) * 4u;
-        L.fo1 = a0 + (unsigned)(ar * 32 + ((((aj << 1) + 1) ^ a_swz) << 2)) * 4u;
-        L.colbase = srf_lds_addr(s_out) + (unsigned)((COUT == 128 ? wave * 32 : wave * 16) + ar + zero) * 4u;
-        const int r = tl >> 4, qq = tl & 15, ch = qq >> 3, q = qq & 7, swz = (r >> 1) & 7;
-        L.goff = (unsigned)(qq * 16 + zero);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) L.sto[jj] = a0 + (unsigned)(ch * CHS + r * 32 + (q & 3) + (((jj * 2 + (q >> 2)) ^ swz) << 2)) * 4u;
-        const int wc = COUT == 128 ? wave : (wave >> 1), g0 = COUT == 128 ? 0 : 2 * (wave & 1);
-        L.boff = (unsigned)(lane * 16 + wc * 4096 + g0 * 1024 + zero);
-    }
-    const int row_q = tl >> 4;
-    f32x4 b0[NCH][NB], b1[NCH][NB], ra[NA], acc[NT];
-    SrfGsqRegs G;
-    int buf = 0;
-    {
-        constexpr unsigned ABUF = NCH * CHS * 4;
-        const int aj = lane >> 4;
-        G.f0 = L.fo0;
-        G.f1 = L.fo1;
-        const unsigned sl0 = *reinterpret_cast<const unsigned *>(s_pslot + aj * 4);   // slots of step 0
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            G.st[jj] = L.sto[jj] + ABUF;
-            G.oaddr_r[jj] = ((sl0 >> (8 * jj)) & 255u) * (unsigned)(OS * 4) + L.colbase;
-#pragma unroll
-            for (int cb = 0; cb < NT; ++cb) acc[cb][jj] = 0.0f;
-        }
-        G.gaddr = s_pin[2 * 16 + row_q] + L.goff;                                   // step 0's S phase requests the rows of step 2
-        G.pin_addr = srf_lds_addr(s_pin) + (unsigned)(3 * 16 + row_q) * 4u;         // ... and reads the list entry of step 3
-        G.slot_addr = srf_lds_addr(s_pslot) + (unsigned)(16 + aj * 4);              // ... and the slots of step 1
-    }
-    if (ntap > 0) {
-        const int k0 = s_klist[0];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int g = 0; g < NB; ++g) {
-                auto vv = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(L.boff + g * 1024), (k0 * NCH + c) * (NB * 4096), 0);
-                b0[c][g] = *reinterpret_cast<f32x4 *>(&vv);
-            }
-        {
-            const unsigned ro = s_pin[row_q];
-#pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                auto vv = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro + L.goff + j * 256), 0, 0);
-                ra[j] = *reinterpret_cast<f32x4 *>(&vv);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NA; ++j)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<srf_lds_float *>(L.sto[jj] + j * (2 * CHS * 4)) = ra[j][jj];
-        {
-            const unsigned ro = s_pin[16 + row_q];
-#pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                auto vv = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro + L.goff + j * 256), 0, 0);
-                ra[j] = *reinterpret_cast<f32x4 *>(&vv);
-            }
-        }
-    }
-    __syncthreads();
-    if (STAMP) {
-        tl0 = __builtin_amdgcn_s_memtime();
-        stamp[5] += tl0 - tp0;
-    }
-    // the teams run half a step apart: team 1 starts one barrier late, team 0 ends one barrier late -- the same count for every wave
-    if (team == 1) __syncthreads();
-    for (int tk = 0; tk < ntap; tk += 2) {
-        {
-            const bool more = tk + 1 < ntap;
-            const int kc = __builtin_amdgcn_readfirstlane(s_klist[tk]), kn = more ? __builtin_amdgcn_readfirstlane(s_klist[tk + 1]) : kc;
-            const int i0 = __builtin_amdgcn_readfirstlane(s_gstart[kc]), i1 = __builtin_amdgcn_readfirstlane(s_gstart[kc + 1]);
-            for (int i = i0; i + 1 < i1; ++i) srf_gsq_step<NCH, COUT, false, STAMP>(rs, wrs, kn, buf, L, G, b0, b1, ra, acc, stamp);
-            srf_gsq_step<NCH, COUT, true, STAMP>(rs, wrs, kn, buf, L, G, b0, b1, ra, acc, stamp);
-        }
-        if (tk + 1 < ntap) {
-            const bool more = tk + 2 < ntap;
-            const int kc = __builtin_amdgcn_readfirstlane(s_klist[tk + 1]), kn = more ? __builtin_amdgcn_readfirstlane(s_klist[tk + 2]) : kc;
-            const int i0 = __builtin_amdgcn_readfirstlane(s_gstart[kc]), i1 = __builtin_amdgcn_readfirstlane(s_gstart[kc + 1]);
-            for (int i = i0; i + 1 < i1; ++i) srf_gsq_step<NCH, COUT, false, STAMP>(rs, wrs, kn, buf, L, G, b1, b0, ra, acc, stamp);
-            srf_gsq_step<NCH, COUT, true, STAMP>(rs, wrs, kn, buf, L, G, b1, b0, ra, acc, stamp);
-        }
-    }
-    for (int i = S; i < N; ++i) {   // the other team has more steps: keep its barriers company
-        __syncthreads();
-        __syncthreads();
-    }
-    if (team == 0) __syncthreads();
-    if (STAMP) {
-        te0 = __builtin_amdgcn_s_memtime();
-        stamp[6] += te0 - tl0;
-    }
-    __syncthreads();   // (every step wrote its accumulators back at the end of its M phase)
-
-    constexpr int CQ = COUT / 4;
-    const int c4 = ((tl & (CQ - 1)) + zero) * 4;
-    f32x4 al = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
-    if (alpha) {
-        al = *reinterpret_cast<const f32x4 *>(alpha + c4);
-        be = *reinterpret_cast<const f32x4 *>(beta + c4);
-    }
-    for (int r = tl / CQ; r < TM; r += 256 / CQ) {
-        const int row = row0 + r;
-        if (row >= row_end) break;
-        f32x4 vv = *reinterpret_cast<const f32x4 *>(s_out + r * OS + c4);
-        f32x4 rsd = {0.f, 0.f, 0.f, 0.f};
-        if (residual) rsd = *reinterpret_cast<const f32x4 *>(residual + (size_t)row * COUT + c4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float x = vv[j];
-            if (alpha) x = __fmaf_rn(x, al[j], be[j]);
-            if (residual) x = __fadd_rn(x, rsd[j]);
-            if (relu) x = x > 0.0f ? x : 0.0f;
-            vv[j] = x;
-        }
-        *reinterpret_cast<f32x4 *>(out + (size_t)row * COUT + c4) = vv;
-    }
-    __syncthreads();
-    if (STAMP) stamp[7] += __builtin_amdgcn_s_memtime() - te0;
-    }
-    }
-#ifdef SRF_DEV
-    if (STAMP && tl == 0 && blockIdx.x < 256) {
-        long long *dst = srf_gsq_stamps + ((size_t)blockIdx.x * 2 + team) * 16;
+        long long *dst = srf_gsp_stamps + (size_t)blockIdx.x * 16;
 #pragma unroll
         for (int j = 0; j < 8; ++j) dst[j] = stamp[j];
         dst[8] = __builtin_amdgcn_s_memtime() - tk0;
@@ -2363,37 +1971,6 @@ __global__ __launch_bounds__(512) void srf_spconv_w32_k(const float *__restrict_
     }
 }
 
-template <int NCH, int COUT>
-static int srf_gsq_launch(const float *in, int A_in, const float *W_packed, int K, const int *nbr, int nbr_stride, int A_out, const float *alpha,
-                          const float *beta, const float *residual, int relu, float *out, const int *rows_dev, const int *tiles, hipStream_t st)
-{
-    constexpr int lds = 2 * SrfGsqLds<NCH, COUT>::TEAM_B;
-    int dev = 0;
-    SRF_HIP_TRY(hipGetDevice(&dev));
-    static bool attr_set[64] = {false};
-    if (dev < 0 || dev >= 64) return SRF_EUNSUPPORTED;
-    if (!attr_set[dev]) {
-        SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_spconv_gsq_k<NCH, COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set[dev] = true;
-    }
-    const int nwg = (srf_gs_ranges(A_out) + 1) / 2;
-#ifdef SRF_DEV
-    if (getenv("SRF_GSQ_STAMP")) {
-        static bool attr2[64] = {false};
-        if (!attr2[dev]) {
-            SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_spconv_gsq_k<NCH, COUT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr2[dev] = true;
-        }
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gsq_k<NCH, COUT, true>), dim3(nwg), dim3(512), lds, st, in, A_in, W_packed, K, nbr, nbr_stride, A_out,
-                           alpha, beta, residual, relu, out, rows_dev, tiles);
-        return SRF_OK;
-    }
-#endif
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gsq_k<NCH, COUT>), dim3(nwg), dim3(512), lds, st, in, A_in, W_packed, K, nbr, nbr_stride, A_out,
-                       alpha, beta, residual, relu, out, rows_dev, tiles);
-    return SRF_OK;
-}
-
 extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const float *W_packed, int K, const int *nbr,
                                      int nbr_stride, int A_out, int Cout, const float *alpha, const float *beta,
                                      const float *residual, int relu, float *out, const int *rows_dev, const int *tiles,
@@ -2433,13 +2010,21 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
                            0, st, SRF_ARGS);
         break;
     case 64:
-        if (srf_gs_layout(Cin, Cout) && srf_gsp_enabled() && srf_gsq_enabled() && (long long)A_in * Cin * 4 < (1ll << 31)) {
-            const int rc = srf_gsq_launch<2, 64>(in, A_in, W_packed, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev, tiles, st);
-            if (rc != SRF_OK) return rc;
-            break;
-        }
         if (srf_gs_layout(Cin, Cout)) {
             const dim3 grid(tiles ? srf_gs_ranges(A_out) : SRF_GS_SLOTS * srf_gs_rounds(A_out));
+#ifdef SRF_DEV
+            if (srf_gsp_enabled() && (long long)A_in * Cin * 4 < (1ll << 31) && (getenv("SRF_GSP_ABL") || getenv("SRF_GSP_GP2"))) {
+                const bool stamp = getenv("SRF_GSP_ABL") && atoi(getenv("SRF_GSP_ABL")) == 5, gp2 = getenv("SRF_GSP_GP2") != nullptr;
+#define SRF_GSP_DEV64(A, G) hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gsp_k<2, 64, A, G>), grid, dim3(256), 0, st, in, A_in, W_packed, K, nbr, nbr_stride, \
+                                               A_out, alpha, beta, residual, relu, out, rows_dev, tiles)
+                if (stamp && gp2) SRF_GSP_DEV64(5, 2);
+                else if (stamp) SRF_GSP_DEV64(5, 1);
+                else if (gp2) SRF_GSP_DEV64(0, 2);
+                else SRF_GSP_DEV64(0, 1);
+#undef SRF_GSP_DEV64
+                break;
+            }
+#endif
             if (srf_gsp_enabled() && (long long)A_in * Cin * 4 < (1ll << 31))
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gsp_k<2, 64>), grid, dim3(256), 0, st, in, A_in, W_packed, K, nbr, nbr_stride, A_out,
                                    alpha, beta, residual, relu, out, rows_dev, tiles);
@@ -2457,12 +2042,6 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
                            st, SRF_ARGS);
         break;
     case 128: {
-        if (srf_gs_layout(Cin, Cout) && srf_gsp_enabled() && srf_gsq_enabled() && (long long)A_in * Cin * 4 < (1ll << 31)) {
-            const int rc = Cin == 128 ? srf_gsq_launch<4, 128>(in, A_in, W_packed, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev, tiles, st)
-                                      : srf_gsq_launch<2, 128>(in, A_in, W_packed, K, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev, tiles, st);
-            if (rc != SRF_OK) return rc;
-            break;
-        }
         if (srf_gs_layout(Cin, Cout)) {
             // >= the tiles of any live row count <= A_out / the ranges srf_spconv_tiles_build cut for this capacity
             const dim3 grid(tiles ? srf_gs_ranges(A_out) : SRF_GS_SLOTS * srf_gs_rounds(A_out));

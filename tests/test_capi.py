@@ -46,7 +46,7 @@ def test_host_side_helpers():
     assert L.srf_spconv_fwd(None, 0, 16, None, 27, None, 0, 10, 24, None, None, None, 0, None, None, None) == -1
     assert L.srf_roi_extract(None, 0, 128, None, 0, 7, 2, 56.0, None, 0, 0, 0, 0, None, None) == -1
     assert L.srf_spconv_fwd_packed(None, 0, 128, None, 27, None, 0, 10, 128, None, None, None, 0, None, None, None, None) == -1
-    assert L.srf_spconv_tiles_count(35000) == 2048 and L.srf_spconv_tiles_count(100) == 12 and L.srf_spconv_tiles_count(0) == 1   # 4 pieces of the cost cut per range
+    assert L.srf_spconv_tiles_count(35000) == 512 and L.srf_spconv_tiles_count(100) == 3 and L.srf_spconv_tiles_count(0) == 1
     assert L.srf_spconv_tiles_workspace_bytes(35000) >= 35000 * 4
     assert L.srf_spconv_tiles_build(None, 0, 27, 10, None, None, None, None) == -1
     assert L.srf_points_filter_workspace_bytes(30000) >= 8 and L.srf_points_filter_workspace_bytes(-1) == 0
