@@ -172,8 +172,10 @@ def main():
                            "replay as one hipGraph; per-launch times inside it: profiles/)")
         with torch.no_grad():
             for i in range(5):
-                # + SECOND and the BEV FPN: their GEMM-shaped layers report which arithmetic route they take (config.gemm_route)
-                model.extract_point_features([frames[(rank + i) % n_pool]])
+                if model.use_img:
+                    model.extract_bev([frames[(rank + i) % n_pool]])   # (the camera branch's launches are timed below: SECOND's stay out of its sums)
+                else:   # + SECOND and the BEV FPN: their GEMM-shaped layers report which arithmetic route they take (config.gemm_route)
+                    model.extract_point_features([frames[(rank + i) % n_pool]])
         torch.cuda.synchronize()
         records = ops.KERNEL_TIMING["spconv"]
     dense_source = roofline_source
