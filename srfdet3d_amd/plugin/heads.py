@@ -15,6 +15,7 @@ SingleSRFDetHead :2103-2630, DynamicConv :2633-2693): same registry names, const
 """
 import copy
 import math
+import os
 
 import numpy as np
 import torch
@@ -43,6 +44,18 @@ def _const(values, like):
         t = torch.tensor(key[0], dtype=like.dtype, device=like.device)
         _CONSTS[key] = t
     return t
+
+
+_STAGE_SIDE = {}
+
+
+def _stage_side_stream(device):
+    """one side stream per device for the forked half of a decoder stage (`_StageBase._fork_gather`)"""
+    key = (device.type, device.index)
+    st = _STAGE_SIDE.get(key)
+    if st is None:
+        st = _STAGE_SIDE[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 def _channels_last(feats):
@@ -225,18 +238,51 @@ class _StageBase(BaseModule):
                 and len(self.cls_module_lidar) <= 12 and len(self.reg_module_lidar) <= 12
                 and self.class_logits_lidar.weight.shape[0] <= 32 and 8 <= self.bboxes_delta_lidar.weight.shape[0] <= 32)
 
-    def _refine_hip(self, roi_feats, boxes_m, prop_feats, bs, n_p):
-        """The stage on the hand-written kernels of csrc/decoder.hip (inference): 10 launches (12 with geometry + gather) instead of ~60."""
-        C = self.feat_channels_lidar
-        R = bs * n_p
-        S = roi_feats.shape[1]
-        q0 = (roi_feats.mean(dim=1) if prop_feats is None else prop_feats).reshape(R, C).contiguous()
+    def _attend_hip(self, q0, bs):
+        """The half of a stage that needs no RoI feature (srfdet_head.py:1486-1496, :2636-2646 and the head of DynamicConv, :2671):
+        self-attention among the proposals + norm1, then the dynamic parameters.  -> (q1, params)."""
         mha = self.self_attn_lidar
         qkv = ops.linear(q0, mha.in_proj_weight, mha.in_proj_bias)
         att = ops.self_attention(qkv, mha.num_heads, batch=bs)  # among the proposals of each sample, one launch for the batch
         q1 = ops.linear(att, mha.out_proj.weight, mha.out_proj.bias, residual=q0, ln2=self.norm1_lidar)
         dc = self.inst_interact_lidar
-        params = ops.linear(q1, dc.dynamic_layer.weight, dc.dynamic_layer.bias)
+        return q1, ops.linear(q1, dc.dynamic_layer.weight, dc.dynamic_layer.bias)
+
+    def _fork_gather(self, prop_feats, bs, n_p, gather, default_on):
+        """Inside a graph capture the geometry + RoI gather of a stage (`gather()` -> (roi_feats, boxes_m)) and its attention half can be
+        two branches of the graph: neither reads what the other writes (the gather reads the boxes and the feature maps, the attention
+        half the proposal features), the gather fills 200 workgroups for 15-45 us, the attention half is a chain of four launches of
+        1-64 workgroups.  Measured (round 5, same box, alternating runs): the fusion stages of LC, whose gather + projection take 69 us
+        beside 42 us of attention, 33.12 -> 32.98 ms per frame; the LiDAR-only stages (23 us of gather) 3.66-3.67 -> 3.69 ms -- a fork /
+        join pair costs about what the short branch saves.  So: on for the fusion stages, off for the LiDAR-only ones
+        (SRF_STAGE_FORK=0 / 1 forces it).  -> (roi_feats, boxes_m, (q1, params) or None)."""
+        C = self.feat_channels_lidar
+        want = os.environ.get("SRF_STAGE_FORK")
+        on = default_on if want is None else want != "0"
+        if (prop_feats is None or not prop_feats.is_cuda or torch.is_grad_enabled() or self.training
+                or not torch.cuda.is_current_stream_capturing() or not on):
+            roi_feats, boxes_m = gather()
+            return roi_feats, boxes_m, None
+        main = torch.cuda.current_stream()
+        side = _stage_side_stream(prop_feats.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            roi_feats, boxes_m = gather()
+        attended = self._attend_hip(prop_feats.reshape(bs * n_p, C).contiguous(), bs) if self._hip_eligible(
+            prop_feats.new_empty((1, 49, 1))) else None
+        main.wait_stream(side)   # the join; everything the branch allocated stays referenced by the caller until the stage ends
+        return roi_feats, boxes_m, attended
+
+    def _refine_hip(self, roi_feats, boxes_m, prop_feats, bs, n_p, attended=None):
+        """The stage on the hand-written kernels of csrc/decoder.hip (inference): 10 launches (12 with geometry + gather) instead of ~60."""
+        C = self.feat_channels_lidar
+        R = bs * n_p
+        S = roi_feats.shape[1]
+        if attended is None:
+            q0 = (roi_feats.mean(dim=1) if prop_feats is None else prop_feats).reshape(R, C).contiguous()
+            attended = self._attend_hip(q0, bs)
+        q1, params = attended
+        dc = self.inst_interact_lidar
         mid = ops.dynconv_mid(roi_feats, params, dc.norm1, dc.norm2)
         obj = ops.linear(mid.view(R, S * C), dc.out_layer.weight, dc.out_layer.bias, ln1=dc.norm3, relu1=True, residual=q1,
                          ln2=self.norm2_lidar)
@@ -260,12 +306,12 @@ class _StageBase(BaseModule):
         pred = ops.apply_deltas(deltas, boxes_m.reshape(R, -1), self.bbox_weights[:6], self.pc_range_lidar, self.scale_clamp)
         return logits.view(bs, n_p, -1), pred.view(bs, n_p, -1), obj.view(1, R, C)
 
-    def _refine(self, roi_feats, boxes_m, prop_feats, bs, n_p):
+    def _refine(self, roi_feats, boxes_m, prop_feats, bs, n_p, attended=None):
         """roi_feats (R,S,C); boxes_m (bs,n_p,D) with centres in metres; prop_feats (bs,n_p,C)-viewable or None.
         Inference on the GPU runs `_refine_hip`; the torch formulation below is the autograd (training) form and what
         the host-side fixture tests exercise."""
         if self._hip_eligible(roi_feats):
-            return self._refine_hip(roi_feats, boxes_m, prop_feats, bs, n_p)
+            return self._refine_hip(roi_feats, boxes_m, prop_feats, bs, n_p, attended)
         C = self.feat_channels_lidar
         R = bs * n_p
         if prop_feats is None:
@@ -310,9 +356,12 @@ class SingleSRFDetHeadLiDAR(_StageBase):
         """(bs,n_p,D) boxes with normalised centres -> (logits (bs,n_p,#cls), boxes (bs,n_p,D), obj (1,bs*n_p,C)).
         `bboxes[..., :3]` is overwritten with metres, as in the reference."""
         bs, n_p = bboxes.shape[:2]
-        bboxes, rois, _ = self._geometry(bboxes, True, None)
-        roi_feats = self._gather(point_feats, rois, pooler)
-        return self._refine(roi_feats, bboxes, prop_feats, bs, n_p)
+
+        def gather():
+            boxes_m, rois, _ = self._geometry(bboxes, True, None)
+            return self._gather(point_feats, rois, pooler), boxes_m
+        roi_feats, boxes_m, attended = self._fork_gather(prop_feats, bs, n_p, gather, False)
+        return self._refine(roi_feats, boxes_m, prop_feats, bs, n_p, attended)
 
 
 @HEADS.register_module()
@@ -342,14 +391,17 @@ class SingleSRFDetHead(_StageBase):
     def forward(self, img_feats, point_feats, bboxes, prop_feats, pooler, img_metas, pooler_img=None):
         bs, n_p = bboxes.shape[:2]
         l2i = self._lidar2img(img_metas, bboxes) if img_feats is not None else None
-        bboxes, rois_bev, rois_img = self._geometry(bboxes, point_feats is not None, l2i)
-        if (img_feats is not None and point_feats is not None and self.use_fusion and rois_bev.is_cuda and not torch.is_grad_enabled()
+        if (img_feats is not None and point_feats is not None and self.use_fusion and bboxes.is_cuda and not torch.is_grad_enabled()
                 and isinstance(pooler, SingleRoIExtractor) and isinstance(pooler_img, SingleRoIExtractor)
-                and self._hip_eligible(rois_bev.new_empty((1, pooler.roi_layers[0].output_size ** 2, 1)))):
-            fused_in = self._fused_gather(img_feats, point_feats, rois_img, rois_bev, pooler_img, pooler, bs, n_p, l2i.shape[1])
-            roi_feats = ops.linear(fused_in.view(-1, fused_in.shape[-1]), self.output_fused_proj.weight,
-                                   self.output_fused_proj.bias).view(fused_in.shape[0], fused_in.shape[1], -1)
-            return self._refine(roi_feats, bboxes, prop_feats, bs, n_p)
+                and self._hip_eligible(bboxes.new_empty((1, pooler.roi_layers[0].output_size ** 2, 1)))):
+            def gather():
+                boxes_m, rois_bev, rois_img = self._geometry(bboxes, True, l2i)
+                fused_in = self._fused_gather(img_feats, point_feats, rois_img, rois_bev, pooler_img, pooler, bs, n_p, l2i.shape[1])
+                return ops.linear(fused_in.view(-1, fused_in.shape[-1]), self.output_fused_proj.weight,
+                                  self.output_fused_proj.bias).view(fused_in.shape[0], fused_in.shape[1], -1), boxes_m
+            roi_feats, boxes_m, attended = self._fork_gather(prop_feats, bs, n_p, gather, True)
+            return self._refine(roi_feats, boxes_m, prop_feats, bs, n_p, attended)
+        bboxes, rois_bev, rois_img = self._geometry(bboxes, point_feats is not None, l2i)
         img_roi = self._img_rois_feats(img_feats, rois_img, pooler_img, bs, n_p, l2i.shape[1]) \
             if img_feats is not None else None
         pts_roi = self._gather(point_feats, rois_bev, pooler) if point_feats is not None else None
