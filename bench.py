@@ -277,6 +277,21 @@ def main():
                          gbs=round(by / (ms * 1e-3) / 1e9, 1), frac_hbm=round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          measured=roofline_source)
 
+            # the two regimes of the stage apart: layers of at most 32 channels move 64-128 B per gathered row for 1-4 kFLOP --
+            # HBM / L2 bound, read against the 8 TB/s peak; layers from 64 channels up carry 22-33 FLOP per byte -- MFMA bound, read
+            # against the f32 MFMA peak
+            def _part(sel, label):
+                rr = [(s_.elapsed_time(e_), fl_, by_) for (s_, e_, cin, cout, K, fl_, by_) in records if sel(cin, cout)]
+                if not rr:
+                    return None
+                ms_, fl_, by_ = sum(r[0] for r in rr), sum(r[1] for r in rr), sum(r[2] for r in rr)
+                return dict(layers=label, launches_per_frame=round(len(rr) / nfr, 1), ms_per_frame=round(ms_ / nfr, 4),
+                            gflop_per_frame=round(fl_ / nfr / 1e9, 3), mbytes_per_frame=round(by_ / nfr / 1e6, 2),
+                            tflops=round(fl_ / (ms_ * 1e-3) / 1e12, 3), frac_mfma=round(fl_ / (ms_ * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                            gbs=round(by_ / (ms_ * 1e-3) / 1e9, 1), frac_hbm=round(by_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            stage["c_le_32"] = _part(lambda cin, cout: max(cin, cout) <= 32, "Cin, Cout <= 32 (bound: HBM; frac_hbm is the figure to read)")
+            stage["c_ge_64"] = _part(lambda cin, cout: max(cin, cout) >= 64, "Cout >= 64 (bound: f32 MFMA; frac_mfma is the figure to read)")
+
         def _dense(recs, kernel, name, passes=1, peak=F32_MFMA_PEAK_TFLOPS):
             if not recs:
                 return None

@@ -866,9 +866,11 @@ static bool srf_gs_enabled()
     }();
     return on;
 }
+static bool srf_gsp_enabled();
 static bool srf_gs_layout(int Cin, int Cout)
 {
-    return srf_gs_enabled() && ((Cout == 128 && (Cin == 64 || Cin == 128)) || (Cout == 64 && Cin == 64));
+    // (32 -> 64, the strided convolution into the 64-channel level: only the pipelined kernel srf_spconv_gsp_k has a one-chunk form)
+    return srf_gs_enabled() && ((Cout == 128 && (Cin == 64 || Cin == 128)) || (Cout == 64 && (Cin == 64 || (Cin == 32 && srf_gsp_enabled()))));
 }
 
 __global__ __launch_bounds__(256) void srf_pack_weights_gs_k(const float *__restrict__ W, int K, int Cin, int Cout, int nchunk,
@@ -1420,11 +1422,13 @@ struct SrfGspRegs {
 template <int NCH, int COUT, int GP, bool LAST, int ABL = 0>
 __device__ __forceinline__ void srf_gsp_step(__amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t wrs, int kn, int &buf, const SrfGspLane &L,
                                              SrfGspRegs<GP> &G, f32x4 (&bc)[NCH][COUT / 32], f32x4 (&bn)[NCH][COUT / 32],
-                                             f32x4 (&ra)[GP][16 * 8 * NCH / 256], f32x4 (&acc)[GP][COUT / 64], long long (&stamp)[8], int &info_next)
+                                             f32x4 (&ra)[GP][NCH >= 2 ? NCH / 2 : 1], f32x4 (&acc)[GP][COUT / 64], long long (&stamp)[8], int &info_next)
 {
-    constexpr int NT = COUT / 64, NB = COUT / 32, NA = 16 * 8 * NCH / 256, RS = 16 * GP, CHS = RS * 32 + 8, OS = COUT + 4;
+    constexpr int NT = COUT / 64, NB = COUT / 32, NA = NCH >= 2 ? NCH / 2 : 1, RS = 16 * GP, CHS = RS * 32 + 8, OS = COUT + 4;
+    constexpr int TPR = NCH >= 2 ? 16 : 8;     // threads per gathered row (a quad each; rows of 128 channels: two quads each)
     constexpr unsigned ABUF = NCH * CHS * 4;   // bytes of one A buffer
     typedef const __attribute__((address_space(3))) unsigned srf_lds_u32;
+    const bool gathers = TPR == 16 || threadIdx.x < 16 * TPR;   // 32-channel rows: 128 threads (two waves) carry a group of 16 rows
     long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if (ABL == 5) t0 = __builtin_amdgcn_s_memtime();
     // ---- LDS / memory instructions only.  In-kernel stamps (the ping-pong experiment, tools/micro/spconv_gsq_experiment.patch): a wave
@@ -1445,7 +1449,7 @@ __device__ __forceinline__ void srf_gsp_step(__amdgpu_buffer_rsrc_t rs, __amdgpu
         sl4[gp] = *reinterpret_cast<srf_lds_u32 *>(G.slot_addr + gp * 16);   // slots of step i + 1
     }
     const unsigned inf = *reinterpret_cast<const __attribute__((address_space(3))) unsigned char *>(G.info_addr);  // ... and its offset flag
-    if (ABL != 2) {
+    if (ABL != 2 && gathers) {
         // A[i + 1]: rows gathered during step i - 1, into the buffer the previous step read
 #pragma unroll
         for (int gp = 0; gp < GP; ++gp)
@@ -1589,12 +1593,12 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
 {
     constexpr int NT = COUT / 64, NB = COUT / 32;
     constexpr int RS = 16 * GP;   // rows per step (srf_gsp_step)
-    constexpr int NA = 16 * 8 * NCH / 256, NKW = (SRF_KMAX + 3) / 4, CHS = RS * 32 + 8;
+    constexpr int NA = NCH >= 2 ? NCH / 2 : 1, TPR = NCH >= 2 ? 16 : 8, NKW = (SRF_KMAX + 3) / 4, CHS = RS * 32 + 8;
     constexpr int TMAX = COUT == 128 ? SRF_GS_TMAX : 128, OS = COUT + 4;   // (64 channels: 128 rows = the two ballot segments; 63 KB of LDS)
     constexpr int FL = ((TMAX * SRF_KMAX + SRF_KMAX * (RS - 1) + RS - 1) / RS) * RS + 2 * RS;   // every offset padded to whole steps, two dummy steps
     static_assert(COUT == 128 || COUT == 64, "column tiling of the waves");
     static_assert(TMAX <= 128 && TMAX < 255, "two ballot segments of 64 rows; slots are bytes");
-    static_assert(NA >= 1 && (NCH & 1) == 0, "fragment double buffer assumes an even chunk count");
+    static_assert(NCH == 1 || (NCH & 1) == 0, "a gathered row is one quad (32 channels) or NCH / 2 quads per thread");
     __shared__ unsigned s_pin[FL];                          // flat step list: byte offset of the input row (padding: out of range)
     __shared__ __attribute__((aligned(4))) unsigned char s_pslot[FL];  // ... and the row's slot in the output tile
     __shared__ int s_cnt[SRF_KMAX];
@@ -1723,7 +1727,7 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
         L.fo1 = a0 + (unsigned)(ar * 32 + ((((aj << 1) + 1) ^ a_swz) << 2)) * 4u;
         L.colbase = srf_lds_addr(s_out) + (unsigned)((COUT == 128 ? wave * 32 : wave * 16) + ar + zero) * 4u;
         // gather: thread = (row tid / 16, quad tid % 16 of the row, and for Cin = 128 the quad 16 further = two chunks further)
-        const int r = tid >> 4, qq = tid & 15, ch = qq >> 3, q = qq & 7, swz = (r >> 1) & 7;
+        const int r = (tid / TPR) & 15, qq = tid % TPR, ch = qq >> 3, q = qq & 7, swz = (r >> 1) & 7;
         L.goff = (unsigned)(qq * 16 + zero);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) L.sto[jj] = a0 + (unsigned)(ch * CHS + r * 32 + (q & 3) + (((jj * 2 + (q >> 2)) ^ swz) << 2)) * 4u;
@@ -1750,9 +1754,9 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
 #pragma unroll
                 for (int cb = 0; cb < NT; ++cb) acc[gp][cb][jj] = 0.0f;   // the tile was just zeroed
             }
-            G.gaddr[gp] = s_pin[2 * RS + gp * 16 + (tid >> 4)] + L.goff;                // step 0 requests the rows of step 2
+            G.gaddr[gp] = s_pin[2 * RS + gp * 16 + ((tid / TPR) & 15)] + L.goff;        // step 0 requests the rows of step 2
         }
-        G.pin_addr = srf_lds_addr(s_pin) + (unsigned)(3 * RS + (tid >> 4)) * 4u;        // ... and reads the list entries of step 3
+        G.pin_addr = srf_lds_addr(s_pin) + (unsigned)(3 * RS + ((tid / TPR) & 15)) * 4u;   // ... and reads the list entries of step 3
         G.slot_addr = srf_lds_addr(s_pslot) + (unsigned)(RS + aj * 4);                  // ... and the slots of step 1
         G.info_addr = srf_lds_addr(s_sinfo) + 1u + (unsigned)zero;                      // ... and its offset flag
     }
@@ -1767,22 +1771,24 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
             }
 #pragma unroll
         for (int gp = 0; gp < GP; ++gp) {
-            const unsigned ro = s_pin[gp * 16 + (tid >> 4)];
+            const unsigned ro = s_pin[gp * 16 + ((tid / TPR) & 15)];
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
                 auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro + L.goff + j * 256), 0, 0);
                 ra[gp][j] = *reinterpret_cast<f32x4 *>(&v);
             }
         }
+        if (TPR == 16 || tid < 16 * TPR) {
 #pragma unroll
-        for (int gp = 0; gp < GP; ++gp)
+            for (int gp = 0; gp < GP; ++gp)
 #pragma unroll
-            for (int j = 0; j < NA; ++j)
+                for (int j = 0; j < NA; ++j)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<srf_lds_float *>(L.sto[jj] + gp * 2048 + j * (2 * CHS * 4)) = ra[gp][j][jj];
+                    for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<srf_lds_float *>(L.sto[jj] + gp * 2048 + j * (2 * CHS * 4)) = ra[gp][j][jj];
+        }
 #pragma unroll
         for (int gp = 0; gp < GP; ++gp) {
-            const unsigned ro = s_pin[RS + gp * 16 + (tid >> 4)];
+            const unsigned ro = s_pin[RS + gp * 16 + ((tid / TPR) & 15)];
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
                 auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro + L.goff + j * 256), 0, 0);
@@ -2013,7 +2019,7 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
         if (srf_gs_layout(Cin, Cout)) {
             const dim3 grid(tiles ? srf_gs_ranges(A_out) : SRF_GS_SLOTS * srf_gs_rounds(A_out));
 #ifdef SRF_DEV
-            if (srf_gsp_enabled() && (long long)A_in * Cin * 4 < (1ll << 31) && (getenv("SRF_GSP_ABL") || getenv("SRF_GSP_GP2"))) {
+            if (Cin == 64 && srf_gsp_enabled() && (long long)A_in * Cin * 4 < (1ll << 31) && (getenv("SRF_GSP_ABL") || getenv("SRF_GSP_GP2"))) {
                 const bool stamp = getenv("SRF_GSP_ABL") && atoi(getenv("SRF_GSP_ABL")) == 5, gp2 = getenv("SRF_GSP_GP2") != nullptr;
 #define SRF_GSP_DEV64(A, G) hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gsp_k<2, 64, A, G>), grid, dim3(256), 0, st, in, A_in, W_packed, K, nbr, nbr_stride, \
                                                A_out, alpha, beta, residual, relu, out, rows_dev, tiles)
@@ -2025,7 +2031,11 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
                 break;
             }
 #endif
-            if (srf_gsp_enabled() && (long long)A_in * Cin * 4 < (1ll << 31))
+            if (Cin == 32) {   // only the pipelined kernel has a one-chunk form (the weights are packed for it: srf_gs_layout)
+                if ((long long)A_in * Cin * 4 >= (1ll << 31)) return SRF_EUNSUPPORTED;
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gsp_k<1, 64>), grid, dim3(256), 0, st, in, A_in, W_packed, K, nbr, nbr_stride, A_out,
+                                   alpha, beta, residual, relu, out, rows_dev, tiles);
+            } else if (srf_gsp_enabled() && (long long)A_in * Cin * 4 < (1ll << 31))
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gsp_k<2, 64>), grid, dim3(256), 0, st, in, A_in, W_packed, K, nbr, nbr_stride, A_out,
                                    alpha, beta, residual, relu, out, rows_dev, tiles);
             else
@@ -2059,6 +2069,13 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
                     else if (abl == 5) SRF_GSP_DEV(5);
                     else SRF_GSP_DEV(0);
 #undef SRF_GSP_DEV
+                    break;
+                }
+#endif
+#ifdef SRF_DEV
+                if (Cin == 64 && getenv("SRF_GSP_ABL") && atoi(getenv("SRF_GSP_ABL")) == 5) {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_gsp_k<2, 128, 5>), grid, dim3(256), 0, st, in, A_in, W_packed, K, nbr, nbr_stride,
+                                       A_out, alpha, beta, residual, relu, out, rows_dev, tiles);
                     break;
                 }
 #endif

@@ -360,7 +360,7 @@ def pack_spconv_weights(weight):
 
 def spconv_tiles_wanted(Cin, Cout):
     """True for the layer shapes whose packed kernel takes work-balanced row ranges (`tiles=` of spconv_fwd)."""
-    return (Cout == 128 and Cin in (64, 128)) or (Cout == 64 and Cin == 64)
+    return (Cout == 128 and Cin in (64, 128)) or (Cout == 64 and Cin in (32, 64))
 
 
 def spconv_tiles(nbr, rows_dev=None):
