@@ -67,6 +67,7 @@ class SRFDet(BaseModule):
         # hard voxelization: the whole LiDAR frame replays as one graph (no host read-back inside the frame); with
         # cameras it reads the image graph's feature buffers in place
         self._graphed_frame = GraphedFrame(self) if (enabled and whole_frame and GraphedFrame.eligible(self)) else None
+        self._graph_weights_sig = self._weights_signature()
         return self
 
     def _drop_derived_state(self):
@@ -84,9 +85,33 @@ class SRFDet(BaseModule):
     def train(self, mode=True):
         """Also drops what was derived from the weights (`_drop_derived_state`): whatever was done to them before a mode switch --
         incl. in-place updates through `.data`, which the caches' (version, pointer) key cannot see -- the next inference pass
-        packs them afresh and recaptures its graphs."""
-        self._drop_derived_state()
+        packs them afresh and recaptures its graphs.  A call that changes nothing (`.eval()` on a model already in eval mode whose
+        parameters still are the tensors the graphs were captured with, at the same versions) keeps them."""
+        if bool(mode) != self.training or self._weights_signature() != getattr(self, "_graph_weights_sig", None):
+            self._drop_derived_state()
         return super().train(mode)
+
+    def _weights_signature(self):
+        """(sum of versions, sum of pointers, count) of the parameters and buffers: changes with every optimiser step, `copy_`,
+        `load_state_dict`, `.to()` / `.float()` (new storage); NOT with updates through `.data` -- call `weights_changed()` after those."""
+        v = p = n = 0
+        for t in list(self.parameters()) + list(self.buffers()):
+            v += t._version
+            p += t.data_ptr()
+            n += 1
+        return (v, p, n)
+
+    def weights_changed(self):
+        """Tell the model that its weights were modified in place while it stayed in eval mode (optimizer.step() between two
+        inference calls, `p.data.copy_()`, EMA updates): captured hipGraphs replay raw pointers to packed-weight images that no
+        longer match.  `train()`, `load_state_dict()` and `.to()` / `.cuda()` / `.float()` call this themselves."""
+        self._drop_derived_state()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if getattr(self, "_graph_cfg", None) is not None:
+            self._drop_derived_state()   # the parameters may live in new storage: every captured pointer is stale
+        return out
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)

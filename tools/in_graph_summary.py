@@ -6,7 +6,10 @@ HIP-event times of `roofline`).
     python tools/in_graph_summary.py profiles/r03_bench_nuscLC_np200_kernel_stats.csv nusc_LC 88 [out.json]
 
 `launches per frame` of the reference family (srf_wino43_mm_k: 88 on LC) turns call counts into frames: every graph replay,
-validation replay and warm-up pass of the traced process is a frame like any other."""
+validation replay and warm-up pass of the traced process is a frame like any other.  bench.py's eager post-timing passes of the camera
+branch (3, for the per-launch HIP events of `roofline`) run the same launches serially, not beside the BEV half: they are a few of ~80
+frames in the trace and bias `in_graph_ms_per_frame` low by that share; `_frames_in_trace` says how many frames the sums cover and
+`_eager_passes_in_trace` how many of them were those serial passes."""
 import csv
 import json
 import os
@@ -49,7 +52,8 @@ def main():
     if os.path.exists(out):
         res = json.load(open(out))
     res[workload] = {k: round(v[1] / 1e6 / frames, 3) for k, v in tot.items() if frames and v[0]}
-    res[workload]["_frames_in_trace"] = frames
+    res[workload]["_frames_in_trace"] = round(frames, 2)
+    res[workload]["_eager_passes_in_trace"] = 3
     res[workload]["_source"] = os.path.basename(path)
     res["kernel_source_sha16"] = source_id()
     json.dump(res, open(out, "w"), indent=1)

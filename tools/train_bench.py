@@ -127,6 +127,15 @@ def main():
         optm = sum(e[2].elapsed_time(e[3]) for e in phases) / len(phases)
         step_ms = dt / a.iters * 1e3
         comm_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in comm_events) / a.iters if comm_events else 0.0
+        # the per-bucket intervals start when the hook is CALLED (an event on the compute stream), so each contains the queueing behind
+        # earlier buckets and they overlap one another: their sum is an upper bound; the span from the first bucket's start to the last
+        # bucket's end (per step) is the time the communication stream was engaged at most
+        span_ms = 0.0
+        if comm_events:
+            per_step = max(1, len(comm_events) // a.iters)
+            for i in range(0, len(comm_events) - per_step + 1, per_step):
+                span_ms += comm_events[i][0].elapsed_time(comm_events[i + per_step - 1][1])
+            span_ms /= a.iters
         comm_bytes = sum(n for _, _, n in comm_events) / a.iters if comm_events else 0
         print(json.dumps(dict(metric="training iterations/s, srfdet_voxel_nusc_LC", value=round(a.iters / dt, 3), n_gpus=world,
                               frames_per_s=round(a.iters * a.bs * world / dt, 3), bs_per_gpu=a.bs, num_proposals=a.np,
@@ -135,11 +144,13 @@ def main():
                               phases_ms=dict(forward_and_loss=round(fwd, 2), backward_incl_overlapped_allreduce=round(bwd, 2),
                                              clip_and_optimizer=round(optm, 2)),
                               backward_share_of_step=round(bwd / step_ms, 4),
-                              grad_allreduce=dict(ms_on_comm_stream_per_step=round(comm_ms, 3), bytes_per_step=int(comm_bytes),
+                              grad_allreduce=dict(ms_on_comm_stream_per_step=round(comm_ms, 3), first_start_to_last_end_ms_per_step=round(span_ms, 3),
+                                                  upper_bound=True, verified_on_gpus=None if world == 1 else world, bytes_per_step=int(comm_bytes),
                                                   buckets_per_step=round(len(comm_events) / a.iters, 1),
                                                   share_of_step=round(comm_ms / step_ms, 4),
-                                                  note="RCCL all-reduce of the DDP buckets, HIP events on the stream they run on; they overlap "
-                                                       "with backward (world == 1: no collective)"),
+                                                  note="RCCL all-reduce of the DDP buckets; per-bucket intervals from the hook call to the future's callback "
+                                                       "(they include queueing behind earlier buckets and overlap one another: an UPPER bound, as is the "
+                                                       "first-start-to-last-end span); the buckets overlap with backward (world == 1: no collective)"),
                               loss_scalar_allreduces_per_step=1 if world > 1 else 0)))
     if rank == 0 and a.kernel_table:
         from torch.profiler import ProfilerActivity, profile
