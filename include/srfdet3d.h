@@ -469,6 +469,18 @@ int srf_conv_gemm_nhwc_split(const float *x, int N, int H, int W, int Cin, long 
 
 
 
+/* srf_conv_wgrad_nhwc (training, config 4): the WEIGHT gradient of a stride-1 Conv2d on channels-last tensors,
+ *   dW[co][ci][ky][kx] = sum over (n, y, x) of g[n][y][x][co] * x[n][y + ky - pad][x + kx - pad][ci],
+ * ksize 1 (padding 0) or 3 (padding 1) -- what torch.autograd computes through aten::convolution_backward for the trainable layers of
+ * tools/train.py:220-234 (VoVNet stages 4-5, vovnet.py:354-374; the image FPN; the head's img_convs, srfdet_head.py:404-416), there on
+ * MIOpen's float-atomic split-K kernels.  Here: an f32 GEMM over the pixels on the bf16 MFMA through the exact three-way split of both
+ * operands (csrc/wgrad.hip), the pixel ranges added in a fixed order: deterministic.  g: (N, H, W, g_ld) with Cout channels, x:
+ * (N, H, W, x_ld) with Cin channels, dW: (Cout, Cin, ksize, ksize) contiguous; workspace: srf_conv_wgrad_workspace_bytes bytes.
+ * Cin % 4 == Cout % 4 == 0, W >= 32, tensors below 2 GB, 16-byte aligned bases, g_ld % 4 == x_ld % 4 == 0; else SRF_EUNSUPPORTED. */
+size_t srf_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int ksize);
+int srf_conv_wgrad_nhwc(const float *g, long long g_ld, const float *x, long long x_ld, int N, int H, int W, int Cin, int Cout, int ksize,
+                        void *workspace, size_t workspace_bytes, float *dW, srf_stream_t stream);
+
 /* srf_conv1x1_nhwc_topdown: an FPN lateral convolution with the top-down step in its epilogue (mmdet FPN.forward:
  * `laterals[i - 1] += F.interpolate(laterals[i], size=..., mode="nearest")`, necks of configs/nus/srfdet_voxel_nusc_LC.py:55-64
  * and :67-76): y[n][py][px][co] = act(conv) + top[n][floor(py Ht / H)][floor(px Wt / W)][co].  x rows are the pixels of an

@@ -60,6 +60,8 @@ SIGNATURES = {
     "srf_spconv_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int]),
     "srf_spconv_pack_weights": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "srf_spconv_fwd_packed": (c_int, [_P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    "srf_conv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "srf_conv_wgrad_nhwc": (c_int, [_P, c_int64, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
     "srf_spconv_tiles_count": (c_int, [c_int]),
     "srf_spconv_tiles_row_cost": (c_int, []),
     "srf_spconv_tiles_workspace_bytes": (c_size_t, [c_int]),

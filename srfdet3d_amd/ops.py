@@ -1484,6 +1484,36 @@ def conv_gemm_nhwc(x, packed_weight, Cout, ksize, stride, pad, scale=None, shift
     return out
 
 
+def conv_wgrad_supported(g, x, ksize):
+    """Shapes `conv_wgrad_nhwc` takes: (N, H, W, C) channel slices of channels-last f32 buffers, ksize 1 or 3, W >= 32, channel counts
+    and pixel pitches multiples of 4, every tensor below 2 GB."""
+    try:
+        g_ld, x_ld = nhwc_ld(g), nhwc_ld(x)
+    except RuntimeError:
+        return False
+    N, H, W, Cin = x.shape
+    Cout = g.shape[3]
+    return (ksize in (1, 3) and tuple(g.shape[:3]) == (N, H, W) and W >= 32 and Cin % 4 == 0 and Cout % 4 == 0 and g_ld % 4 == 0
+            and x_ld % 4 == 0 and g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and N * H * W * max(g_ld, x_ld) * 4 < (1 << 31))
+
+
+def conv_wgrad_nhwc(g, x, ksize):
+    """Weight gradient of a stride-1 Conv2d (ksize 1 / padding 0, or ksize 3 / padding 1) from the channels-last output gradient
+    g (N, H, W, Cout) and input x (N, H, W, Cin): -> (Cout, Cin, ksize, ksize), `srf_conv_wgrad_nhwc` (an f32 GEMM over the pixels on
+    the bf16 MFMA, exact three-way split of both operands, fixed summation order: deterministic)."""
+    if not conv_wgrad_supported(g, x, ksize):
+        raise ValueError("conv_wgrad_nhwc: unsupported shapes / layout")
+    N, H, W, Cin = x.shape
+    Cout = g.shape[3]
+    L = _lib.lib()
+    nbytes = L.srf_conv_wgrad_workspace_bytes(N, H, W, Cin, Cout, ksize)
+    ws = _empty((max(nbytes, 4) // 4,), torch.float32, x.device)
+    dW = _empty((Cout, Cin, ksize, ksize), torch.float32, x.device)
+    check(L.srf_conv_wgrad_nhwc(_ptr(g), nhwc_ld(g), _ptr(x), nhwc_ld(x), N, H, W, Cin, Cout, ksize, _ptr(ws), nbytes, _ptr(dW), _stream()),
+          "conv_wgrad_nhwc")
+    return dW
+
+
 def conv_gemm_nhwc_supported(x):
     """Layout / size limits of srf_conv_gemm_nhwc as `conv_gemm_nhwc` drives it (batches are split, one image must fit)."""
     try:

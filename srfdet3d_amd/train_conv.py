@@ -43,6 +43,25 @@ def enabled():
     return os.environ.get("SRF_TRAIN_CONV", "1") != "0"
 
 
+def _weight_grad(gn, xn, weight, k):
+    """dW of a stride-1 convolution from the channels-last output gradient gn (N, H, W, Cout) and input xn (N, H, W, Cin).
+    `srf_conv_wgrad_nhwc` (round 5: an f32 GEMM over the pixels on the bf16 MFMA, exact three-way split of both operands, pixel ranges
+    added in a fixed order -- deterministic) where it applies; else (SRF_TRAIN_WGRAD=0, maps narrower than 32 pixels, tensors of 2 GB)
+    the library route of rounds 3-4: aten.convolution_backward = MIOpen's float-atomic split-K kernels for 3x3, one rocBLAS GEMM for 1x1."""
+    Co, Ci = weight.shape[0], weight.shape[1]
+    fill = (Co * Ci) / float(((Co + 127) // 128) * ((Ci + 127) // 128) * 128 * 128)   # share of the kernel's 128 x 128 tiles that is real
+    # (192 -> 192, VoVNet stage 4: 56 % of the tiles -- measured 543 us against MIOpen's 465; every other trainable shape of config 4 is
+    # 1.1-3x faster on the kernel: profiles/r05_wgrad_bench.txt)
+    want = os.environ.get("SRF_TRAIN_WGRAD", "1")
+    if want != "0" and (fill >= 0.6 or k == 1 or want == "2") and ops.conv_wgrad_supported(gn, xn, k):
+        return ops.conv_wgrad_nhwc(gn, xn, k)
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    if k == 1:
+        return (gn.reshape(-1, Cout).t() @ xn.reshape(-1, Cin)).view(Cout, Cin, 1, 1)
+    return torch.ops.aten.convolution_backward(gn.permute(0, 3, 1, 2), xn.permute(0, 3, 1, 2), weight, None, (1, 1), (1, 1), (1, 1), False,
+                                               (0, 0), 1, (False, True, False))[1]
+
+
 def eligible(conv, x):
     """A trainable (or gradient-carrying) 3x3 / stride 1 / padding 1 convolution on an fp32 GPU tensor under autograd."""
     return (enabled() and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
@@ -90,8 +109,7 @@ class _Wino43Conv(torch.autograd.Function):
             if dbg:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            gw = torch.ops.aten.convolution_backward(gy_cl, x.contiguous(memory_format=torch.channels_last), weight, None, (1, 1), (1, 1),
-                                                     (1, 1), False, (0, 0), 1, (False, True, False))[1]
+            gw = _weight_grad(gyn, _nhwc(x), weight, 3)
             if dbg:
                 e1.record()
                 _DEBUG.append((tuple(x.shape), weight.shape[0], e0, e1))
@@ -153,12 +171,7 @@ class _ConvAffineRelu(torch.autograd.Function):
                 gx = ops.conv1x1_nhwc(gz, lambda: ops.pack_conv1x1_nhwc_weights(w_t), Cin,
                                       packed_split=lambda: ops.pack_conv1x1_nhwc_split_weights(w_t)).permute(0, 3, 1, 2)
         if need[1]:
-            if ctx.k == 3:
-                gw = torch.ops.aten.convolution_backward(gz.permute(0, 3, 1, 2), x.contiguous(memory_format=torch.channels_last), weight, None,
-                                                         (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
-            else:
-                xn = _nhwc(x)
-                gw = (gz.reshape(-1, Cout).t() @ xn.reshape(-1, Cin)).view(Cout, Cin, 1, 1)
+            gw = _weight_grad(gz, _nhwc(x), weight, ctx.k)
         return gx, gw, gb, ggamma, gbeta, None, None, None, None
 
 

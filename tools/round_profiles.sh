@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collects the measurements of a round on the GPU box into gpurun_out/<round>/ (copy what is to be judged into profiles/).
-# usage (from the repo root, through gpurun):  bash tools/round_profiles.sh r04 [A|B|C|all]
+# usage (from the repo root, through gpurun):  bash tools/round_profiles.sh r05 [A|B|C|all]
 #   A = bench lines + kernel traces, B = per-stage tables / host feed / training / rehearsal, C = PMC traffic (a gpurun call is limited
 #   to 20 minutes: one part per call)
 set -o pipefail
-R=${1:-r04}
+R=${1:-r05}
 PART=${2:-all}
 O=gpurun_out/$R
 mkdir -p $O
