@@ -328,16 +328,19 @@ __global__ __launch_bounds__(256) void srf_rows_epilogue_k(const float *__restri
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         float s = 0.f;
-        if (c < N)
-            for (int p0 = 0; p0 < nsplit; p0 += 8) {  // eight slab loads in flight, summed in slab order
-                float t[8];
+        const int cc = c < N ? c : 0;   // (unconditional loads at clamped addresses: a load under a branch is waited for on its own)
+        for (int p0 = 0; p0 < nsplit; p0 += 8) {  // eight slab loads in flight, summed in slab order
+            float t[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = p0 + u < nsplit ? partial[((size_t)(p0 + u) * M + row) * N + c] : 0.f;
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (p0 + u < nsplit) s += t[u];
+            for (int u = 0; u < 8; ++u) {
+                const int pp = p0 + u < nsplit ? p0 + u : nsplit - 1;
+                t[u] = partial[((size_t)pp * M + row) * N + cc];
             }
-        v[i] = s;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (p0 + u < nsplit) s += t[u];
+        }
+        v[i] = c < N ? s : 0.f;
     }
     if (NV <= 2) srf_row_epilogue_regs<NV>(v, N, lane, res, ep, pv);
     else srf_row_epilogue<NV>(v, N, lane, row, ep);
@@ -776,28 +779,45 @@ __global__ __launch_bounds__(256) void srf_stage_tail_k(const float *__restrict_
         f32x4 v[4];
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) v[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();  // the bias / LayerNorm vectors in s_par are complete
-        if (live) {
-            for (int sl = 0; sl < ns; ++sl) {
-                const float *src = partial + ((size_t)sl * R + row) * C + q * 4;
+        // the residual row and the slices are loaded UNCONDITIONALLY (rows past R read row R - 1; their results are dropped by `live`
+        // below), four slices = 16 float4 in flight at a time, added in slice order: as `if (live) for (sl) { 4 loads; 4 adds }` every
+        // slice was its own L2 round trip, 16 in a row at F = 2048
+        const int rowc = live ? row : R - 1;
+        f32x4 rsv[4];
 #pragma unroll
-                for (int ch = 0; ch < 4; ++ch) {
-                    const f32x4 t = *reinterpret_cast<const f32x4 *>(src + ch * 32);
-                    v[ch][0] = __fadd_rn(v[ch][0], t[0]);
-                    v[ch][1] = __fadd_rn(v[ch][1], t[1]);
-                    v[ch][2] = __fadd_rn(v[ch][2], t[2]);
-                    v[ch][3] = __fadd_rn(v[ch][3], t[3]);
-                }
-            }
+        for (int ch = 0; ch < 4; ++ch) rsv[ch] = *reinterpret_cast<const f32x4 *>(obj_in + (size_t)rowc * C + ch * 32 + q * 4);
+        const float *src0 = partial + (size_t)rowc * C + q * 4;
+        const size_t slice_stride = (size_t)R * C;
+        int sl = 0;
+        for (; sl + 4 <= ns; sl += 4) {
+            f32x4 t[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) t[u][ch] = *reinterpret_cast<const f32x4 *>(src0 + (size_t)(sl + u) * slice_stride + ch * 32);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[ch][i] = __fadd_rn(v[ch][i], t[u][ch][i]);
         }
+        for (; sl < ns; ++sl) {
+            f32x4 t[4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) t[ch] = *reinterpret_cast<const f32x4 *>(src0 + (size_t)sl * slice_stride + ch * 32);
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[ch][i] = __fadd_rn(v[ch][i], t[ch][i]);
+        }
+        __syncthreads();  // the bias / LayerNorm vectors in s_par are complete
         float sm = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
             const f32x4 bb = *reinterpret_cast<const f32x4 *>(p_b2 + ch * 32 + q * 4);
-            f32x4 rs = {0.f, 0.f, 0.f, 0.f};
-            if (live) rs = *reinterpret_cast<const f32x4 *>(obj_in + (size_t)row * C + ch * 32 + q * 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[ch][i] = (v[ch][i] + bb[i]) + rs[i];
+            for (int i = 0; i < 4; ++i) v[ch][i] = live ? (v[ch][i] + bb[i]) + rsv[ch][i] : bb[i];
             sm += (v[ch][0] + v[ch][1]) + (v[ch][2] + v[ch][3]);
         }
         sm += __shfl_xor(sm, 1, 64);
@@ -1051,11 +1071,31 @@ __global__ __launch_bounds__(256) void srf_dynconv_mid_k(const float *__restrict
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *Fr = F + (size_t)r * S * C;
     const float *W1 = params + (size_t)r * 2 * C * D, *W2 = W1 + C * D;
-    for (int e = tid; e < SP * C; e += 256) {
-        const int i = e / C, c = e % C;
-        s_f[i * (C + 1) + c] = i < S ? Fr[(size_t)i * C + c] : 0.f;
+    // every global load of the workgroup in flight at once, as float4 (rows past S read row S - 1 and are stored as zeros; W2 waits in
+    // registers for the end of product 1): the scalar `i < S ? Fr[..] : 0` copy loops were 32 + 16 + 16 dependent round trips
+    constexpr int NF = SP * C / 4 / 256, NW = C * D / 4 / 256;
+    f32x4 fv[NF], w1v[NW], w2v[NW];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int e4 = tid + j * 256, i = e4 / (C / 4), c4 = e4 % (C / 4);
+        fv[j] = *reinterpret_cast<const f32x4 *>(Fr + (size_t)(i < S ? i : S - 1) * C + c4 * 4);
     }
-    for (int e = tid; e < C * D; e += 256) s_w1[(e / D) * (D + 1) + e % D] = W1[e];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) w1v[j] = *reinterpret_cast<const f32x4 *>(W1 + (size_t)(tid + j * 256) * 4);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) w2v[j] = *reinterpret_cast<const f32x4 *>(W2 + (size_t)(tid + j * 256) * 4);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int e4 = tid + j * 256, i = e4 / (C / 4), c4 = e4 % (C / 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s_f[i * (C + 1) + c4 * 4 + u] = i < S ? fv[j][u] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int e = (tid + j * 256) * 4;   // D % 4 == 0: the four values share a row of W1
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s_w1[(e / D) * (D + 1) + e % D + u] = w1v[j][u];
+    }
     __syncthreads();
     // product 1: (SP x C)(C x D): 4 x (D/16) tiles of 16x16, wave w takes row tile w
     const int l15 = lane & 15, lq = lane >> 4;
@@ -1075,7 +1115,12 @@ __global__ __launch_bounds__(256) void srf_dynconv_mid_k(const float *__restrict
             for (int j = 0; j < 4; ++j) s_x1[(wave * 16 + lq * 4 + j) * (D + 1) + t * 16 + l15] = acc[t][j];
     }
     __syncthreads();  // every wave is done reading F: its region now takes W2
-    for (int e = tid; e < C * D; e += 256) s_w2[(e / C) * (C + 1) + e % C] = W2[e];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int e = (tid + j * 256) * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s_w2[(e / C) * (C + 1) + e % C + u] = w2v[j][u];
+    }
     // LayerNorm(D) + ReLU on each of the S rows: 4 lanes per row
     {
         const int row = tid >> 2, part = tid & 3;

@@ -127,16 +127,40 @@ __global__ __launch_bounds__(128) void srf_roi_extract_k(RoiLevels L, int C, con
         const float *plane = f.data + (long long)c * f.stride_c;
         for (int pw = 0; pw < pooled; ++pw) {
             float acc = 0.0f;
-            for (int s = 0; s < sr * sr; ++s) {
-                const int q = pw * sr * sr + s;
-                float v = 0.0f;
-                if (s_w[q][0] != 0.f || s_w[q][1] != 0.f || s_w[q][2] != 0.f || s_w[q][3] != 0.f) {
-                    v = __fmul_rn(s_w[q][0], plane[s_off[q][0]]);
-                    v = __fadd_rn(v, __fmul_rn(s_w[q][1], plane[s_off[q][1]]));
-                    v = __fadd_rn(v, __fmul_rn(s_w[q][2], plane[s_off[q][2]]));
-                    v = __fadd_rn(v, __fmul_rn(s_w[q][3], plane[s_off[q][3]]));
+            // The taps are loaded UNCONDITIONALLY, four samples (16 taps) at a time: a sample outside its map has offset 0 (a valid
+            // address) and its value is dropped by the select below, exactly the `v = 0` of the branch this replaces.  With the
+            // loads under `if (any weight != 0)` hipcc waited for each sample's four taps before issuing the next sample's
+            // (s_waitcnt vmcnt(0) per sample): 28 round trips in a row per bin row, the whole of this launch-sized kernel.
+            const int q0 = pw * sr * sr, nq = sr * sr;
+            int s = 0;
+            for (; s + 4 <= nq; s += 4) {
+                float p[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) p[u][t] = plane[s_off[q0 + s + u][t]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = q0 + s + u;
+                    float v = __fmul_rn(s_w[q][0], p[u][0]);
+                    v = __fadd_rn(v, __fmul_rn(s_w[q][1], p[u][1]));
+                    v = __fadd_rn(v, __fmul_rn(s_w[q][2], p[u][2]));
+                    v = __fadd_rn(v, __fmul_rn(s_w[q][3], p[u][3]));
+                    const bool nz = s_w[q][0] != 0.f || s_w[q][1] != 0.f || s_w[q][2] != 0.f || s_w[q][3] != 0.f;
+                    acc = __fadd_rn(acc, nz ? v : 0.0f);
                 }
-                acc = __fadd_rn(acc, v);
+            }
+            for (; s < nq; ++s) {
+                const int q = q0 + s;
+                float p[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) p[t] = plane[s_off[q][t]];
+                float v = __fmul_rn(s_w[q][0], p[0]);
+                v = __fadd_rn(v, __fmul_rn(s_w[q][1], p[1]));
+                v = __fadd_rn(v, __fmul_rn(s_w[q][2], p[2]));
+                v = __fadd_rn(v, __fmul_rn(s_w[q][3], p[3]));
+                const bool nz = s_w[q][0] != 0.f || s_w[q][1] != 0.f || s_w[q][2] != 0.f || s_w[q][3] != 0.f;
+                acc = __fadd_rn(acc, nz ? v : 0.0f);
             }
             const float res = __fdiv_rn(acc, count);
             if (in_regs) {

@@ -1884,6 +1884,9 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
 // Every output is the same chain as before (offset ascending, channel ascending, zero terms added as +0): bit-identical to
 // the tile kernel and the oracle.
 // =====================================================================================================================
+#ifndef SRF_W32_DEPTH
+#define SRF_W32_DEPTH 6
+#endif
 template <int CIN>
 __global__ __launch_bounds__(512) void srf_spconv_w32_k(const float *__restrict__ in, int A_in, const float *__restrict__ Wp,
                                                        const int *__restrict__ nbr, int nbr_stride, int A_out,
@@ -1905,32 +1908,42 @@ __global__ __launch_bounds__(512) void srf_spconv_w32_k(const float *__restrict_
     const int row = row0 + wave * 32 + r;
     const f32x4 *Wp4 = reinterpret_cast<const f32x4 *>(Wp);
     for (int i = tid; i < K * NB * 64; i += 512) s_w32[i] = Wp4[i];
+    // all K rulebook entries of the row in flight at once (a load under `row < A_out` is a load under a branch: hipcc then waits for
+    // each one before the next -- 27 round trips in a row): rows past the end read the last row's entries and drop them
     int idx[K];
     unsigned anym = 0;
+    const int row_ld = row < A_out ? row : A_out - 1;
+#pragma unroll
+    for (int k = 0; k < K; ++k) idx[k] = nbr[(size_t)k * nbr_stride + row_ld];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        idx[k] = row < A_out ? nbr[(size_t)k * nbr_stride + row] : -1;
+        idx[k] = row < A_out ? idx[k] : -1;
         anym |= (__ballot(idx[k] >= 0) != 0ull ? 1u : 0u) << k;
     }
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)((long long)A_in * CIN * 4), 0x00020000);
-    f32x4 a[3][NV];
+    // D offsets in flight.  The loads are NOT under the `anym` test: a load inside a scalar branch makes hipcc's wait-count pass
+    // give up counting (it emitted s_waitcnt vmcnt(0) in front of every offset's MFMAs, 109 of them: the "three offsets in flight"
+    // of round 3 were drained at every step and each offset paid a full gather latency, 1.4 us against 0.43 us of MFMAs).  An
+    // offset no row of the wave has is 64 out-of-range lanes: the descriptor returns zeros without touching memory.
+    constexpr int D = SRF_W32_DEPTH;
+    f32x4 a[D][NV];
 #define W32_LOAD(SET, KK)                                                                                    \
-    if (anym & (1u << (KK))) {                                                                               \
+    {                                                                                                        \
         const unsigned vo_ = idx[KK] >= 0 ? (unsigned)(idx[KK] * (CIN * 4) + kh * (H * 4)) : 0x80000000u;    \
         _Pragma("unroll") for (int j_ = 0; j_ < NV; ++j_) {                                                  \
             auto v_ = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(vo_ + j_ * 16), 0, 0);                      \
             a[SET][j_] = *reinterpret_cast<f32x4 *>(&v_);                                                    \
         }                                                                                                    \
     }
-    W32_LOAD(0, 0)
-    W32_LOAD(1, 1)
+#pragma unroll
+    for (int k = 0; k < D - 1; ++k) W32_LOAD(k, k)
     __syncthreads();   // the weights are in LDS
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        if (k + 2 < K) { W32_LOAD((k + 2) % 3, k + 2) }
+        if (k + D - 1 < K) W32_LOAD((k + D - 1) % D, k + D - 1)
         if (anym & (1u << k)) {
             f32x4 b[NB];
 #pragma unroll
@@ -1940,7 +1953,7 @@ __global__ __launch_bounds__(512) void srf_spconv_w32_k(const float *__restrict_
             float e0[NV], e1[NV], o0[NV], o1[NV];
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const f32x4 v = a[k % 3][j];
+                const f32x4 v = a[k % D][j];
                 auto p0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
                 auto p1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2]), __float_as_uint(v[3]), false, false);
                 e0[j] = __uint_as_float(p0[0]);   // channel 4 j + kh
@@ -1964,16 +1977,23 @@ __global__ __launch_bounds__(512) void srf_spconv_w32_k(const float *__restrict_
 #undef W32_LOAD
     const float al = alpha ? alpha[r] : 1.0f;
     const float be = alpha ? beta[r] : 0.0f;
+    // the 16 residual values in flight together (one load per row under its own `orow < A_out` branch was 16 round trips in a row)
+    float res[16];
+    if (residual) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int orow = row0 + wave * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+            res[j] = residual[(size_t)(orow < A_out ? orow : A_out - 1) * 32 + r];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int orow = row0 + wave * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
-        if (orow < A_out) {
-            float v = acc[j];
-            if (alpha) v = __fmaf_rn(v, al, be);
-            if (residual) v = __fadd_rn(v, residual[(size_t)orow * 32 + r]);
-            if (relu) v = v > 0.0f ? v : 0.0f;
-            out[(size_t)orow * 32 + r] = v;
-        }
+        float v = acc[j];
+        if (alpha) v = __fmaf_rn(v, al, be);
+        if (residual) v = __fadd_rn(v, res[j]);
+        if (relu) v = v > 0.0f ? v : 0.0f;
+        if (orow < A_out) out[(size_t)orow * 32 + r] = v;
     }
 }
 
