@@ -555,6 +555,12 @@ size_t srf_nhwc_affine_relu_bwd_workspace_bytes(long long M, int C);
 int srf_nhwc_affine_relu_bwd(const float *gy, long long gy_ld, const float *y, long long y_ld, long long M, int C, const float *scale /*or NULL*/,
                              int relu, float *gz, long long gz_ld, float *sums /*2 C*/, void *workspace, size_t workspace_bytes,
                              srf_stream_t stream);
+/* ... with a second gradient of the same output, gy2 (M x C, row stride gy2_ld; NULL: none): gy + gy2 takes the place of gy (one rounding,
+ * the add autograd makes as a pass of its own when an output has two consumers -- an OSA layer feeds the next layer AND the block's
+ * concat convolution, vovnet.py:208-230). */
+int srf_nhwc_affine_relu_bwd2(const float *gy, long long gy_ld, const float *gy2 /*or NULL*/, long long gy2_ld, const float *y, long long y_ld,
+                              long long M, int C, const float *scale /*or NULL*/, int relu, float *gz, long long gz_ld, float *sums /*2 C*/,
+                              void *workspace, size_t workspace_bytes, srf_stream_t stream);
 /* srf_ese_apply: the end of VoVNet's eSEModule (vovnet.py:165-177) applied to an OSA block's concat output (:225-228) in one launch:
  * gate[n][c] = hsigmoid(fc(mean[n])) (the bits of srf_ese_gate) and y = x * gate (+ residual = the block's identity input), the bits of
  * srf_nhwc_affine with a per-sample scale.  x / residual / y: (N * HW) pixel rows of x_ld / r_ld / y_ld floats; W (C x C), bias (C) the

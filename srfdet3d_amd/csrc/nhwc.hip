@@ -501,7 +501,8 @@ extern "C" int srf_nhwc_pool_sum(const float *x, long long x_ld, int B, int n_ca
 
 __global__ __launch_bounds__(256) void srf_affine_relu_bwd_k(const float *__restrict__ gy, long long gy_ld, const float *__restrict__ y,
                                                            long long y_ld, long long M, int Cq, const float *__restrict__ scale, int relu,
-                                                           float *__restrict__ gz, long long gz_ld, float *__restrict__ partial)
+                                                           float *__restrict__ gz, long long gz_ld, float *__restrict__ partial,
+                                                           const float *__restrict__ gy2, long long gy2_ld)
 {
     __shared__ float s_red[256 * 8];
     const int rpp = 256 / Cq;  // rows per pass (Cq <= 256)
@@ -513,8 +514,13 @@ __global__ __launch_bounds__(256) void srf_affine_relu_bwd_k(const float *__rest
         f32x4n s = {1.f, 1.f, 1.f, 1.f};
         if (scale) s = *reinterpret_cast<const f32x4n *>(scale + cq * 4);
         for (long long row = row0 + r_local; row < row1; row += rpp) {
-            const f32x4n g = *reinterpret_cast<const f32x4n *>(gy + row * gy_ld + cq * 4);
+            f32x4n g = *reinterpret_cast<const f32x4n *>(gy + row * gy_ld + cq * 4);
             const f32x4n v = *reinterpret_cast<const f32x4n *>(y + row * y_ld + cq * 4);
+            if (gy2) {   // a second gradient of the same output (its other consumer): gy + gy2, the add autograd would make as a pass of its own
+                const f32x4n g2 = *reinterpret_cast<const f32x4n *>(gy2 + row * gy2_ld + cq * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = __fadd_rn(g[j], g2[j]);
+            }
             f32x4n o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -572,13 +578,13 @@ extern "C" size_t srf_nhwc_affine_relu_bwd_workspace_bytes(long long M, int C)
     return (size_t)((M + SRF_ARB_ROWS - 1) / SRF_ARB_ROWS) * 2 * C * sizeof(float);
 }
 
-extern "C" int srf_nhwc_affine_relu_bwd(const float *gy, long long gy_ld, const float *y, long long y_ld, long long M, int C,
+extern "C" int srf_nhwc_affine_relu_bwd2(const float *gy, long long gy_ld, const float *gy2, long long gy2_ld, const float *y, long long y_ld, long long M, int C,
                                         const float *scale, int relu, float *gz, long long gz_ld, float *sums, void *workspace,
                                         size_t workspace_bytes, srf_stream_t stream)
 {
-    if (M < 0 || C <= 0 || gy_ld < C || y_ld < C || gz_ld < C) return SRF_EINVAL;
+    if (M < 0 || C <= 0 || gy_ld < C || y_ld < C || gz_ld < C || (gy2 && gy2_ld < C)) return SRF_EINVAL;
     if ((C & 3) || C > 1024 || (gy_ld & 3) || (y_ld & 3) || (gz_ld & 3) || ((uintptr_t)gy & 15) || ((uintptr_t)y & 15) || ((uintptr_t)gz & 15) ||
-        (scale && ((uintptr_t)scale & 15)))
+        (scale && ((uintptr_t)scale & 15)) || (gy2 && ((gy2_ld & 3) || ((uintptr_t)gy2 & 15))))
         return SRF_EUNSUPPORTED;
     if (!sums) return SRF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -591,9 +597,16 @@ extern "C" int srf_nhwc_affine_relu_bwd(const float *gy, long long gy_ld, const 
     const long long nb = (M + SRF_ARB_ROWS - 1) / SRF_ARB_ROWS;
     if (nb > 0x7FFFFFFF) return SRF_EUNSUPPORTED;
     hipLaunchKernelGGL(srf_affine_relu_bwd_k, dim3((unsigned)nb), dim3(256), 0, st, gy, gy_ld, y, y_ld, M, C / 4, scale, relu, gz, gz_ld,
-                       (float *)workspace);
+                       (float *)workspace, gy2, gy2_ld);
     hipLaunchKernelGGL(srf_affine_relu_bwd_finish_k, dim3(srf_ceil_div(2 * C, 16)), dim3(256), 0, st, (const float *)workspace, (int)nb, 2 * C,
                        sums);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
+}
+
+extern "C" int srf_nhwc_affine_relu_bwd(const float *gy, long long gy_ld, const float *y, long long y_ld, long long M, int C,
+                                        const float *scale, int relu, float *gz, long long gz_ld, float *sums, void *workspace,
+                                        size_t workspace_bytes, srf_stream_t stream)
+{
+    return srf_nhwc_affine_relu_bwd2(gy, gy_ld, nullptr, 0, y, y_ld, M, C, scale, relu, gz, gz_ld, sums, workspace, workspace_bytes, stream);
 }

@@ -1074,10 +1074,16 @@ __global__ __launch_bounds__(256) void srf_gs_rowpairs_k(const int *__restrict__
     for (int j = 0; j < SRF_TB_ROWS / 256; ++j) {  // block-uniform trip count: the barriers inside the scan are safe
         const int r = r0 + j * 256 + threadIdx.x;
         int c = 0;
-        if (r < A)
         {
-            for (int k = 0; k < K; ++k) c += nbr[(size_t)k * nbr_stride + r] >= 0 ? 1 : 0;
-            c += row_cost;
+            // all K entries of the row in flight at once (as a loop of `c += nbr[..] >= 0` every entry was its own round trip: 27 in a
+            // row, the whole of this 9-10 us launch); rows past the end read row A - 1 and count nothing
+            const int rc = r < A ? r : A - 1;
+            int v[SRF_KMAX];
+#pragma unroll
+            for (int k = 0; k < SRF_KMAX; ++k) v[k] = nbr[(size_t)(k < K ? k : K - 1) * nbr_stride + rc];
+#pragma unroll
+            for (int k = 0; k < SRF_KMAX; ++k) c += (k < K && v[k] >= 0) ? 1 : 0;
+            c = r < A ? c + row_cost : 0;
         }
         int total;
         const int ex = srf_block_scan_excl(c, s_scan, total);

@@ -43,6 +43,7 @@ struct WgArgs {
     int N, H, W, Cin, Cout, kw, pad, taps;
     int mtiles, ctiles, nsplit, chunks_per_split, nchunks;
     int g_bytes, x_bytes;
+    int flat;   // column tiles cut the flattened (tap, input channel) axis in 128s (Cin % 32 == 0) instead of every tap's channels apart
 };
 
 __device__ __forceinline__ unsigned wg_pk_bf16(float a, float b)
@@ -73,11 +74,33 @@ __global__ __launch_bounds__(256, 2) void srf_wgrad_split_k(WgArgs a)
     int b = blockIdx.x;
     const int mt = b % a.mtiles;
     b /= a.mtiles;
-    const int ntiles = a.taps * a.ctiles;
+    // column tiles: `flat` (Cin % 32 == 0): 128 consecutive columns of the (tap, input channel) axis -- a tile may straddle taps, every
+    // 32-channel group of it lies in one (192 -> 192, VoVNet stage 4: 14 column tiles instead of 9 x 2 half-empty ones); else the tiles
+    // of every tap apart
+    const int ntiles = a.flat ? a.ctiles : a.taps * a.ctiles;
     const int nt = b % ntiles, sp = b / ntiles;
-    const int tap = nt / a.ctiles, ct = nt - tap * a.ctiles;
-    const int ky = tap / a.kw, kx = tap - ky * a.kw;
-    const int co0 = mt * 128, ci0 = ct * 128;
+    const int co0 = mt * 128;
+    int tapj[4], cij0[4], kyj[4], kxj[4];   // per 32-channel group j of the tile: its tap and its first input channel (uniform: SGPRs)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int tp_, c0_;
+        if (a.flat) {
+            const int f0 = nt * 128 + 32 * j;
+            tp_ = f0 / a.Cin;
+            c0_ = f0 - tp_ * a.Cin;
+            if (tp_ >= a.taps) {   // past the last column: nothing to load (channel a.Cin does not exist)
+                tp_ = a.taps - 1;
+                c0_ = a.Cin;
+            }
+        } else {
+            tp_ = nt / a.ctiles;
+            c0_ = (nt - tp_ * a.ctiles) * 128 + 32 * j;
+        }
+        tapj[j] = tp_;
+        cij0[j] = c0_;
+        kyj[j] = tp_ / a.kw;
+        kxj[j] = tp_ - kyj[j] * a.kw;
+    }
     const int c_begin = sp * a.chunks_per_split;
     int c_end = c_begin + a.chunks_per_split;
     c_end = c_end < a.nchunks ? c_end : a.nchunks;
@@ -101,17 +124,17 @@ __global__ __launch_bounds__(256, 2) void srf_wgrad_split_k(WgArgs a)
     for (int j = 0; j < 4; ++j) {
         const int c = 4 * qg + 32 * j;
         gcol[j] = co0 + c < a.Cout ? (unsigned)((co0 + c) * 4) : 0x80000000u;
-        xcol[j] = ci0 + c < a.Cin ? (unsigned)((ci0 + c) * 4) : 0x80000000u;
+        xcol[j] = cij0[j] + 4 * qg < a.Cin ? (unsigned)((cij0[j] + 4 * qg) * 4) : 0x80000000u;
     }
     wg_f4 graw[4], xraw[4];
 #define WG_LOAD()                                                                                                          \
     do {                                                                                                                   \
         const bool pok_ = p < a.P;                                                                                         \
         const unsigned grow_ = pok_ ? (unsigned)(p * a.g_ld * 4) : 0x80000000u;                                            \
-        const int iy_ = oy + ky - a.pad, ix_ = ox + kx - a.pad;                                                            \
-        const bool xok_ = pok_ && iy_ >= 0 && iy_ < a.H && ix_ >= 0 && ix_ < a.W;                                          \
-        const unsigned xrow_ = xok_ ? (unsigned)((((long long)n * a.H + iy_) * a.W + ix_) * a.x_ld * 4) : 0x80000000u;     \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                 \
+            const int iy_ = oy + kyj[j_] - a.pad, ix_ = ox + kxj[j_] - a.pad;                                              \
+            const bool xok_ = pok_ && iy_ >= 0 && iy_ < a.H && ix_ >= 0 && ix_ < a.W;                                      \
+            const unsigned xrow_ = xok_ ? (unsigned)((((long long)n * a.H + iy_) * a.W + ix_) * a.x_ld * 4) : 0x80000000u; \
             const unsigned go_ = ((grow_ | gcol[j_]) & 0x80000000u) ? 0x80000000u : grow_ + gcol[j_];                      \
             const unsigned xo_ = ((xrow_ | xcol[j_]) & 0x80000000u) ? 0x80000000u : xrow_ + xcol[j_];                      \
             auto vg_ = __builtin_amdgcn_raw_buffer_load_b128(gr, (int)go_, 0, 0);                                          \
@@ -246,12 +269,14 @@ __global__ __launch_bounds__(256, 2) void srf_wgrad_split_k(WgArgs a)
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int ci = ci0 + wn * 64 + j * 32 + li;
+            const int jj = wn * 2 + j;                     // the 32-channel group of the tile this accumulator tile holds
+            const int ci = cij0[jj] + li;
             if (ci >= a.Cin) continue;
+            const size_t col = (size_t)tapj[jj] * a.Cin + ci;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (co < a.Cout) dst[(size_t)co * NC + (size_t)tap * a.Cin + ci] = acc[i][j][r];
+                if (co < a.Cout) dst[(size_t)co * NC + col] = acc[i][j][r];
             }
         }
 }
@@ -271,14 +296,16 @@ __global__ __launch_bounds__(256) void srf_wgrad_reduce_k(const float *__restric
     dW[((size_t)co * Cin + ci) * taps + tap] = s;
 }
 
+static bool wg_flat(int Cin, int taps) { return taps > 1 && (Cin & 31) == 0 && (Cin & 127) != 0; }
+
 static int wg_plan(long long P, int Cin, int Cout, int taps, int *mtiles, int *ctiles, int *nsplit, int *cps, int *nchunks)
 {
     *mtiles = srf_ceil_div(Cout, 128);
-    *ctiles = srf_ceil_div(Cin, 128);
+    *ctiles = wg_flat(Cin, taps) ? srf_ceil_div(taps * Cin, 128) : srf_ceil_div(Cin, 128);
     const long long nch = (P + 31) / 32;
     if (nch >= (1ll << 30)) return SRF_EUNSUPPORTED;
     *nchunks = (int)nch;
-    const int tiles = *mtiles * *ctiles * taps;
+    const int tiles = *mtiles * (wg_flat(Cin, taps) ? *ctiles : *ctiles * taps);
     int ns = srf_ceil_div(768, tiles);          // ~1.5 rounds of 512 co-resident workgroups
     const int most = (int)((nch + 15) / 16);    // a range is at least 16 chunks deep
     ns = ns > most ? most : ns;
@@ -328,7 +355,8 @@ extern "C" int srf_conv_wgrad_nhwc(const float *g, long long g_ld, const float *
     if (workspace_bytes < (size_t)a.nsplit * Cout * (size_t)a.taps * Cin * sizeof(float)) return SRF_EINVAL;
     a.g_bytes = (int)(P * g_ld * 4);
     a.x_bytes = (int)(P * x_ld * 4);
-    const long long blocks = (long long)a.nsplit * a.taps * a.ctiles * a.mtiles;
+    a.flat = wg_flat(Cin, a.taps) ? 1 : 0;
+    const long long blocks = (long long)a.nsplit * (a.flat ? a.ctiles : a.taps * a.ctiles) * a.mtiles;
     if (blocks >= (1ll << 31)) return SRF_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(srf_wgrad_split_k, dim3((unsigned)blocks), dim3(256), 0, st, a);

@@ -1379,11 +1379,14 @@ def nhwc_dwconv3x3s2_cat(x, weight, scale, shift, relu, side, out):
     return out
 
 
-def nhwc_affine_relu_bwd(gy, y, scale, relu):
+def nhwc_affine_relu_bwd(gy, y, scale, relu, gy2=None):
     """Backward of y = relu(z * scale + shift) on NHWC tensors (N, H, W, C): -> gz (N, H, W, C) = masked gy * scale, and the column
-    sums (2, C) [sum gu, sum gu * y] (gu = gy where y > 0); one streaming pass + a finish launch (srf_nhwc_affine_relu_bwd)."""
+    sums (2, C) [sum gu, sum gu * y] (gu = gy where y > 0); one streaming pass + a finish launch (srf_nhwc_affine_relu_bwd).
+    gy2: a second gradient of the same output, added to gy on the way in."""
     N, H, W, C = gy.shape
     gy_ld, y_ld = nhwc_ld(gy), nhwc_ld(y)
+    if gy2 is not None and tuple(gy2.shape) != tuple(gy.shape):
+        raise ValueError("nhwc_affine_relu_bwd: gy2 has another shape")
     M = N * H * W
     L = _lib.lib()
     gz = _empty((N, H, W, C), torch.float32, gy.device)
@@ -1391,8 +1394,8 @@ def nhwc_affine_relu_bwd(gy, y, scale, relu):
     nbytes = L.srf_nhwc_affine_relu_bwd_workspace_bytes(M, C)
     ws = _empty((max(nbytes, 4) // 4,), torch.float32, gy.device)
     sc = None if scale is None else _aligned16(_dev(scale, "scale", torch.float32))
-    check(L.srf_nhwc_affine_relu_bwd(_ptr(gy), gy_ld, _ptr(y), y_ld, M, C, _ptr(sc), int(bool(relu)), _ptr(gz), C, _ptr(sums), _ptr(ws),
-                                     nbytes, _stream()), "nhwc_affine_relu_bwd")
+    check(L.srf_nhwc_affine_relu_bwd2(_ptr(gy), gy_ld, _ptr(gy2), 0 if gy2 is None else nhwc_ld(gy2), _ptr(y), y_ld, M, C, _ptr(sc),
+                                      int(bool(relu)), _ptr(gz), C, _ptr(sums), _ptr(ws), nbytes, _stream()), "nhwc_affine_relu_bwd")
     return gz, sums
 
 

@@ -82,6 +82,10 @@ class OSAModule(nn.Module):
         self.ese = eSEModule(cout)
 
     def forward(self, x):
+        from .. import train_conv
+        if train_conv.enabled() and train_conv.osa_eligible(self, x):
+            # training behind the frozen prefix: layers + concat convolution as one autograd node over one channels-last buffer
+            return self.ese(train_conv.osa_chain(self, x), x if self.identity else None)
         feats = [x]
         y = run_sequential(self.reduce, x) if self.reduce is not None else x
         for layer in self.layers:

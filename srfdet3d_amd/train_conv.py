@@ -49,9 +49,11 @@ def _weight_grad(gn, xn, weight, k):
     added in a fixed order -- deterministic) where it applies; else (SRF_TRAIN_WGRAD=0, maps narrower than 32 pixels, tensors of 2 GB)
     the library route of rounds 3-4: aten.convolution_backward = MIOpen's float-atomic split-K kernels for 3x3, one rocBLAS GEMM for 1x1."""
     Co, Ci = weight.shape[0], weight.shape[1]
-    fill = (Co * Ci) / float(((Co + 127) // 128) * ((Ci + 127) // 128) * 128 * 128)   # share of the kernel's 128 x 128 tiles that is real
-    # (192 -> 192, VoVNet stage 4: 56 % of the tiles -- measured 543 us against MIOpen's 465; every other trainable shape of config 4 is
-    # 1.1-3x faster on the kernel: profiles/r05_wgrad_bench.txt)
+    cols = k * k * Ci if (k > 1 and Ci % 32 == 0) else None            # 3x3 layers: the column tiles run over the flattened (tap, channel) axis
+    fill = ((Co * cols) / float(((Co + 127) // 128) * ((cols + 127) // 128) * 128 * 128) if cols is not None
+            else (Co * Ci) / float(((Co + 127) // 128) * ((Ci + 127) // 128) * 128 * 128))   # share of the kernel's 128 x 128 tiles that is real
+    # (192 -> 192, VoVNet stage 4, with every tap's channels in tiles of their own: 56 % -- 543 us against MIOpen's 465; flattened: 72 %;
+    # every other trainable shape of config 4 is 1.1-3x faster on the kernel: profiles/r05_wgrad_bench.txt)
     want = os.environ.get("SRF_TRAIN_WGRAD", "1")
     if want != "0" and (fill >= 0.6 or k == 1 or want == "2") and ops.conv_wgrad_supported(gn, xn, k):
         return ops.conv_wgrad_nhwc(gn, xn, k)
@@ -226,6 +228,157 @@ def conv_bn_act(conv, bn, relu, x):
     if fused_eligible(conv, bn, x) and (not bn.weight.requires_grad or gamma_well_conditioned(bn)):
         return _ConvAffineRelu.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bool(relu))
     return None
+
+
+class _OSAChain(torch.autograd.Function):
+    """The body of a VoVNet OSA block (vovnet.py:208-230) -- L x [conv 3x3 -> eval BatchNorm -> ReLU] in a chain, then the 1x1 `concat`
+    convolution over [x, y_0 .. y_{L-1}] -> eval BatchNorm -> ReLU -- as ONE autograd node over ONE channels-last buffer
+    cat = [x | y_0 | .. | y_{L-1}]:
+
+    * forward: every layer reads its input slice of `cat` and writes its output slice (the kernels take a pixel pitch), the concat
+      convolution reads `cat` in place: no torch.cat, and `cat` is all that is saved (it holds every layer's input AND output);
+    * backward: the concat convolution's data gradient g_cat has the same layout; layer i's output gradient is g_cat's slice PLUS the
+      data gradient of layer i + 1 -- added inside the ReLU / BatchNorm backward pass (`srf_nhwc_affine_relu_bwd2`), read from the slice
+      in place.  As separate `_ConvAffineRelu` nodes autograd made that sum with a strided add per layer (213 launches, 7.3 ms per
+      step) after a contiguous copy of the slice (4.3 ms) and torch.cat had copied every output once more forward (2.9 ms):
+      profiles/r05_train_step_kernels.md.
+    Same arithmetic per layer as `_ConvAffineRelu` (same kernels, same d gamma / d beta formulas); the one difference is where the two
+    gradients of an output are added (one f32 add either way)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, *params):
+        L = len(params) // 5 - 1
+        xn = _nhwc(x)
+        N, H, W, Cin = xn.shape
+        ws = [params[5 * i] for i in range(L + 1)]
+        widths = [int(w.shape[0]) for w in ws[:L]]
+        Ctot = Cin + sum(widths)
+        cat = torch.empty((N, H, W, Ctot), dtype=torch.float32, device=x.device)
+        cat[..., :Cin].copy_(xn)
+        aff = []
+        lo, hi = 0, Cin            # the input slice of the next layer
+        for i in range(L):
+            w, gamma, beta, mean, var = params[5 * i:5 * i + 5]
+            inv = torch.rsqrt(var + eps[i])
+            sc = gamma.detach() * inv
+            t0 = beta.detach() - mean * sc
+            ops.wino43(cat[..., lo:hi], ops.pack_wino43_weights(w.detach()), widths[i], sc, t0, True, out=cat[..., hi:hi + widths[i]])
+            aff += [sc, t0, inv]
+            lo, hi = hi, hi + widths[i]
+            if i == 0:
+                lo = Cin
+        wc, gamma, beta, mean, var = params[5 * L:5 * L + 5]
+        Cout = int(wc.shape[0])
+        inv = torch.rsqrt(var + eps[L])
+        sc = gamma.detach() * inv
+        t0 = beta.detach() - mean * sc
+        w2 = wc.detach().reshape(Cout, Ctot)
+        yc = ops.conv1x1_nhwc(cat, lambda: ops.pack_conv1x1_nhwc_weights(w2), Cout, sc, t0, True,
+                              packed_split=lambda: ops.pack_conv1x1_nhwc_split_weights(w2))
+        aff += [sc, t0, inv]
+        ctx.save_for_backward(cat, yc, *ws, *[params[5 * i + 3] for i in range(L + 1)], *aff)
+        ctx.L, ctx.Cin, ctx.widths = L, Cin, widths
+        return yc.permute(0, 3, 1, 2)          # logical NCHW, channels-last strides
+
+    @staticmethod
+    def backward(ctx, gy):
+        L, Cin, widths = ctx.L, ctx.Cin, ctx.widths
+        sv = ctx.saved_tensors
+        cat, yc = sv[0], sv[1]
+        ws, means, aff = sv[2:3 + L], sv[3 + L:4 + 2 * L], sv[4 + 2 * L:]
+        need = ctx.needs_input_grad            # x, eps, then 5 per layer: weight, gamma, beta, mean, var
+        grads = [None] * (2 + 5 * (L + 1))
+
+        def affine_grads(i, sums):
+            sc, t0, inv = aff[3 * i:3 * i + 3]
+            if need[2 + 5 * i + 2]:
+                grads[2 + 5 * i + 2] = sums[0]
+            if need[2 + 5 * i + 1]:
+                grads[2 + 5 * i + 1] = (torch.where(sc != 0, (sums[1] - t0 * sums[0]) / sc, torch.zeros_like(sc)) - means[i] * sums[0]) * inv
+
+        # the concat convolution
+        Ctot = cat.shape[3]
+        wc = ws[L].detach()
+        Cout = wc.shape[0]
+        gz, sums = ops.nhwc_affine_relu_bwd(_nhwc(gy), yc, aff[3 * L], True)
+        affine_grads(L, sums)
+        w_t = wc.reshape(Cout, Ctot).t().contiguous()
+        g_cat = ops.conv1x1_nhwc(gz, lambda: ops.pack_conv1x1_nhwc_weights(w_t), Ctot,
+                                 packed_split=lambda: ops.pack_conv1x1_nhwc_split_weights(w_t))
+        if need[2 + 5 * L]:
+            grads[2 + 5 * L] = _weight_grad(gz, cat, ws[L], 1)
+        del gz
+        # the chain, last layer first
+        carry = None
+        out_hi = Ctot
+        for i in range(L - 1, -1, -1):
+            out_lo = out_hi - widths[i]
+            in_lo, in_hi = (0, Cin) if i == 0 else (out_lo - widths[i - 1], out_lo)
+            gz, sums = ops.nhwc_affine_relu_bwd(g_cat[..., out_lo:out_hi], cat[..., out_lo:out_hi], aff[3 * i], True, gy2=carry)
+            affine_grads(i, sums)
+            w = ws[i].detach()
+            if need[2 + 5 * i]:
+                grads[2 + 5 * i] = _weight_grad(gz, cat[..., in_lo:in_hi], ws[i], 3)
+            carry = None
+            if i > 0 or need[0]:
+                w_r = w.flip(2, 3).transpose(0, 1).contiguous()           # (Cin, Cout, 3, 3), rotated by 180 degrees
+                carry = ops.wino43(gz, ops.pack_wino43_weights(w_r), in_hi - in_lo)
+            out_hi = out_lo
+        if need[0]:
+            grads[0] = carry.add_(g_cat[..., :Cin]).permute(0, 3, 1, 2)
+        return tuple(grads)
+
+
+def osa_eligible(block, x):
+    """An OSA block whose body can run as `_OSAChain`: plain 3x3 layers (no reduction / depthwise form), every layer and the concat
+    convolution fit `_ConvAffineRelu`'s conditions (bias-free convolutions, eval-mode BatchNorms with well-conditioned gammas), and
+    the input is channels-last under autograd.  SRF_TRAIN_OSA=0 keeps the per-layer nodes."""
+    if os.environ.get("SRF_TRAIN_OSA", "1") == "0" or os.environ.get("SRF_TRAIN_FUSED", "1") == "0" or block.reduce is not None:
+        return False
+    if not (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.stride(1) == 1 and len(block.layers) >= 1):
+        return False
+    if torch.is_autocast_enabled():
+        return False
+    N, _, H, W = x.shape
+    seqs = list(block.layers) + [block.concat]
+    cin = x.shape[1]
+    ctot = cin
+    for j, seq in enumerate(seqs):
+        mods = list(seq.children())
+        if len(mods) != 3 or type(mods[0]) is not nn.Conv2d or not isinstance(mods[2], nn.ReLU) or mods[0].bias is not None:
+            return False
+        conv, bn = mods[0], mods[1]
+        if not (isinstance(bn, nn.BatchNorm2d) and not bn.training and bn.track_running_stats and bn.affine):
+            return False
+        if conv.dilation != (1, 1) or conv.groups != 1 or conv.stride != (1, 1) or conv.padding_mode != "zeros":
+            return False
+        last = j == len(seqs) - 1
+        if not last:
+            if not (conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.in_channels == cin and cin % 8 == 0 and cin >= 32
+                    and conv.out_channels % 8 == 0 and conv.out_channels <= 1024):
+                return False
+            cin = conv.out_channels
+            ctot += cin
+        elif not (conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.in_channels == ctot and ctot % 32 == 0
+                  and conv.out_channels % 32 == 0 and conv.out_channels <= 1024 and H * W > 1):
+            return False
+        if bn.weight.requires_grad and not gamma_well_conditioned(bn):
+            return False
+    if not (x.requires_grad or any(p.requires_grad for seq in seqs for p in seq.parameters())):
+        return False
+    if N * H * W * ctot * 4 >= (1 << 31) or N * H * W * max(ctot, seqs[-1][0].out_channels) * 512 >= (1 << 31) * 128:
+        return False
+    return N * ((H + 3) // 4) * ((W + 3) // 4) < (1 << 31) - 64   # (the Winograd kernel's tile count)
+
+
+def osa_chain(block, x):
+    seqs = list(block.layers) + [block.concat]
+    params, eps = [], []
+    for seq in seqs:
+        conv, bn = seq[0], seq[1]
+        params += [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        eps.append(float(bn.eps))
+    return _OSAChain.apply(x, tuple(eps), *params)
 
 
 class _DepthwiseNative(torch.autograd.Function):

@@ -29,7 +29,9 @@ def _ref(g, x, k):
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k", [(2, 9, 40, 64, 96, 3), (1, 13, 33, 160, 224, 3), (3, 7, 50, 192, 192, 1), (1, 29, 50, 224, 224, 3),
-                                             (2, 5, 37, 36, 20, 3), (1, 40, 64, 256, 256, 3), (2, 11, 32, 128, 128, 1)])
+                                             (2, 5, 37, 36, 20, 3), (1, 40, 64, 256, 256, 3), (2, 11, 32, 128, 128, 1),
+                                             # column tiles over the flattened (tap, channel) axis (Cin % 32 == 0, not a multiple of 128)
+                                             (2, 12, 45, 192, 192, 3), (1, 9, 36, 96, 136, 3), (1, 8, 33, 32, 64, 3), (2, 7, 40, 160, 64, 3)])
 def test_wgrad_matches_float64_autograd(dev, N, H, W, Cin, Cout, k):
     g_ = torch.Generator().manual_seed(N * 1000 + Cin + Cout + k)
     x = torch.relu(torch.randn(N, H, W, Cin, generator=g_) + 0.2)

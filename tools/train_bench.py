@@ -172,6 +172,23 @@ def main():
             fh.write(f"GPU kernel time per iteration: {tot / 2e3:.1f} ms\n\n| kernel | calls / iteration | ms / iteration | % |\n|---|---|---|---|\n")
             for name, (n, us) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:60]:
                 fh.write(f"| `{name[:150]}` | {n / 2:.1f} | {us / 2e3:.3f} | {100 * us / tot:.1f} |\n")
+    if rank == 0 and os.environ.get("SRF_TRAIN_OP_TABLE"):
+        # developer: device time per (aten op, input shapes) of one iteration -- where the element-wise launches come from
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            step()
+            torch.cuda.synchronize()
+        rows = []
+        for ev in prof.key_averages(group_by_input_shape=True):
+            t = getattr(ev, "self_device_time_total", None)
+            if t is None:
+                t = ev.self_cuda_time_total
+            if t > 0:
+                rows.append((t / 1e3, ev.count, ev.key, str(ev.input_shapes)[:150]))
+        rows.sort(reverse=True)
+        with open(os.environ["SRF_TRAIN_OP_TABLE"], "w") as fh:
+            for t, n, key, shp in rows[:120]:
+                fh.write(f"{t:8.3f} ms {n:5d} {key:40s} {shp}\n")
     if rank == 0 and os.environ.get("SRF_TRAIN_CONV_DEBUG"):
         from srfdet3d_amd import train_conv
         for k, n, ms in train_conv.debug_report()[:12]:
