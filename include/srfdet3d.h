@@ -561,6 +561,13 @@ int srf_nhwc_affine_relu_bwd(const float *gy, long long gy_ld, const float *y, l
 int srf_nhwc_affine_relu_bwd2(const float *gy, long long gy_ld, const float *gy2 /*or NULL*/, long long gy2_ld, const float *y, long long y_ld,
                               long long M, int C, const float *scale /*or NULL*/, int relu, float *gz, long long gz_ld, float *sums /*2 C*/,
                               void *workspace, size_t workspace_bytes, srf_stream_t stream);
+/* The per-channel arithmetic around an eval-mode BatchNorm2d under training (norm_eval=True, vovnet.py:371; tools/train.py:220-234), C values:
+ * srf_bn_eval_fold: out[0..C) = s = gamma / sqrt(var + eps), out[C..2C) = t0 = beta - mean s, out[2C..3C) = inv = 1 / sqrt(var + eps);
+ * srf_bn_eval_grads: from sums = srf_nhwc_affine_relu_bwd's [sum gu, sum gu y] and fold = srf_bn_eval_fold's output:
+ *   out[0..C) = d gamma = ((s != 0 ? (sum gu y - t0 sum gu) / s : 0) - mean sum gu) inv,  out[C..2C) = d beta = sum gu. */
+int srf_bn_eval_fold(const float *gamma, const float *beta, const float *mean, const float *var, float eps, int C, float *out /*3 C*/,
+                     srf_stream_t stream);
+int srf_bn_eval_grads(const float *sums /*2 C*/, const float *fold /*3 C*/, const float *mean, int C, float *out /*2 C*/, srf_stream_t stream);
 /* srf_ese_apply: the end of VoVNet's eSEModule (vovnet.py:165-177) applied to an OSA block's concat output (:225-228) in one launch:
  * gate[n][c] = hsigmoid(fc(mean[n])) (the bits of srf_ese_gate) and y = x * gate (+ residual = the block's identity input), the bits of
  * srf_nhwc_affine with a per-sample scale.  x / residual / y: (N * HW) pixel rows of x_ld / r_ld / y_ld floats; W (C x C), bias (C) the

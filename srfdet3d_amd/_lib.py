@@ -141,6 +141,8 @@ SIGNATURES = {
                                          c_int, _P, _P]),
     "srf_nhwc_affine_relu_bwd_workspace_bytes": (c_size_t, [c_longlong, c_int]),
     "srf_nhwc_affine_relu_bwd": (c_int, [_P, c_longlong, _P, c_longlong, c_longlong, c_int, _P, c_int, _P, c_longlong, _P, _P, c_size_t, _P]),
+    "srf_bn_eval_fold": (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P]),
+    "srf_bn_eval_grads": (c_int, [_P, _P, _P, c_int, _P, _P]),
     "srf_nhwc_affine_relu_bwd2": (c_int, [_P, c_longlong, _P, c_longlong, _P, c_longlong, c_longlong, c_int, _P, c_int, _P, c_longlong, _P, _P,
                                           c_size_t, _P]),
     "srf_ese_apply": (c_int, [_P, c_longlong, c_int, c_longlong, c_int, _P, _P, _P, _P, c_longlong, _P, c_longlong, _P, _P]),

@@ -572,6 +572,52 @@ __global__ __launch_bounds__(256) void srf_affine_relu_bwd_finish_k(const float 
     }
 }
 
+// The per-channel arithmetic around an eval-mode BatchNorm under training (norm_eval=True, vovnet.py:371), one launch each instead of
+// five and seven element-wise torch launches per layer and step (76 layers: ~900 launches of ~4 us):
+//   srf_bn_eval_fold_k:   inv = rsqrt(var + eps), s = gamma inv, t0 = beta - mean s          (the folded affine map y = z s + t0)
+//   srf_bn_eval_grads_k:  d beta = sum gu,  d gamma = ((s != 0 ? (sum gu y - t0 sum gu) / s : 0) - mean sum gu) inv
+// -- the operations of train_conv._ConvAffineRelu's torch expressions in their order, one f32 rounding each.
+__global__ __launch_bounds__(256) void srf_bn_eval_fold_k(const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        const float *__restrict__ mean, const float *__restrict__ var, float eps, int C,
+                                                        float *__restrict__ out /* [3][C]: s, t0, inv */)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float inv = rsqrtf(__fadd_rn(var[c], eps));
+    const float sc = __fmul_rn(gamma[c], inv);
+    out[c] = sc;
+    out[C + c] = __fsub_rn(beta[c], __fmul_rn(mean[c], sc));
+    out[2 * C + c] = inv;
+}
+
+__global__ __launch_bounds__(256) void srf_bn_eval_grads_k(const float *__restrict__ sums /* [2][C] */, const float *__restrict__ fold /* [3][C] */,
+                                                         const float *__restrict__ mean, int C, float *__restrict__ out /* [2][C]: d gamma, d beta */)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float s0 = sums[c], s1 = sums[C + c], sc = fold[c], t0 = fold[C + c], inv = fold[2 * C + c];
+    const float z = sc != 0.f ? __fdiv_rn(__fsub_rn(s1, __fmul_rn(t0, s0)), sc) : 0.f;
+    out[c] = __fmul_rn(__fsub_rn(z, __fmul_rn(mean[c], s0)), inv);
+    out[C + c] = s0;
+}
+
+extern "C" int srf_bn_eval_fold(const float *gamma, const float *beta, const float *mean, const float *var, float eps, int C, float *out,
+                                srf_stream_t stream)
+{
+    if (C <= 0 || !gamma || !beta || !mean || !var || !out) return SRF_EINVAL;
+    hipLaunchKernelGGL(srf_bn_eval_fold_k, dim3(srf_ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps, C, out);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+extern "C" int srf_bn_eval_grads(const float *sums, const float *fold, const float *mean, int C, float *out, srf_stream_t stream)
+{
+    if (C <= 0 || !sums || !fold || !mean || !out) return SRF_EINVAL;
+    hipLaunchKernelGGL(srf_bn_eval_grads_k, dim3(srf_ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, fold, mean, C, out);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
 extern "C" size_t srf_nhwc_affine_relu_bwd_workspace_bytes(long long M, int C)
 {
     if (M <= 0 || C <= 0) return 0;

@@ -1399,6 +1399,24 @@ def nhwc_affine_relu_bwd(gy, y, scale, relu, gy2=None):
     return gz, sums
 
 
+def bn_eval_fold(gamma, beta, mean, var, eps):
+    """(3, C): s = gamma / sqrt(var + eps), t0 = beta - mean s, inv = 1 / sqrt(var + eps) of an eval-mode BatchNorm (one launch)."""
+    C = gamma.numel()
+    out = _empty((3, C), torch.float32, gamma.device)
+    check(_lib.lib().srf_bn_eval_fold(_ptr(_dev(gamma, "gamma", torch.float32)), _ptr(_dev(beta, "beta", torch.float32)),
+                                      _ptr(_dev(mean, "mean", torch.float32)), _ptr(_dev(var, "var", torch.float32)), float(eps), C, _ptr(out),
+                                      _stream()), "bn_eval_fold")
+    return out
+
+
+def bn_eval_grads(sums, fold, mean):
+    """(2, C): d gamma, d beta of an eval-mode BatchNorm from nhwc_affine_relu_bwd's column sums and bn_eval_fold's vectors (one launch)."""
+    C = mean.numel()
+    out = _empty((2, C), torch.float32, sums.device)
+    check(_lib.lib().srf_bn_eval_grads(_ptr(sums), _ptr(fold), _ptr(_dev(mean, "mean", torch.float32)), C, _ptr(out), _stream()), "bn_eval_grads")
+    return out
+
+
 def nhwc_pool_sum(x, n_cam=1, size=None, pad_to=4):
     """x (B * n_cam, H, W, C) channels-last -> (B, pad(Ho * Wo)): per output pixel the sum over cameras and channels at its `nearest`
     source pixel (size = (Ho, Wo); None: the map itself); columns past Ho * Wo are zeros (row length rounded up to pad_to)."""

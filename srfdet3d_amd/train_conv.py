@@ -134,9 +134,8 @@ class _ConvAffineRelu(torch.autograd.Function):
     def forward(ctx, x, weight, bias, gamma, beta, mean, var, eps, relu):
         xn = _nhwc(x)
         Cout, Cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
-        inv = torch.rsqrt(var + eps)
-        s = gamma.detach() * inv
-        t0 = beta.detach() - mean * s
+        fold = ops.bn_eval_fold(gamma.detach(), beta.detach(), mean, var, eps)     # s, t0, inv in one launch
+        s, t0 = fold[0], fold[1]
         t = t0 if bias is None else t0 + bias.detach() * s
         w = weight.detach()
         if k == 3:
@@ -145,22 +144,23 @@ class _ConvAffineRelu(torch.autograd.Function):
             w2 = w.reshape(Cout, Cin)
             yn = ops.conv1x1_nhwc(xn, lambda: ops.pack_conv1x1_nhwc_weights(w2), Cout, s, t, relu,
                                   packed_split=lambda: ops.pack_conv1x1_nhwc_split_weights(w2))
-        ctx.save_for_backward(x, weight, yn, s, t0, inv, mean)
+        ctx.save_for_backward(x, weight, yn, fold, mean)
         ctx.relu, ctx.has_bias, ctx.k = bool(relu), bias is not None, k
         return yn.permute(0, 3, 1, 2)          # logical NCHW, channels-last strides
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, yn, s, t0, inv, mean = ctx.saved_tensors
+        x, weight, yn, fold, mean = ctx.saved_tensors
+        s = fold[0]
         Cout, Cin = weight.shape[0], weight.shape[1]
         gz, sums = ops.nhwc_affine_relu_bwd(_nhwc(gy), yn, s, ctx.relu)
         need = ctx.needs_input_grad
         gx = gw = gb = ggamma = gbeta = None
-        if need[4]:
-            gbeta = sums[0]
-        if need[3]:
-            # u = (z - mean) inv gamma + beta:  d gamma = inv (sum gu z - mean sum gu),  sum gu z = (sum gu y - t0 sum gu) / s
-            ggamma = (torch.where(s != 0, (sums[1] - t0 * sums[0]) / s, torch.zeros_like(s)) - mean * sums[0]) * inv
+        if need[3] or need[4]:
+            # u = (z - mean) inv gamma + beta:  d gamma = inv (sum gu z - mean sum gu),  sum gu z = (sum gu y - t0 sum gu) / s;  d beta = sum gu
+            pg = ops.bn_eval_grads(sums, fold, mean)
+            ggamma = pg[0] if need[3] else None
+            gbeta = pg[1] if need[4] else None
         if ctx.has_bias and need[2]:
             gb = sums[0] * s
         w = weight.detach()
@@ -259,23 +259,19 @@ class _OSAChain(torch.autograd.Function):
         lo, hi = 0, Cin            # the input slice of the next layer
         for i in range(L):
             w, gamma, beta, mean, var = params[5 * i:5 * i + 5]
-            inv = torch.rsqrt(var + eps[i])
-            sc = gamma.detach() * inv
-            t0 = beta.detach() - mean * sc
-            ops.wino43(cat[..., lo:hi], ops.pack_wino43_weights(w.detach()), widths[i], sc, t0, True, out=cat[..., hi:hi + widths[i]])
-            aff += [sc, t0, inv]
+            fold = ops.bn_eval_fold(gamma.detach(), beta.detach(), mean, var, eps[i])
+            ops.wino43(cat[..., lo:hi], ops.pack_wino43_weights(w.detach()), widths[i], fold[0], fold[1], True, out=cat[..., hi:hi + widths[i]])
+            aff.append(fold)
             lo, hi = hi, hi + widths[i]
             if i == 0:
                 lo = Cin
         wc, gamma, beta, mean, var = params[5 * L:5 * L + 5]
         Cout = int(wc.shape[0])
-        inv = torch.rsqrt(var + eps[L])
-        sc = gamma.detach() * inv
-        t0 = beta.detach() - mean * sc
+        fold = ops.bn_eval_fold(gamma.detach(), beta.detach(), mean, var, eps[L])
         w2 = wc.detach().reshape(Cout, Ctot)
-        yc = ops.conv1x1_nhwc(cat, lambda: ops.pack_conv1x1_nhwc_weights(w2), Cout, sc, t0, True,
+        yc = ops.conv1x1_nhwc(cat, lambda: ops.pack_conv1x1_nhwc_weights(w2), Cout, fold[0], fold[1], True,
                               packed_split=lambda: ops.pack_conv1x1_nhwc_split_weights(w2))
-        aff += [sc, t0, inv]
+        aff.append(fold)
         ctx.save_for_backward(cat, yc, *ws, *[params[5 * i + 3] for i in range(L + 1)], *aff)
         ctx.L, ctx.Cin, ctx.widths = L, Cin, widths
         return yc.permute(0, 3, 1, 2)          # logical NCHW, channels-last strides
@@ -285,22 +281,23 @@ class _OSAChain(torch.autograd.Function):
         L, Cin, widths = ctx.L, ctx.Cin, ctx.widths
         sv = ctx.saved_tensors
         cat, yc = sv[0], sv[1]
-        ws, means, aff = sv[2:3 + L], sv[3 + L:4 + 2 * L], sv[4 + 2 * L:]
+        ws, means, aff = sv[2:3 + L], sv[3 + L:4 + 2 * L], sv[4 + 2 * L:]      # aff[i] = (3, C): s, t0, inv of layer i
         need = ctx.needs_input_grad            # x, eps, then 5 per layer: weight, gamma, beta, mean, var
         grads = [None] * (2 + 5 * (L + 1))
 
         def affine_grads(i, sums):
-            sc, t0, inv = aff[3 * i:3 * i + 3]
-            if need[2 + 5 * i + 2]:
-                grads[2 + 5 * i + 2] = sums[0]
-            if need[2 + 5 * i + 1]:
-                grads[2 + 5 * i + 1] = (torch.where(sc != 0, (sums[1] - t0 * sums[0]) / sc, torch.zeros_like(sc)) - means[i] * sums[0]) * inv
+            if need[2 + 5 * i + 1] or need[2 + 5 * i + 2]:
+                pg = ops.bn_eval_grads(sums, aff[i], means[i])
+                if need[2 + 5 * i + 1]:
+                    grads[2 + 5 * i + 1] = pg[0]
+                if need[2 + 5 * i + 2]:
+                    grads[2 + 5 * i + 2] = pg[1]
 
         # the concat convolution
         Ctot = cat.shape[3]
         wc = ws[L].detach()
         Cout = wc.shape[0]
-        gz, sums = ops.nhwc_affine_relu_bwd(_nhwc(gy), yc, aff[3 * L], True)
+        gz, sums = ops.nhwc_affine_relu_bwd(_nhwc(gy), yc, aff[L][0], True)
         affine_grads(L, sums)
         w_t = wc.reshape(Cout, Ctot).t().contiguous()
         g_cat = ops.conv1x1_nhwc(gz, lambda: ops.pack_conv1x1_nhwc_weights(w_t), Ctot,
@@ -314,7 +311,7 @@ class _OSAChain(torch.autograd.Function):
         for i in range(L - 1, -1, -1):
             out_lo = out_hi - widths[i]
             in_lo, in_hi = (0, Cin) if i == 0 else (out_lo - widths[i - 1], out_lo)
-            gz, sums = ops.nhwc_affine_relu_bwd(g_cat[..., out_lo:out_hi], cat[..., out_lo:out_hi], aff[3 * i], True, gy2=carry)
+            gz, sums = ops.nhwc_affine_relu_bwd(g_cat[..., out_lo:out_hi], cat[..., out_lo:out_hi], aff[i][0], True, gy2=carry)
             affine_grads(i, sums)
             w = ws[i].detach()
             if need[2 + 5 * i]:
