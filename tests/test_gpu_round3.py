@@ -332,7 +332,10 @@ def test_graphs_are_recaptured_when_the_packed_weights_are_dropped(dev):
             g.simple_test(None, [pts], copy.deepcopy(metas))
         first = g._graphed_frame
         assert first.stats["replays"] >= 1
-        g.eval()                                           # drops the packed weights -> must drop the graphs too
+        g.eval()                                           # nothing changed (same mode, same parameter tensors and versions): kept
+        assert g._graphed_frame is first
+        g.train()
+        g.eval()                                           # a mode switch drops the packed weights -> must drop the graphs too
         assert g._graphed_frame is not first and g._graphed_frame.entry is None
         junk = [torch.full((1 << 20,), float("nan"), device=dev) for _ in range(64)]   # recycle the freed blocks
         for _ in range(3):
