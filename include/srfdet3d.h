@@ -247,6 +247,13 @@ int srf_spconv_tiles_row_cost(void);
 size_t srf_spconv_tiles_workspace_bytes(int A_out);
 int srf_spconv_tiles_build(const int *nbr, int nbr_stride, int K, int A_out, const int *rows_dev, void *workspace,
                            int *tiles, srf_stream_t stream);
+/* Row order for the 32-output-channel layers of srf_spconv_fwd_packed (optional; passed as its `tiles` argument when Cout == 32,
+ * Cin in {16, 32}, K == 27): rows with the same set of kernel offsets side by side, so that a wave, which multiplies every offset any of
+ * its 32 rows has, skips more of them.  plan: srf_spconv_order_ints(A_out, K) ints = [order: A_pad][sorted rulebook: K x A_pad], A_pad =
+ * A_out rounded up to 1024; order[pos] = the row at position pos (-1: padding).  One launch, no workspace; rows_dev as for the
+ * convolution.  Outputs are bit-identical with and without a plan (every row is its own fma chain).  No reference counterpart. */
+size_t srf_spconv_order_ints(int A_out, int K);
+int srf_spconv_order_build(const int *nbr, int nbr_stride, int K, int A_out, const int *rows_dev, int *plan, srf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * K6  SparseConvTensor.dense() (+ the view to (B, C*D, H, W), which is a no-op on this layout).

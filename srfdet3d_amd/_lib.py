@@ -66,6 +66,8 @@ SIGNATURES = {
     "srf_spconv_tiles_row_cost": (c_int, []),
     "srf_spconv_tiles_workspace_bytes": (c_size_t, [c_int]),
     "srf_spconv_tiles_build": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "srf_spconv_order_ints": (c_size_t, [c_int, c_int]),
+    "srf_spconv_order_build": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "srf_densify": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "srf_roi_extract": (c_int, [POINTER(FeatMap), c_int, c_int, _P, c_int, c_int, c_int, c_float, _P, c_int64,
                                 c_int64, c_int64, c_int, _P, _P]),

@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(256) void srf_gs_rowpairs_k(const int *__restrict__
         {
             // all K entries of the row in flight at once (as a loop of `c += nbr[..] >= 0` every entry was its own round trip: 27 in a
             // row, the whole of this 9-10 us launch); rows past the end read row A - 1 and count nothing
-            const int rc = r < A ? r : A - 1;
+            const int rc = r < A ? r : (A > 0 ? A - 1 : 0);   // (A == 0, a level without live rows: row 0 of the capacity-sized table, counted as nothing)
             int v[SRF_KMAX];
 #pragma unroll
             for (int k = 0; k < SRF_KMAX; ++k) v[k] = nbr[(size_t)(k < K ? k : K - 1) * nbr_stride + rc];
@@ -1890,6 +1890,103 @@ __global__ __launch_bounds__(256, 2) void srf_spconv_gsp_k(const float *__restri
 // Every output is the same chain as before (offset ascending, channel ascending, zero terms added as +0): bit-identical to
 // the tile kernel and the oracle.
 // =====================================================================================================================
+// ---------------------------------------------------------------------------------------------------------------------
+// Row order for the 32-channel layers (srf_spconv_w32_k): a wave multiplies EVERY offset that any of its 32 rows has -- 0.77 of the
+// 27 offsets on the level-2 rulebook of a nuScenes sweep, 0.54 on the strided 16 -> 32 one, where 0.28 / 0.05 exist.  Rows with the same
+// set of offsets put side by side share their zeros: sorted by an 11-bit key of the offset mask (has any z - 1 neighbour, has any z + 1
+// neighbour, the nine offsets of the row's own z plane) inside windows of 1024 rows a 32-row group executes 0.47 / 0.28 of the
+// offsets.  One launch per rulebook (shared by the SubM layers of a level): a workgroup counting-sorts its window in LDS and writes
+//   plan[0 .. A_pad)                      order[pos] = row at sorted position pos (-1: padding)
+//   plan[A_pad + k A_pad + pos]           the rulebook entry nbr[k][order[pos]] (-1: none)
+// Which rows share a wave changes nothing in any output (every row is its own fma chain): bit-identical.
+// ---------------------------------------------------------------------------------------------------------------------
+#define SRF_ORD_WIN 1024
+#define SRF_ORD_BINS 2048
+__host__ __device__ static inline int srf_ord_pad(int A) { return ((A + SRF_ORD_WIN - 1) / SRF_ORD_WIN) * SRF_ORD_WIN; }
+
+__global__ __launch_bounds__(256) void srf_spconv_order_k(const int *__restrict__ nbr, int nbr_stride, int K, int A, int A_pad,
+                                                         const int *__restrict__ rows_dev, int *__restrict__ plan)
+{
+    __shared__ int s_hist[SRF_ORD_BINS];
+    __shared__ int s_part[256];
+    __shared__ int s_row[SRF_ORD_WIN];
+    if (rows_dev) {
+        const int live = *rows_dev;
+        A = A < live ? A : live;
+    }
+    const int tid = threadIdx.x, w0 = blockIdx.x * SRF_ORD_WIN;
+    for (int b = tid; b < SRF_ORD_BINS; b += 256) s_hist[b] = 0;
+    __syncthreads();
+    int key[4], rank[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = w0 + i * 256 + tid;
+        const int rc = row < A ? row : (A > 0 ? A - 1 : 0);
+        unsigned m = 0;
+        int v[SRF_KMAX];
+#pragma unroll
+        for (int k = 0; k < SRF_KMAX; ++k) v[k] = nbr[(size_t)(k < K ? k : K - 1) * nbr_stride + rc];
+#pragma unroll
+        for (int k = 0; k < SRF_KMAX; ++k) m |= (k < K && v[k] >= 0 ? 1u : 0u) << k;
+        const unsigned p0 = m & 0x1ffu, p1 = (m >> 9) & 0x1ffu, p2 = (m >> 18) & 0x1ffu;
+        unsigned kk = K == SRF_KMAX ? ((((p0 != 0 ? 1u : 0u) | (p2 != 0 ? 2u : 0u)) << 9) | p1) : (m & (SRF_ORD_BINS - 1));
+        key[i] = row < A ? (int)kk : SRF_ORD_BINS - 1;   // rows past the end sort last (their order entry becomes -1)
+        rank[i] = atomicAdd(&s_hist[key[i]], 1);
+    }
+    __syncthreads();
+    // exclusive prefix of the 2048 bins: 8 consecutive bins per thread, then the 256 partial sums
+    int loc[8], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        loc[j] = sum;
+        sum += s_hist[tid * 8 + j];
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    int base = 0;
+    for (int t = 0; t < tid; ++t) base += s_part[t];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_hist[tid * 8 + j] = base + loc[j];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_row[s_hist[key[i]] + rank[i]] = i * 256 + tid;   // (ranks inside a bin: arrival order, any order is right)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = i * 256 + tid, pos = w0 + p;
+        if (pos >= A_pad) continue;
+        const int row = w0 + s_row[p];
+        const bool live = row < A;
+        plan[pos] = live ? row : -1;
+        const int rc = live ? row : (A > 0 ? A - 1 : 0);
+        int v[SRF_KMAX];
+#pragma unroll
+        for (int k = 0; k < SRF_KMAX; ++k) v[k] = nbr[(size_t)(k < K ? k : K - 1) * nbr_stride + rc];
+#pragma unroll
+        for (int k = 0; k < SRF_KMAX; ++k)
+            if (k < K) plan[(size_t)A_pad + (size_t)k * A_pad + pos] = live ? v[k] : -1;
+    }
+}
+
+extern "C" size_t srf_spconv_order_ints(int A_out, int K)
+{
+    if (A_out <= 0 || K <= 0 || K > SRF_KMAX) return 0;
+    return (size_t)srf_ord_pad(A_out) * (size_t)(1 + K);
+}
+
+extern "C" int srf_spconv_order_build(const int *nbr, int nbr_stride, int K, int A_out, const int *rows_dev, int *plan, srf_stream_t stream)
+{
+    if (A_out < 0 || K <= 0 || K > SRF_KMAX || nbr_stride < A_out) return SRF_EINVAL;
+    if (A_out == 0) return SRF_OK;
+    if (!nbr || !plan) return SRF_EINVAL;
+    const int A_pad = srf_ord_pad(A_out);
+    hipLaunchKernelGGL(srf_spconv_order_k, dim3(A_pad / SRF_ORD_WIN), dim3(256), 0, (hipStream_t)stream, nbr, nbr_stride, K, A_out, A_pad,
+                       rows_dev, plan);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
 #ifndef SRF_W32_DEPTH
 #define SRF_W32_DEPTH 6
 #endif
@@ -1898,32 +1995,48 @@ __global__ __launch_bounds__(512) void srf_spconv_w32_k(const float *__restrict_
                                                        const int *__restrict__ nbr, int nbr_stride, int A_out,
                                                        const float *__restrict__ alpha, const float *__restrict__ beta,
                                                        const float *__restrict__ residual, int relu, float *__restrict__ out,
-                                                       const int *__restrict__ rows_dev)
+                                                       const int *__restrict__ rows_dev, const int *__restrict__ plan)
 {
     constexpr int K = SRF_KMAX, H = CIN / 2, NV = H / 4, NB = CIN / 8, TM = 256;
     extern __shared__ __attribute__((aligned(16))) f32x4 s_w32[];   // [K][NB][2][32]
+    const int A_cap = A_out;
     if (rows_dev) {
         const int live = *rows_dev;
         A_out = A_out < live ? A_out : live;
     }
-    const int n_tiles = (A_out + TM - 1) / TM;
+    const int n_tiles = plan ? ((A_out + SRF_ORD_WIN - 1) / SRF_ORD_WIN) * 4 : (A_out + TM - 1) / TM;
     if ((int)blockIdx.x >= n_tiles) return;
-    const int row0 = srf_xcd_tile(blockIdx.x, n_tiles) * TM;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, kh = lane >> 5;
-    const int row = row0 + wave * 32 + r;
+    // with a plan (srf_spconv_order_build) the wave's 32 rows are a group of the sorted order: `row` is a POSITION, the rulebook
+    // entries come from the plan's sorted copy, the output row is order[position].  The 32 groups of a 1024-row window go to its
+    // four workgroups in turn (group 4 w + b to wave w of workgroup b): every workgroup, and every pair of waves that shares a SIMD,
+    // gets light and heavy groups alike.
+    int row0 = 0, row;
+    if (plan) {
+        const int A_pad = srf_ord_pad(A_cap);
+        const int win = blockIdx.x >> 2, b = blockIdx.x & 3;
+        row = win * SRF_ORD_WIN + (4 * wave + b) * 32 + r;
+        nbr = plan + A_pad;
+        nbr_stride = A_pad;
+    } else {
+        row0 = srf_xcd_tile(blockIdx.x, n_tiles) * TM;
+        row = row0 + wave * 32 + r;
+    }
     const f32x4 *Wp4 = reinterpret_cast<const f32x4 *>(Wp);
     for (int i = tid; i < K * NB * 64; i += 512) s_w32[i] = Wp4[i];
     // all K rulebook entries of the row in flight at once (a load under `row < A_out` is a load under a branch: hipcc then waits for
     // each one before the next -- 27 round trips in a row): rows past the end read the last row's entries and drop them
     int idx[K];
     unsigned anym = 0;
-    const int row_ld = row < A_out ? row : A_out - 1;
+    const int row_ld = (plan || row < A_out) ? row : A_out - 1;     // (every position of a plan exists: padding holds -1)
+    const bool row_ok = plan || row < A_out;
+    const int ord = plan ? plan[row] : row;                          // the output row behind this lane's row / position (-1: none)
 #pragma unroll
     for (int k = 0; k < K; ++k) idx[k] = nbr[(size_t)k * nbr_stride + row_ld];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        idx[k] = row < A_out ? idx[k] : -1;
+        idx[k] = row_ok ? idx[k] : -1;
         anym |= (__ballot(idx[k] >= 0) != 0ull ? 1u : 0u) << k;
     }
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)((long long)A_in * CIN * 4), 0x00020000);
@@ -1984,22 +2097,24 @@ __global__ __launch_bounds__(512) void srf_spconv_w32_k(const float *__restrict_
     const float al = alpha ? alpha[r] : 1.0f;
     const float be = alpha ? beta[r] : 0.0f;
     // the 16 residual values in flight together (one load per row under its own `orow < A_out` branch was 16 round trips in a row)
+    int orow[16];   // accumulator register j holds row (j & 3) + 8 (j >> 2) + 4 kh of the wave's 32: its output row is lane that-index's `ord`
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int o = __shfl(ord, (j & 3) + 8 * (j >> 2) + 4 * kh);
+        orow[j] = (o >= 0 && o < A_out) ? o : -1;
+    }
     float res[16];
     if (residual) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int orow = row0 + wave * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
-            res[j] = residual[(size_t)(orow < A_out ? orow : A_out - 1) * 32 + r];
-        }
+        for (int j = 0; j < 16; ++j) res[j] = residual[(size_t)(orow[j] >= 0 ? orow[j] : 0) * 32 + r];
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const int orow = row0 + wave * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
         float v = acc[j];
         if (alpha) v = __fmaf_rn(v, al, be);
         if (residual) v = __fadd_rn(v, res[j]);
         if (relu) v = v > 0.0f ? v : 0.0f;
-        if (orow < A_out) out[(size_t)orow * 32 + r] = v;
+        if (orow[j] >= 0) out[(size_t)orow[j] * 32 + r] = v;
     }
 }
 
@@ -2030,12 +2145,14 @@ extern "C" int srf_spconv_fwd_packed(const float *in, int A_in, int Cin, const f
                 SRF_HIP_TRY(hipFuncSetAttribute((const void *)srf_spconv_w32_k<16>, hipFuncAttributeMaxDynamicSharedMemorySize, SRF_KMAX * 16 * 32 * 4));
                 attr_set[dev] = true;
             }
+            // `tiles` of a 32-channel layer = the plan of srf_spconv_order_build (NULL: rows in their own order)
+            const unsigned grid32 = tiles ? (unsigned)(srf_ord_pad(A_out) / 256) : (unsigned)srf_ceil_div(A_out, 256);
             if (Cin == 32)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_w32_k<32>), dim3(srf_ceil_div(A_out, 256)), dim3(512), SRF_KMAX * 32 * 32 * 4, st, in,
-                                   A_in, W_packed, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_w32_k<32>), dim3(grid32), dim3(512), SRF_KMAX * 32 * 32 * 4, st, in,
+                                   A_in, W_packed, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev, tiles);
             else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_w32_k<16>), dim3(srf_ceil_div(A_out, 256)), dim3(512), SRF_KMAX * 16 * 32 * 4, st, in,
-                                   A_in, W_packed, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_w32_k<16>), dim3(grid32), dim3(512), SRF_KMAX * 16 * 32 * 4, st, in,
+                                   A_in, W_packed, nbr, nbr_stride, A_out, alpha, beta, residual, relu, out, rows_dev, tiles);
             break;
         }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_packed_k<32, 128, 4, 1>), dim3(srf_ceil_div(A_out, 128)), dim3(256),

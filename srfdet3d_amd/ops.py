@@ -359,8 +359,36 @@ def pack_spconv_weights(weight):
 
 
 def spconv_tiles_wanted(Cin, Cout):
-    """True for the layer shapes whose packed kernel takes work-balanced row ranges (`tiles=` of spconv_fwd)."""
-    return (Cout == 128 and Cin in (64, 128)) or (Cout == 64 and Cin in (32, 64))
+    """True for the layer shapes whose packed kernel takes a row plan (`tiles=` of spconv_fwd): work-balanced row ranges
+    (`spconv_tiles`) for the 64- / 128-channel kernels, a mask-sorted row order (`spconv_order`) for the 32-channel one."""
+    return (Cout == 128 and Cin in (64, 128)) or (Cout == 64 and Cin in (32, 64)) or spconv_order_wanted(Cin, Cout)
+
+
+SPCONV_ORDER_MIN_ROWS = 100000   # rows of a level from which the sorted order pays for its launch (tools/tmp/w32_probe2.py, MI355X:
+# nuScenes level 2, 60k rows: 32 -> 32 40.2 -> 35.5 us and 16 -> 32 22.7 -> 18.7 for 15-17 us of plan build per rulebook -- a loss;
+# Waymo level 2, 226k rows: 145 -> 120 us and 70 -> 45 for 20 us -- 85 us per frame gained)
+
+
+def spconv_order_wanted(Cin, Cout, K=27, rows=None):
+    """rows=None: is this a layer shape the plan exists for; with rows: also, is the level large enough for it to pay
+    (SRF_SPCONV_ORDER=0 / 2: never / at any size)."""
+    mode = os.environ.get("SRF_SPCONV_ORDER", "1")
+    if not (Cout == 32 and Cin in (16, 32) and K == 27 and mode != "0"):
+        return False
+    return rows is None or mode == "2" or rows >= SPCONV_ORDER_MIN_ROWS
+
+
+def spconv_order(nbr, rows_dev=None):
+    """The plan of `srf_spconv_order_build` for the rulebook nbr (K, A_out): int32 [order | sorted rulebook].  Built once per
+    rulebook and passed as `tiles=` to every 32-channel spconv_fwd(..., packed=) that uses it."""
+    if not nbr.is_cuda or nbr.dtype != torch.int32 or nbr.stride(1) != 1:
+        raise RuntimeError("srfdet3d_amd: `nbr` must be a GPU int32 tensor with unit inner stride")
+    K, A_out = nbr.shape
+    L = _lib.lib()
+    plan = _empty((max(L.srf_spconv_order_ints(A_out, K), 1),), torch.int32, nbr.device)
+    check(L.srf_spconv_order_build(_ptr(nbr), nbr.stride(0) if A_out > 0 else 0, K, A_out, _ptr(rows_dev), _ptr(plan), _stream()),
+          "spconv_order_build")
+    return plan
 
 
 def spconv_tiles(nbr, rows_dev=None):

@@ -195,10 +195,18 @@ class _SparseConv(SparseModule):
             # from them than they cost (64 -> 128 on the nuScenes encoder: 92 -> 76 us, its steps 36 +- 37 -> 35 +- 19 per workgroup;
             # the three small launches of the cut run on the index stream of the graph, ahead of the convolutions); conv_out (3
             # offsets) runs on equal-height tiles
-            tkey = ("tiles", nbr.data_ptr(), nbr.shape[1])
-            tiles = x.indice_dict.get(tkey)
-            if tiles is None:
-                tiles = x.indice_dict[tkey] = ops.spconv_tiles(nbr, rows_dev)
+            if self.out_channels == 32:
+                # 32-channel layers: a mask-sorted row order instead of ranges, from ~100k rows up (Waymo's levels)
+                if ops.spconv_order_wanted(self.in_channels, self.out_channels, rows=nbr.shape[1]):
+                    tkey = ("order", nbr.data_ptr(), nbr.shape[1])
+                    tiles = x.indice_dict.get(tkey)
+                    if tiles is None:
+                        tiles = x.indice_dict[tkey] = ops.spconv_order(nbr, rows_dev)
+            else:
+                tkey = ("tiles", nbr.data_ptr(), nbr.shape[1])
+                tiles = x.indice_dict.get(tkey)
+                if tiles is None:
+                    tiles = x.indice_dict[tkey] = ops.spconv_tiles(nbr, rows_dev)
         if x.features is None:
             return SparseConvTensor(None, out_idx, oshape, x.batch_size, x.indice_dict, rows_dev)
         K = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]

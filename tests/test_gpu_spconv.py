@@ -108,8 +108,8 @@ def test_spconv_fwd_exact(dev, cin, cout, K):
             got = ops.spconv_fwd(tt(feats), tt(W), tt(nbr), tt(alpha) if use_bn else None, tt(beta) if use_bn else None,
                                  tt(res) if use_res else None, relu, packed=ops.pack_spconv_weights(tt(W))).cpu().numpy()
             assert np.array_equal(got, ref), f"packed: max abs diff {np.abs(got - ref).max()}"
-            if ops.spconv_tiles_wanted(cin, cout):  # the same kernel walking work-balanced row ranges
-                tiles = ops.spconv_tiles(tt(nbr))
+            if ops.spconv_tiles_wanted(cin, cout):  # the same kernel walking work-balanced row ranges / a mask-sorted row order
+                tiles = ops.spconv_order(tt(nbr)) if ops.spconv_order_wanted(cin, cout) else ops.spconv_tiles(tt(nbr))
                 got = ops.spconv_fwd(tt(feats), tt(W), tt(nbr), tt(alpha) if use_bn else None, tt(beta) if use_bn else None,
                                      tt(res) if use_res else None, relu, packed=ops.pack_spconv_weights(tt(W)),
                                      tiles=tiles).cpu().numpy()
@@ -265,3 +265,48 @@ def test_bitmap_rulebook_empty_and_corner(dev):
     perm = np.argsort(_sort_key(oi, osh), kind="stable")
     np.testing.assert_array_equal(gi.cpu().numpy(), oi[perm])
     np.testing.assert_array_equal(gn.cpu().numpy(), nbr[:, perm])
+
+
+@pytest.mark.parametrize("n,live", [(6000, None), (6000, 4100), (700, None), (3000, 0)])
+def test_spconv_order_plan_is_a_sorted_permutation(dev, n, live):
+    """srf_spconv_order_build: order = a permutation of the live rows (padding -1) that keeps every row inside its window of 1024, the
+    plan's rulebook = the rulebook's columns in that order, and inside a window the rows are grouped by the key of their offset mask;
+    the 32-channel convolution with the plan equals the one without, bit for bit, on a padded (static-shape) level too"""
+    idx = _level1(n=n)
+    nbr, _ = O.rulebook_subm(idx, SHAPE1, [3, 3, 3])
+    A = nbr.shape[1]
+    cap = A + 300                                    # capacity > live rows: the static-shape form
+    nb = np.full((27, cap), -1, np.int32)
+    nb[:, :A] = nbr
+    n_live = A if live is None else min(live, A)
+    t_nbr = torch.from_numpy(nb).to(dev)
+    rows_dev = torch.tensor([n_live], dtype=torch.int32, device=dev)
+    plan = ops.spconv_order(t_nbr, rows_dev).cpu().numpy()
+    a_pad = (cap + 1023) // 1024 * 1024
+    assert plan.shape[0] == a_pad * 28
+    order, snbr = plan[:a_pad], plan[a_pad:].reshape(27, a_pad)
+    livepos = order >= 0
+    assert np.array_equal(np.sort(order[livepos]), np.arange(n_live))
+    pos = np.nonzero(livepos)[0]
+    assert np.array_equal(pos // 1024, order[livepos] // 1024)          # rows stay inside their window
+    assert np.array_equal(snbr[:, livepos], nb[:, order[livepos]]) and (snbr[:, ~livepos] == -1).all()
+    mask = (nb[:, :n_live] >= 0)
+    m = (mask * (1 << np.arange(27))[:, None]).sum(0)
+    key = ((((m & 0x1ff) != 0) * 1 + (((m >> 18) & 0x1ff) != 0) * 2) << 9) | ((m >> 9) & 0x1ff)
+    for w in range((n_live + 1023) // 1024):
+        inw = pos[(pos // 1024) == w]
+        k = key[order[inw]]
+        assert (np.diff(k) >= 0).all()                                     # grouped by key inside the window
+    if n_live == 0:
+        return
+    rng = np.random.default_rng(n)
+    for cin in (16, 32):
+        feats = rng.standard_normal((A, cin)).astype(np.float32)
+        W = (rng.standard_normal((27, cin, 32)) / np.sqrt(cin * 3)).astype(np.float32)
+        res = rng.standard_normal((cap, 32)).astype(np.float32)
+        tt = lambda x: torch.from_numpy(x).to(dev)
+        packed = ops.pack_spconv_weights(tt(W))
+        a = ops.spconv_fwd(tt(feats), tt(W), t_nbr, None, None, tt(res), True, packed=packed, rows_dev=rows_dev).cpu().numpy()
+        b = ops.spconv_fwd(tt(feats), tt(W), t_nbr, None, None, tt(res), True, packed=packed, rows_dev=rows_dev,
+                           tiles=ops.spconv_order(t_nbr, rows_dev)).cpu().numpy()
+        assert np.array_equal(a[:n_live], b[:n_live])
