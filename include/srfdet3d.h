@@ -521,7 +521,7 @@ int srf_stem_conv_nchw(const float *x, int N, int Cin, int H, int W, const float
 
 /* ---- streaming layers of the channels-last camera branch (csrc/nhwc.hip); all take (N, H, W, ld) channel slices, C % 4 == 0,
  * 16-byte aligned pointers, ld % 4 == 0 ---------------------------------------------------------------------------------
- * srf_nhwc_affine: y = x * scale[(per_sample ? n : 0)][c] + shift[c] (+ residual), optional ReLU; scale / shift / residual
+ * srf_nhwc_affine: y = x * scale[(per_sample & 1 ? n : 0)][c] + shift[(per_sample & 2 ? n : 0)][c] (+ residual), optional ReLU; scale / shift / residual
  *   may be NULL; in place allowed: eval BatchNorm2d + ReLU behind a library convolution, and the eSE gate multiply + OSA
  *   identity add of VoVNet (vovnet.py:165-177, :225-228).  HW = pixels per sample.
  * srf_nhwc_colmean: mean[n][c] over the HW pixels (AdaptiveAvgPool2d(1) of the eSE module), deterministic two-level sum;
@@ -536,6 +536,10 @@ int srf_nhwc_affine(const float *x, long long x_ld, int N, long long HW, int C, 
 size_t srf_nhwc_colmean_workspace_bytes(int N, int C);
 int srf_nhwc_colmean(const float *x, long long x_ld, int N, long long HW, int C, float *mean, void *workspace,
                      size_t workspace_bytes, srf_stream_t stream);
+/* out[n][c] = sum over the pixels of a[n][p][c] * b[n][p][c] (training: the pixel sum behind the gradient of the eSE gate, vovnet.py:165-177);
+ * deterministic; workspace: srf_nhwc_colmean_workspace_bytes(N, C). */
+int srf_nhwc_colsum_prod(const float *a, long long a_ld, const float *b, long long b_ld, int N, long long HW, int C, float *out /*N x C*/,
+                         void *workspace, size_t workspace_bytes, srf_stream_t stream);
 int srf_nhwc_maxpool3s2_ceil(const float *x, long long x_ld, int N, int H, int W, int C, float *y, long long y_ld,
                              srf_stream_t stream);
 int srf_nhwc_upsample_add(const float *lat, long long l_ld, const float *top, long long t_ld, int N, int H, int W, int Ht, int Wt,

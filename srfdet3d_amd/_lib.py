@@ -136,6 +136,7 @@ SIGNATURES = {
     "srf_nhwc_affine": (c_int, [_P, c_longlong, c_int, c_longlong, c_int, _P, c_int, _P, _P, c_longlong, c_int, _P, c_longlong, _P]),
     "srf_nhwc_colmean_workspace_bytes": (c_size_t, [c_int, c_int]),
     "srf_nhwc_colmean": (c_int, [_P, c_longlong, c_int, c_longlong, c_int, _P, _P, c_size_t, _P]),
+    "srf_nhwc_colsum_prod": (c_int, [_P, c_longlong, _P, c_longlong, c_int, c_longlong, c_int, _P, _P, c_size_t, _P]),
     "srf_nhwc_maxpool3s2_ceil": (c_int, [_P, c_longlong, c_int, c_int, c_int, c_int, _P, c_longlong, _P]),
     "srf_nhwc_upsample_add": (c_int, [_P, c_longlong, _P, c_longlong, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_longlong, _P]),
     "srf_nhwc_dwconv3x3s2": (c_int, [_P, c_longlong, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_longlong, _P]),

@@ -26,10 +26,10 @@ __global__ __launch_bounds__(256) void srf_nhwc_affine_k(const float *__restrict
     const int cq = (int)(t - p * Cq);
     f32x4n v = *reinterpret_cast<const f32x4n *>(x + p * x_ld + cq * 4);
     if (scale) {
-        const long long n = per_sample ? p / HW : 0;
+        const long long n = (per_sample & 1) ? p / HW : 0;
         v *= *reinterpret_cast<const f32x4n *>(scale + n * Cq * 4 + cq * 4);
     }
-    if (shift) v += *reinterpret_cast<const f32x4n *>(shift + cq * 4);
+    if (shift) v += *reinterpret_cast<const f32x4n *>(shift + ((per_sample & 2) ? (p / HW) * Cq * 4 : 0) + cq * 4);
     if (res) v += *reinterpret_cast<const f32x4n *>(res + p * r_ld + cq * 4);
     if (relu) {
         v[0] = fmaxf(v[0], 0.f);
@@ -159,7 +159,8 @@ extern "C" int srf_ese_apply(const float *x, long long x_ld, int N, long long HW
 #define CM_CHUNKS 64
 
 __global__ __launch_bounds__(256) void srf_nhwc_colsum_k(const float *__restrict__ x, long long x_ld, long long HW, int Cq,
-                                                         float *__restrict__ partial)
+                                                         float *__restrict__ partial, const float *__restrict__ x2 = nullptr,
+                                                         long long x2_ld = 0)
 {
     __shared__ f32x4n s_p[256];
     const int n = blockIdx.y, chunk = blockIdx.x;
@@ -171,8 +172,14 @@ __global__ __launch_bounds__(256) void srf_nhwc_colsum_k(const float *__restrict
     if (p1 > HW) p1 = HW;
     f32x4n acc = {0.f, 0.f, 0.f, 0.f};
     const float *xn = x + (long long)n * HW * x_ld + cq * 4;
-    if (pl < lanes)
-        for (long long p = p0 + pl; p < p1; p += lanes) acc += *reinterpret_cast<const f32x4n *>(xn + p * x_ld);
+    if (pl < lanes) {
+        if (x2) {   // column sums of the product x * x2 (the eSE gate's gradient: sum over the pixels of g * out)
+            const float *x2n = x2 + (long long)n * HW * x2_ld + cq * 4;
+            for (long long p = p0 + pl; p < p1; p += lanes)
+                acc += *reinterpret_cast<const f32x4n *>(xn + p * x_ld) * *reinterpret_cast<const f32x4n *>(x2n + p * x2_ld);
+        } else
+            for (long long p = p0 + pl; p < p1; p += lanes) acc += *reinterpret_cast<const f32x4n *>(xn + p * x_ld);
+    }
     s_p[threadIdx.x] = acc;
     __syncthreads();
     if (pl == 0) {
@@ -206,6 +213,24 @@ extern "C" int srf_nhwc_colmean(const float *x, long long x_ld, int N, long long
     hipLaunchKernelGGL(srf_nhwc_colsum_k, dim3(CM_CHUNKS, N), dim3(256), 0, (hipStream_t)stream, x, x_ld, HW, Cq, (float *)workspace);
     hipLaunchKernelGGL(srf_nhwc_colmean_finish_k, dim3(srf_ceil_div((long long)N * C, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float *)workspace, N, C, 1.0f / (float)HW, mean);
+    SRF_LAUNCH_CHECK();
+    return SRF_OK;
+}
+
+// per-image column sums of a PRODUCT: out[n][c] = sum over the pixels of a[n][p][c] * b[n][p][c] (two-level, fixed order: deterministic);
+// the pixel sum the gradient of VoVNet's eSE gate needs (vovnet.py:165-177: d gate[n][c] = sum_p g * x).  Workspace as srf_nhwc_colmean's.
+extern "C" int srf_nhwc_colsum_prod(const float *a, long long a_ld, const float *b, long long b_ld, int N, long long HW, int C, float *out,
+                                    void *workspace, size_t workspace_bytes, srf_stream_t stream)
+{
+    if (N < 0 || HW <= 0 || C <= 0 || a_ld < C || b_ld < C) return SRF_EINVAL;
+    if (N == 0) return SRF_OK;
+    if (!a || !b || !out || !workspace) return SRF_EINVAL;
+    const int Cq = C / 4;
+    if ((C & 3) || Cq > 256 || (a_ld & 3) || (b_ld & 3) || ((uintptr_t)a & 15) || ((uintptr_t)b & 15) || N > 65535) return SRF_EUNSUPPORTED;
+    if (workspace_bytes < srf_nhwc_colmean_workspace_bytes(N, C)) return SRF_EWORKSPACE;
+    hipLaunchKernelGGL(srf_nhwc_colsum_k, dim3(CM_CHUNKS, N), dim3(256), 0, (hipStream_t)stream, a, a_ld, HW, Cq, (float *)workspace, b, b_ld);
+    hipLaunchKernelGGL(srf_nhwc_colmean_finish_k, dim3(srf_ceil_div((long long)N * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)workspace, N, C, 1.0f, out);
     SRF_LAUNCH_CHECK();
     return SRF_OK;
 }

@@ -1329,9 +1329,11 @@ def nhwc_affine(x, scale=None, shift=None, relu=False, residual=None, out=None):
     N, H, W, C = x.shape
     if out is None:
         out = _empty((N, H, W, C), torch.float32, x.device)
-    per_sample = int(scale is not None and scale.dim() == 2)
-    if scale is not None and scale.numel() != (N * C if per_sample else C):
+    per_sample = int(scale is not None and scale.dim() == 2) | (2 if (shift is not None and shift.dim() == 2) else 0)
+    if scale is not None and scale.numel() != (N * C if per_sample & 1 else C):
         raise ValueError("nhwc_affine: scale has the wrong size")
+    if shift is not None and shift.numel() != (N * C if per_sample & 2 else C):
+        raise ValueError("nhwc_affine: shift has the wrong size")
     check(_lib.lib().srf_nhwc_affine(_ptr(x), x_ld, N, H * W, C, _opt(scale, "scale"), per_sample, _opt(shift, "shift"),
                                      None if residual is None else _ptr(residual),
                                      0 if residual is None else nhwc_ld(residual), int(bool(relu)), _ptr(out), nhwc_ld(out),
@@ -1348,6 +1350,19 @@ def nhwc_colmean(x):
     mean = _empty((N, C), torch.float32, x.device)
     check(L.srf_nhwc_colmean(_ptr(x), x_ld, N, H * W, C, _ptr(mean), _ptr(ws), ws.numel() * 4, _stream()), "nhwc_colmean")
     return mean
+
+
+def nhwc_colsum_prod(a, b):
+    """(N, H, W, C) NHWC slices a, b -> (N, C): the sum over the pixels of a * b (deterministic two-level sum)."""
+    a_ld, b_ld = nhwc_ld(a), nhwc_ld(b)
+    N, H, W, C = a.shape
+    if tuple(b.shape) != (N, H, W, C):
+        raise ValueError("nhwc_colsum_prod: shapes differ")
+    L = _lib.lib()
+    ws = _empty((max(L.srf_nhwc_colmean_workspace_bytes(N, C) // 4, 1),), torch.float32, a.device)
+    out = _empty((N, C), torch.float32, a.device)
+    check(L.srf_nhwc_colsum_prod(_ptr(a), a_ld, _ptr(b), b_ld, N, H * W, C, _ptr(out), _ptr(ws), ws.numel() * 4, _stream()), "nhwc_colsum_prod")
+    return out
 
 
 def pool3s2_out(h):

@@ -51,6 +51,9 @@ class eSEModule(nn.Module):
         self.fc = nn.Conv2d(channel, channel, kernel_size=1)
 
     def forward(self, x, identity=None):
+        from .. import train_conv
+        if train_conv.ese_eligible(self, x, identity):
+            return train_conv.ese_apply(self, x, identity)     # training on channels-last tensors: one autograd node
         if fusable(x) and x.shape[0] <= 8 and x.shape[1] % 4 == 0:
             # the 1x1 conv on the pooled (N, C, 1, 1) tensor is a GEMV: fc + bias + hard sigmoid in one launch
             gate = ops.ese_gate(x.mean(dim=(2, 3)), self.fc.weight, self.fc.bias)

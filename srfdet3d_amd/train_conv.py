@@ -326,6 +326,59 @@ class _OSAChain(torch.autograd.Function):
         return tuple(grads)
 
 
+class _ESEApply(torch.autograd.Function):
+    """VoVNet's eSE module applied to an OSA block's output (vovnet.py:165-177, :225-228): y = out * hsigmoid(fc(mean(out))) (+ identity)
+    as one autograd node on channels-last tensors.  Forward: pixel mean, the gate GEMV, one streaming pass (the inference kernels).
+    Backward: ONE pass for the pixel sums of g * out (what the gate's gradient needs), the (N, C)-sized arithmetic of the gate, ONE pass
+    d out = g * gate + d mean / HW; the identity's gradient is g itself.  As torch ops the same backward is two multiplies, a
+    reduction, an expand and an add over the block's output -- five passes over 53 M elements per stage-4 block."""
+
+    @staticmethod
+    def forward(ctx, out, identity, weight, bias):
+        xn = _nhwc(out)
+        N, H, W, C = xn.shape
+        mean = ops.nhwc_colmean(xn)
+        gate = ops.ese_gate(mean, weight.detach(), bias.detach())
+        y = ops.nhwc_affine(xn, scale=gate, residual=None if identity is None else _nhwc(identity))
+        ctx.save_for_backward(out, mean, gate, weight, bias)
+        ctx.has_identity = identity is not None
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        out, mean, gate, weight, bias = ctx.saved_tensors
+        gn, xn = _nhwc(g), _nhwc(out)
+        N, H, W, C = xn.shape
+        need = ctx.needs_input_grad
+        d_out = d_w = d_b = None
+        w2 = weight.detach().reshape(C, C)
+        s = ops.nhwc_colsum_prod(gn, xn)                                   # (N, C): sum_p g * out = d gate
+        pre = torch.addmm(bias.detach(), mean, w2.t())                     # fc(mean): the gate's argument
+        dpre = s * ((pre > -3.0) & (pre < 3.0)).to(s.dtype) / 6.0          # hsigmoid = relu6(. + 3) / 6
+        if need[2]:
+            d_w = (dpre.t() @ mean).view_as(weight)
+        if need[3]:
+            d_b = dpre.sum(0)
+        if need[0]:
+            dmean = (dpre @ w2) / float(H * W)                            # back through the pixel mean
+            d_out = ops.nhwc_affine(gn, scale=gate, shift=dmean).permute(0, 3, 1, 2)
+        return d_out, (g if (ctx.has_identity and need[1]) else None), d_w, d_b
+
+
+def ese_eligible(mod, x, identity):
+    """The eSE module under autograd on a channels-last f32 GPU tensor (SRF_TRAIN_ESE=0: the torch ops)."""
+    C = x.shape[1] if x.dim() == 4 else 0
+    return (enabled() and os.environ.get("SRF_TRAIN_ESE", "1") != "0" and torch.is_grad_enabled() and x.dim() == 4 and x.is_cuda
+            and x.dtype == torch.float32 and x.stride(1) == 1 and not torch.is_autocast_enabled() and C % 4 == 0 and 0 < C <= 1024
+            and x.shape[0] <= 65535 and (x.requires_grad or mod.fc.weight.requires_grad)
+            and (identity is None or (tuple(identity.shape) == tuple(x.shape) and identity.stride(1) == 1))
+            and type(mod.fc) is nn.Conv2d and mod.fc.kernel_size == (1, 1) and mod.fc.bias is not None)
+
+
+def ese_apply(mod, x, identity):
+    return _ESEApply.apply(x, identity, mod.fc.weight, mod.fc.bias)
+
+
 def osa_eligible(block, x):
     """An OSA block whose body can run as `_OSAChain`: plain 3x3 layers (no reduction / depthwise form), every layer and the concat
     convolution fit `_ConvAffineRelu`'s conditions (bias-free convolutions, eval-mode BatchNorms with well-conditioned gammas), and

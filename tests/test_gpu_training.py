@@ -506,3 +506,31 @@ def test_osa_block_as_one_autograd_node_matches_float64(dev, cin, width, cout, L
         # (an element within rounding of zero takes the other side of a ReLU than float64 does, and five chained layers pass that on: the
         # per-layer nodes, the accepted route of round 4, show the same error on the same data -- the node must not be worse than they are)
         assert err < 2e-2 and err < max(1.5 * err_pl, 5e-4), (name, err, err_pl)
+
+
+@pytest.mark.parametrize("N,C,H,W,identity", [(2, 96, 13, 21, True), (3, 64, 9, 40, False), (12, 256, 8, 8, True)])
+def test_ese_module_as_one_autograd_node_matches_torch_ops(dev, N, C, H, W, identity):
+    """train_conv._ESEApply (pixel mean, gate GEMV, gate multiply + identity; backward: one pass for sum_p g * out, one for
+    g * gate + d mean / HW) against the same module through torch's operators in float64 (SRF_TRAIN_ESE=0 runs them in f32)"""
+    from srfdet3d_amd import train_conv
+    from srfdet3d_amd.plugin.vovnet import eSEModule
+    torch.manual_seed(C + H)
+    mod = eSEModule(C).to(dev)
+    x = (torch.randn(N, C, H, W, device=dev) * 2).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    idt = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True) if identity else None
+    g = torch.randn(N, C, H, W, device=dev)
+    assert train_conv.ese_eligible(mod, x, idt)
+    y = mod(x, idt)
+    assert type(y.grad_fn).__name__ == "_ESEApplyBackward"
+    y.backward(g)
+    got = [y.detach(), x.grad, mod.fc.weight.grad, mod.fc.bias.grad] + ([idt.grad] if identity else [])
+    xd = x.detach().double().requires_grad_(True)
+    wd, bd = mod.fc.weight.detach().double().requires_grad_(True), mod.fc.bias.detach().double().requires_grad_(True)
+    idd = idt.detach().double().requires_grad_(True) if identity else None
+    gate = F.relu6(F.conv2d(xd.mean(dim=(2, 3), keepdim=True), wd, bd) + 3.0) / 6.0
+    yr = xd * gate + (idd if identity else 0.0)
+    yr.backward(g.double())
+    ref = [yr.detach(), xd.grad, wd.grad, bd.grad] + ([idd.grad] if identity else [])
+    for name, a, b in zip(["y", "dx", "dW", "db", "d identity"], got, ref):
+        err = float((a.double() - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+        assert err < 2e-5, (name, err)
