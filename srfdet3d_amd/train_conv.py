@@ -479,11 +479,47 @@ def conv2d(conv, x):
     if eligible_depthwise(conv, x):
         return _DepthwiseNative.apply(x.contiguous(), conv.weight, conv.bias, conv.stride, conv.padding, conv.groups)
     if eligible_1x1(conv, x):
+        if (os.environ.get("SRF_TRAIN_CONV1X1", "1") != "0" and conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0
+                and conv.out_channels <= 1024 and x.shape[0] * x.shape[2] * x.shape[3] * max(conv.in_channels, conv.out_channels) * 512 < (1 << 31) * 128):
+            return _Conv1x1.apply(x, conv.weight, conv.bias)
         xn = _nhwc(x)
         N, H, W, C = xn.shape
         y = torch.nn.functional.linear(xn.reshape(N * H * W, C), conv.weight.view(conv.out_channels, C), conv.bias)
         return y.view(N, H, W, conv.out_channels).permute(0, 3, 1, 2)   # channels-last in, channels-last out
     return conv(x)
+
+
+class _Conv1x1(torch.autograd.Function):
+    """A bias-carrying 1x1 convolution without a BatchNorm behind it (the image FPN's lateral convolutions) on the library's GEMMs in all
+    three directions: forward and data gradient on `srf_conv1x1_nhwc` (the split GEMM from 128 tiles up), the weight gradient on
+    `srf_conv_wgrad_nhwc` (deterministic; as torch's `linear` it was one rocBLAS TN GEMM over 1.1 M pixels at 62 TFLOP/s)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        xn = _nhwc(x)
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        w2 = weight.detach().reshape(Cout, Cin)
+        yn = ops.conv1x1_nhwc(xn, lambda: ops.pack_conv1x1_nhwc_weights(w2), Cout, None, None if bias is None else bias.detach(), False,
+                              packed_split=lambda: ops.pack_conv1x1_nhwc_split_weights(w2))
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return yn.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        gn = _nhwc(gy)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            w_t = weight.detach().reshape(Cout, Cin).t().contiguous()
+            gx = ops.conv1x1_nhwc(gn, lambda: ops.pack_conv1x1_nhwc_weights(w_t), Cin,
+                                  packed_split=lambda: ops.pack_conv1x1_nhwc_split_weights(w_t)).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            gw = _weight_grad(gn, _nhwc(x), weight, 1)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gn.sum(dim=(0, 1, 2))
+        return gx, gw, gb
 
 
 def bn_eval(bn, y):

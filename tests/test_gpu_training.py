@@ -534,3 +534,27 @@ def test_ese_module_as_one_autograd_node_matches_torch_ops(dev, N, C, H, W, iden
     for name, a, b in zip(["y", "dx", "dW", "db", "d identity"], got, ref):
         err = float((a.double() - b).abs().max()) / max(float(b.abs().max()), 1e-30)
         assert err < 2e-5, (name, err)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,bias", [(2, 256, 128, 29, 50, True), (1, 512, 256, 13, 40, False)])
+def test_conv1x1_training_node_matches_float64(dev, N, Cin, Cout, H, W, bias):
+    """train_conv._Conv1x1 (the image FPN's lateral convolutions under autograd: forward / data gradient on the library's 1x1 GEMM, weight
+    gradient on srf_conv_wgrad_nhwc) against float64 autograd"""
+    from srfdet3d_amd import train_conv
+    torch.manual_seed(Cin + Cout)
+    conv = torch.nn.Conv2d(Cin, Cout, 1, bias=bias).to(dev)
+    x = torch.randn(N, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    g = torch.randn(N, Cout, H, W, device=dev)
+    y = train_conv.conv2d(conv, x)
+    assert type(y.grad_fn).__name__ == "_Conv1x1Backward" and y.stride(1) == 1
+    y.backward(g)
+    got = [y.detach(), x.grad, conv.weight.grad] + ([conv.bias.grad] if bias else [])
+    xd = x.detach().double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    bd = conv.bias.detach().double().requires_grad_(True) if bias else None
+    yr = F.conv2d(xd, wd, bd)
+    yr.backward(g.double())
+    ref = [yr.detach(), xd.grad, wd.grad] + ([bd.grad] if bias else [])
+    for name, a, b in zip(["y", "dx", "dW", "db"], got, ref):
+        err = float((a.double() - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+        assert err < 2e-5, (name, err)
