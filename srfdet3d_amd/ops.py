@@ -364,7 +364,7 @@ def spconv_tiles_wanted(Cin, Cout):
     return (Cout == 128 and Cin in (64, 128)) or (Cout == 64 and Cin in (32, 64)) or spconv_order_wanted(Cin, Cout)
 
 
-SPCONV_ORDER_MIN_ROWS = 100000   # rows of a level from which the sorted order pays for its launch (tools/tmp/w32_probe2.py, MI355X:
+SPCONV_ORDER_MIN_ROWS = 100000   # rows of a level from which the sorted order pays for its launch (tools/spconv_order_probe.py, MI355X:
 # nuScenes level 2, 60k rows: 32 -> 32 40.2 -> 35.5 us and 16 -> 32 22.7 -> 18.7 for 15-17 us of plan build per rulebook -- a loss;
 # Waymo level 2, 226k rows: 145 -> 120 us and 70 -> 45 for 20 us -- 85 us per frame gained)
 
