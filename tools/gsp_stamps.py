@@ -1,4 +1,6 @@
-"""developer: in-kernel phase times of srf_spconv_gsq_k (SRF_DEV_LIB=1 SRF_GSQ_STAMP=1 python tools/tmp/gsq_stamps.py [level])"""
+"""In-kernel s_memtime stamps of srf_spconv_gsp_k (developer library: `python -m srfdet3d_amd.build --dev`, then
+`SRF_DEV_LIB=1 SRF_GSP_ABL=5 python tools/gsp_stamps.py [level]`): per-workgroup prologue / loop / epilogue cycles and the per-step spread -- the
+measurement behind DESIGN.md section 4, "a wave issues no vector instruction while its partner streams MFMAs"."""
 import ctypes
 import os
 import sys
@@ -6,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from srfdet3d_amd import _lib, ops, synthetic  # noqa: E402
 
 lvl = int(sys.argv[1]) if len(sys.argv) > 1 else 4
