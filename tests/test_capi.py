@@ -49,6 +49,19 @@ def test_host_side_helpers():
     assert L.srf_spconv_tiles_count(35000) == 512 and L.srf_spconv_tiles_count(100) == 3 and L.srf_spconv_tiles_count(0) == 1
     assert L.srf_spconv_tiles_workspace_bytes(35000) >= 35000 * 4
     assert L.srf_spconv_tiles_build(None, 0, 27, 10, None, None, None, None) == -1
+    # round 5: the row plan of the 32-channel sparse convolutions, the weight-gradient kernel, the training helpers
+    assert L.srf_spconv_tiles_row_cost() >= 0
+    assert L.srf_spconv_order_ints(60451, 27) == ((60451 + 1023) // 1024 * 1024) * 28   # [order | 27 sorted rulebook rows], padded to 1024
+    assert L.srf_spconv_order_ints(0, 27) == 0 and L.srf_spconv_order_ints(100, 28) == 0
+    assert L.srf_spconv_order_build(None, 5, 27, 10, None, None, None) == -1          # row stride below the row count / no tables
+    assert L.srf_spconv_order_build(None, 0, 27, 0, None, None, None) == 0            # an empty level is nothing to do
+    assert L.srf_conv_wgrad_workspace_bytes(12, 58, 100, 192, 192, 3) >= 192 * 192 * 9 * 4
+    assert L.srf_conv_wgrad_workspace_bytes(12, 58, 100, 192, 192, 2) == 0            # 1x1 and 3x3 only
+    assert L.srf_conv_wgrad_nhwc(None, 192, None, 192, 12, 58, 100, 192, 192, 3, None, 0, None, None) == -1
+    assert L.srf_nhwc_affine_relu_bwd2(None, 8, None, 0, None, 8, 10, 7, None, 1, None, 8, None, None, 0, None) == -3   # C % 4
+    assert L.srf_nhwc_colsum_prod(None, 8, None, 8, 2, 10, 8, None, None, 0, None) == -1
+    assert L.srf_bn_eval_fold(None, None, None, None, 1e-5, 8, None, None) == -1
+    assert L.srf_bn_eval_grads(None, None, None, 8, None, None) == -1
     assert L.srf_points_filter_workspace_bytes(30000) >= 8 and L.srf_points_filter_workspace_bytes(-1) == 0
     assert L.srf_points_filter(None, 10, 2, None, 0.0, None, None, None, None, None) == -1      # nf < 3 / no counter
     assert L.srf_image_prepare(None, 6, 900, 1600, _lib.hf([0, 0, 0]), _lib.hf([1, 1, 1]), 0, 928, 1602, None, None) == -1  # Wp % 4
