@@ -2409,6 +2409,97 @@ __global__ __launch_bounds__(256) void srf_spconv_c16_k(const float *__restrict_
     }
 }
 
+// srf_spconv_c16l_k: the same 16-row waves with the weights in LDS instead of 108 registers per lane, and the gathers in nine batches
+// of three offsets, three batches in flight (36 registers): ~100 registers per lane = five waves per SIMD instead of two.  The kernel
+// is bound by the latency of its gathers (three dependent batches per wave, two waves per SIMD to hide them): at nuScenes size every wave
+// of the level is resident at once either way (26k rows = 6 waves per CU), at Waymo size (138k rows = 34 waves per CU) the register form
+// runs 4.3 rounds of 8 waves per CU.  Same chain per output (offset ascending, channel ascending): identical bits.
+template <int STEPS>  // ceil(Cin / 4)
+__global__ __launch_bounds__(256) void srf_spconv_c16l_k(const float *__restrict__ in, int Cin, const float *__restrict__ W, int K,
+                                                       const int *__restrict__ nbr, int nbr_stride, int A_out,
+                                                       const float *__restrict__ alpha, const float *__restrict__ beta,
+                                                       const float *__restrict__ residual, int relu, float *__restrict__ out,
+                                                       const int *__restrict__ rows_dev)
+{
+    constexpr int COUT = 16, KM = SRF_KMAX, G = 3, NBATCH = KM / G, D = 3;
+    __shared__ float s_w[KM * STEPS * 64];   // [k][j][lane]: lane (col r, q) holds W[k][4 j + q][r]
+    if (rows_dev) {
+        const int live = *rows_dev;
+        A_out = A_out < live ? A_out : live;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    for (int e = tid; e < KM * STEPS * 64; e += 256) {
+        const int l = e & 63, kj = e >> 6, k = kj / STEPS, j = kj - k * STEPS;
+        const int c = 4 * j + (l >> 4);
+        s_w[e] = (k < K && c < Cin) ? W[((size_t)k * Cin + c) * COUT + (l & 15)] : 0.f;
+    }
+    __syncthreads();   // the only barrier: the waves are independent from here on
+    const int row0 = (blockIdx.x * 4 + wave) * 16;
+    if (row0 >= A_out) return;
+    const int row = row0 + r;
+    const int row_ld = row < A_out ? row : A_out - 1;
+    int idx[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) idx[k] = nbr[(size_t)(k < K ? k : K - 1) * nbr_stride + row_ld];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) idx[k] = (k < K && row < A_out) ? idx[k] : -1;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float a[D][G][STEPS];
+#define C16L_LOAD(SET, B)                                                                                              \
+    _Pragma("unroll") for (int t_ = 0; t_ < G; ++t_)                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < STEPS; ++j_) {                                                         \
+            const int k_ = (B) * G + t_, c_ = 4 * j_ + q;                                                              \
+            a[SET][t_][j_] = (idx[k_] >= 0 && c_ < Cin) ? in[(size_t)idx[k_] * Cin + c_] : 0.f;                        \
+        }
+    C16L_LOAD(0, 0)
+    C16L_LOAD(1, 1)
+#pragma unroll
+    for (int b = 0; b < NBATCH; ++b) {
+        if (b + 2 < NBATCH) { C16L_LOAD((b + 2) % D, b + 2) }
+        float wv[G][STEPS];
+#pragma unroll
+        for (int t = 0; t < G; ++t)
+#pragma unroll
+            for (int j = 0; j < STEPS; ++j) wv[t][j] = s_w[((b * G + t) * STEPS + j) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < G; ++t)
+#pragma unroll
+            for (int j = 0; j < STEPS; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b % D][t][j], wv[t][j], acc, 0, 0, 0);
+    }
+#undef C16L_LOAD
+    const float al = alpha ? alpha[r] : 1.f, be = alpha ? beta[r] : 0.f;
+    float res[4];
+    if (residual) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int orow = row0 + q * 4 + i;
+            res[i] = residual[(size_t)(orow < A_out ? orow : A_out - 1) * COUT + r];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int orow = row0 + q * 4 + i;
+        float v = acc[i];
+        if (alpha) v = __fmaf_rn(v, al, be);
+        if (residual) v = __fadd_rn(v, res[i]);
+        if (relu) v = v > 0.f ? v : 0.f;
+        if (orow < A_out) out[(size_t)orow * COUT + r] = v;
+    }
+}
+
+#ifndef SRF_C16L_MIN_ROWS
+#define SRF_C16L_MIN_ROWS 60000   /* measured (MI355X): 26k rows 14.1 -> 14.7 us (every wave resident at once either way), 99k rows 47.9 -> 35.1 us */
+#endif
+static bool srf_c16l_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("SRF_SPCONV_C16L");   // developer switch: 0 = the register-weight form (A/B timing; identical bits)
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 extern "C" int srf_spconv_fwd(const float *in, int A_in, int Cin, const float *W, int K, const int *nbr, int nbr_stride,
                               int A_out, int Cout, const float *alpha, const float *beta, const float *residual,
                               int relu, float *out, const int *rows_dev, srf_stream_t stream)
@@ -2423,10 +2514,15 @@ extern "C" int srf_spconv_fwd(const float *in, int A_in, int Cin, const float *W
     switch (Cout) {
     case 16:
         if (Cin <= 16 && K == SRF_KMAX && A_in > 0) {  // register-resident weights, LDS-free gather
-            if (Cin <= 8)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_c16_k<2>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0, st, SRF_ARGS);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_c16_k<4>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0, st, SRF_ARGS);
+            // many rows (Waymo's first level): the LDS-weight form, five waves per SIMD; few rows: every wave is resident at once anyway
+            const bool lds_w = srf_c16l_enabled() && A_out >= SRF_C16L_MIN_ROWS;
+            if (Cin <= 8) {
+                if (lds_w) hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_c16l_k<2>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0, st, SRF_ARGS);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_c16_k<2>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0, st, SRF_ARGS);
+            } else {
+                if (lds_w) hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_c16l_k<4>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0, st, SRF_ARGS);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_c16_k<4>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0, st, SRF_ARGS);
+            }
         } else {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(srf_spconv_mfma16_k<64>), dim3(srf_ceil_div(A_out, 64)), dim3(256), 0, st,
                                SRF_ARGS);

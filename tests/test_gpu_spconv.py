@@ -166,6 +166,25 @@ def test_spconv_tiles_with_padded_rows(dev, C):
     assert np.array_equal(got[:A].cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("cin", [5, 16])
+def test_spconv_c16_lds_weight_form_is_bit_identical(dev, cin):
+    """srf_spconv_c16l_k (weights in LDS, five waves per SIMD; taken from 60k rows up) against the oracle and the register-weight form on
+    a level large enough to select it (70k rows: three sweeps stacked as a batch of three)"""
+    rng = np.random.default_rng(cin)
+    idx = _level1(n=30000, batch=3)
+    nbr, _ = O.rulebook_subm(idx, SHAPE1, [3, 3, 3])
+    assert nbr.shape[1] >= 60000
+    feats = rng.standard_normal((len(idx), cin)).astype(np.float32)
+    W = (rng.standard_normal((27, cin, 16)) / np.sqrt(cin * 3)).astype(np.float32)
+    res = rng.standard_normal((nbr.shape[1], 16)).astype(np.float32)
+    alpha = rng.uniform(0.5, 1.5, 16).astype(np.float32)
+    beta = rng.standard_normal(16).astype(np.float32)
+    ref = O.spconv_fwd(feats, W, nbr, alpha, beta, res, True)
+    tt = lambda x: torch.from_numpy(x).to(dev)
+    got = ops.spconv_fwd(tt(feats), tt(W), tt(nbr), tt(alpha), tt(beta), tt(res), True).cpu().numpy()
+    assert np.array_equal(got, ref)
+
+
 def test_spconv_vs_dense_torch_conv3d(dev):
     """independent check of the whole K4+K5 pair against torch's dense conv3d on a small grid (SubM semantics)."""
     rng = np.random.default_rng(0)
